@@ -1,0 +1,324 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by IMPORTING the real reference from /root/reference.
+
+Runs only in the build container (the reference does not exist on the GPU box and never travels).
+Nothing from the reference is copied: the reference modules are imported, loaded with the
+deterministic synthetic weights of ``dvqvae_amd.synth`` and executed on CPU; only inputs (when
+small), seeds and outputs are written.  Shims applied to make the reference's CPU forward run at
+all:
+
+  (1) ``network.vqvae.quantizer.device = cpu``            (quantizer.py:7 hard-codes cuda)
+  (2) ``Tensor.to('cuda') -> cpu``                         (gen_net.py:79-116 literals)
+  (3) ``network.DVQVAE.f0hand = <83 thumb vertices>``      (DVQVAE.py:93 uses an undefined name)
+  (4) prior restricted to the codebook range: ``output_conv.2.bias[128:] = -1e4``
+  (5) stand-in MANO layer = oracle/mano_oracle.ManoOracle on the synthetic MANO-shaped model
+  (6) ``Tensor.multinomial`` replaced by the exponential race ``argmax(p / q)`` with recorded q;
+      the equivalence with the real ``multinomial(1)`` under a replayed generator is asserted first.
+
+Usage:  python tools/make_golden.py            (writes tests/golden/)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+import dvqvae_amd  # noqa: E402  (alias of d-vqvae_amd/)
+from dvqvae_amd import synth  # noqa: E402
+from oracle import mano_oracle  # noqa: E402
+
+torch.set_num_threads(8)
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+SEED = 1234
+
+# ---- shims -------------------------------------------------------------------------------------
+import network.vqvae.quantizer as ref_quant  # noqa: E402
+
+ref_quant.device = torch.device("cpu")                                   # (1)
+_orig_to = torch.Tensor.to
+
+
+def _to_cpu(self, *a, **k):                                              # (2)
+    a = tuple("cpu" if (isinstance(x, str) and x.startswith("cuda")) else x for x in a)
+    if isinstance(k.get("device"), str) and k["device"].startswith("cuda"):
+        k["device"] = "cpu"
+    return _orig_to(self, *a, **k)
+
+
+torch.Tensor.to = _to_cpu
+
+import network.DVQVAE as ref_dvq  # noqa: E402
+from network.gen_net import GenNet as RefGenNet  # noqa: E402
+from network.pointnet_encoder import PointNetEncoder as RefPointNet  # noqa: E402
+from network.VQVAE import VQVAE as RefVQVAE  # noqa: E402
+from network.pixelcnn.models import GatedPixelCNN as RefPixelCNN  # noqa: E402
+
+THUMB = [240] + list(range(248, 254)) + [266, 267, 286, 287] + list(range(697, 769))
+ref_dvq.f0hand = THUMB                                                   # (3)
+
+
+class RaceSampler:
+    """(6) deterministic stand-in for Tensor.multinomial(1): argmax(p / q) with recorded q."""
+
+    def __init__(self):
+        self.q = None
+        self.pos = 0
+
+    def arm(self, q):
+        self.q, self.pos = q, 0
+
+    def __call__(self, probs, num_samples, *a, **k):
+        assert num_samples == 1
+        q = self.q[:, self.pos]
+        self.pos += 1
+        return torch.argmax(probs / q, dim=-1, keepdim=True)
+
+
+def check_multinomial_equivalence():
+    p = torch.softmax(torch.randn(5, 512, generator=torch.Generator().manual_seed(3)), -1)
+    torch.manual_seed(77)
+    a = p.multinomial(1).squeeze(1)
+    torch.manual_seed(77)
+    q = torch.empty_like(p).exponential_(1)
+    b = torch.argmax(p / q, dim=-1)
+    assert torch.equal(a, b), "multinomial(1) != exponential race on this torch build"
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrs.items()})
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def load_synth(module, seed=SEED, prefix=""):
+    sd = synth.synthetic_state_dict(module.state_dict(), seed)
+    module.load_state_dict(sd, strict=True)
+    module.eval()
+    return sd
+
+
+# ---- G1: PointNetEncoder -------------------------------------------------------------------------
+def g1_pointnet():
+    out = {}
+    for C, N, B in [(4, 64, 4), (4, 1024, 1), (4, 1024, 4), (4, 3000, 1), (3, 778, 4), (3, 100, 2)]:
+        net = RefPointNet(global_feat=True, feature_transform=False, channel=C)
+        load_synth(net, SEED + C)
+        x = synth.synthetic_clouds(B, N, seed=100 + N, channels=C)
+        with torch.no_grad():
+            feat, trans, _ = net(x)
+        tag = f"C{C}_N{N}_B{B}"
+        out[tag + "_feat"], out[tag + "_trans"] = feat, trans
+        if N <= 100:
+            out[tag + "_x"] = x
+    save("g1_pointnet", **out)
+
+
+# ---- G2/G3: VectorQuantizer / VQVAE ----------------------------------------------------------------
+def g2_vq():
+    out = {}
+    for K, D in [(128, 256), (128, 1024), (512, 256)]:
+        vq = RefVQVAE(128, 32, 2, K, D, 0.25, a=1)
+        E = synth.synthetic_normal((K, D), SEED, f"vq/E/{K}/{D}")
+        vq.vector_quantization.embedding.weight.data.copy_(E)
+        vq.eval()
+        for M in (1, 7, 4096):
+            z = synth.synthetic_normal((M, D), SEED, f"vq/z/{K}/{D}/{M}")
+            with torch.no_grad():
+                idx, zq = vq.inference(z)
+                d64 = ((z.double()[:, None, :] - E.double()[None]) ** 2).sum(-1) if M <= 7 else \
+                    (z.double() ** 2).sum(1, keepdim=True) + (E.double() ** 2).sum(1) - 2 * z.double() @ E.double().t()
+            top2 = torch.topk(d64, 2, dim=1, largest=False)[0]
+            tag = f"K{K}_D{D}_M{M}"
+            out[tag + "_idx"] = idx.squeeze(1).to(torch.int32)
+            out[tag + "_gap"] = (top2[:, 1] - top2[:, 0]).float()
+            out[tag + "_zq_rowsum"] = zq.double().sum(1).float()
+            assert torch.equal(zq, E[idx.squeeze(1)])
+        # reference-init regime (quantizer.py:27): E ~ U(+-1/K): tie-prone, gaps tiny
+        Eu = synth.synthetic_uniform((K, D), SEED, f"vq/Eu/{K}/{D}", -1.0 / K, 1.0 / K)
+        vq.vector_quantization.embedding.weight.data.copy_(Eu)
+        z = synth.synthetic_normal((512, D), SEED, f"vq/zu/{K}/{D}")
+        with torch.no_grad():
+            idx, _ = vq.inference(z)
+            d64 = (z.double() ** 2).sum(1, keepdim=True) + (Eu.double() ** 2).sum(1) - 2 * z.double() @ Eu.double().t()
+        top2 = torch.topk(d64, 2, dim=1, largest=False)[0]
+        out[f"K{K}_D{D}_uinit_idx"] = idx.squeeze(1).to(torch.int32)
+        out[f"K{K}_D{D}_uinit_gap"] = (top2[:, 1] - top2[:, 0]).float()
+    # crafted rows: duplicated codebook rows (exact tie -> lowest index), NaN row, Inf row
+    K, D = 128, 256
+    vq = RefVQVAE(128, 32, 2, K, D, 0.25, a=1)
+    E = synth.synthetic_normal((K, D), SEED, "vq/E/crafted")
+    E[77] = E[5]
+    E[100] = E[5]
+    z = synth.synthetic_normal((6, D), SEED, "vq/z/crafted")
+    z[0] = E[5]                     # exact tie between rows 5, 77, 100 -> 5
+    z[1] = E[77] * 1.0              # same
+    z[2, 3] = float("nan")          # NaN row -> every distance NaN -> index 0
+    z[3, 9] = float("inf")          # Inf row -> inf - inf = NaN everywhere -> index 0
+    z[4] = 0.0
+    vq.vector_quantization.embedding.weight.data.copy_(E)
+    with torch.no_grad():
+        idx, _ = vq.inference(z)
+    out["crafted_idx"] = idx.squeeze(1).to(torch.int32)
+    out["crafted_z"], out["crafted_E"] = z, E
+    # G3: train-mode forward (loss, perplexity)
+    vq.train()
+    zt = synth.synthetic_normal((64, D), SEED, "vq/z/train")
+    with torch.no_grad():
+        loss, zq, perp = vq(zt)
+    out["train_loss"], out["train_perplexity"], out["train_zq_rowsum"] = loss, perp, zq.double().sum(1).float()
+    save("g2_vq", **out)
+
+
+# ---- G4/G5: GatedPixelCNN ---------------------------------------------------------------------------
+def g4_pixelcnn(sampler):
+    out = {}
+    # reduced net (weights regenerated from the seed in tests)
+    small = RefPixelCNN(input_dim=32, dim=64, n_layers=3, n_classes=16)
+    load_synth(small, SEED + 1)
+    g = np.random.Generator(np.random.Philox(key=SEED))
+    x = torch.from_numpy(g.integers(0, 32, size=(5, 3, 3)))
+    lab = torch.from_numpy(g.integers(0, 16, size=(5,)))
+    with torch.no_grad():
+        out["small_logits"] = small(x, lab)
+    out["small_x"], out["small_label"] = x, lab
+    q = synth.exp1_noise(5, 9, 32, seed=5)
+    sampler.arm(q)
+    with torch.no_grad():
+        out["small_codes"] = small.generate(None, lab, shape=(3, 3), batch_size=5)
+    # full-size prior
+    full = RefPixelCNN(512, 512, 15)
+    load_synth(full, SEED + 2)
+    x = torch.from_numpy(g.integers(0, 512, size=(2, 3, 3)))
+    lab = torch.from_numpy(g.integers(0, 128, size=(2,)))
+    with torch.no_grad():
+        out["full_logits"] = full(x, lab)
+    out["full_x"], out["full_label"] = x, lab
+    codes = []
+    labs = torch.tensor([0, 17, 64, 127])
+    qf = synth.exp1_noise(4, 9, 512, seed=6)
+    for b in range(4):                              # the reference's generate is called with B=1
+        sampler.arm(qf[b:b + 1])
+        with torch.no_grad():
+            codes.append(full.generate(None, labs[b:b + 1], shape=(3, 3), batch_size=1))
+    out["full_codes"], out["full_gen_label"] = torch.cat(codes), labs
+    save("g4_pixelcnn", **out)
+
+
+# ---- G6: Decoder ------------------------------------------------------------------------------------
+def g6_decoder():
+    out = {}
+    for tag, sizes, lat in [("dec", [1024, 256, 55], 2560), ("pos", [1024, 128, 6], 2048)]:
+        dec = ref_dvq.Decoder(layer_sizes=sizes, latent_size=lat)
+        load_synth(dec, SEED + 3)
+        z = synth.synthetic_normal((5, lat), SEED, f"dec/z/{tag}")
+        with torch.no_grad():
+            out[tag + "_y"] = dec(z)
+    save("g6_decoder", **out)
+
+
+# ---- G7: GenNet.gen end to end (config 1: 1 object x 8 grasps, reference called with B=1) -----------
+class RefManoStandIn:
+    """(5) quacks like the ``mano`` layer: .eval(), __call__(betas=, global_orient=, hand_pose=, transl=).vertices"""
+
+    def __init__(self, oracle):
+        self.oracle = oracle
+
+    def eval(self):
+        return self
+
+    def __call__(self, betas, global_orient, hand_pose, transl):
+        return types.SimpleNamespace(vertices=self.oracle(betas, hand_pose, global_orient, transl))
+
+
+def g7_gen(sampler):
+    net = RefGenNet()
+    sd = synth.synthetic_state_dict(net.state_dict(), SEED)
+    sd["GatedPixelCNN.output_conv.2.bias"][128:] = -1e4                       # (4)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    mano = mano_oracle.ManoOracle(mano_oracle.synthetic_mano_arrays())
+    net.set_rh_mano(RefManoStandIn(mano))
+    n_obj, N = 8, 1024
+    obj = synth.synthetic_clouds(n_obj, N, seed=42)
+    q = synth.exp1_noise(n_obj, 9, 512, seed=43)
+    rec, pos, codes, idx6s, feats = [], [], [], [], []
+    for b in range(n_obj):
+        sampler.arm(q[b:b + 1])
+        captured = {}
+        orig_gen = net.GatedPixelCNN.generate
+
+        def spy(*a, _o=orig_gen, **k):
+            r = _o(*a, **k)
+            captured["codes"] = r.clone()
+            return r
+
+        net.GatedPixelCNN.generate = spy
+        with torch.no_grad():
+            r, p = net.gen(obj[b:b + 1])
+            f, _, _ = net.obj_encoder_type(obj[b:b + 1])
+            i6, _ = net.vqvae6.inference(f)
+        net.GatedPixelCNN.generate = orig_gen
+        rec.append(r); pos.append(p); codes.append(captured["codes"]); idx6s.append(i6); feats.append(f)
+    feats = torch.cat(feats)
+    E6 = sd["vqvae6.vector_quantization.embedding.weight"].double()
+    d64 = (feats.double() ** 2).sum(1, keepdim=True) + (E6 ** 2).sum(1) - 2 * feats.double() @ E6.t()
+    top2 = torch.topk(d64, 2, dim=1, largest=False)[0]
+    save("g7_gen", recon=torch.cat(rec), recon_pos=torch.cat(pos), codes=torch.cat(codes),
+         idx6=torch.cat(idx6s).squeeze(1), idx6_gap=(top2[:, 1] - top2[:, 0]).float(),
+         feat_type=feats, n_points=N, cloud_seed=42, noise_seed=43)
+
+
+def g7_gen_juice(sampler):
+    """Re-run the juice case on the fp16-rounded cloud actually stored (keeps the fixture small and exact)."""
+    net = RefGenNet()
+    sd = synth.synthetic_state_dict(net.state_dict(), SEED)
+    sd["GatedPixelCNN.output_conv.2.bias"][128:] = -1e4
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    net.set_rh_mano(RefManoStandIn(mano_oracle.ManoOracle(mano_oracle.synthetic_mano_arrays())))
+    pts = np.load(os.path.join(REF, "models/Object_models/juice_model/juice_modelresampled.npy"))
+    diag = np.linalg.norm(pts.max(0) - pts.min(0))
+    pc = np.concatenate([pts.T, np.full((1, pts.shape[0]), diag)], 0).astype(np.float16)[None]
+    pc_t = torch.from_numpy(pc.astype(np.float32))
+    q = synth.exp1_noise(8, 9, 512, seed=43)
+    sampler.arm(q[:1])
+    with torch.no_grad():
+        r, p = net.gen(pc_t)
+    save("g7_gen_juice", obj_f16=pc, recon=r, recon_pos=p)
+
+
+# ---- G8: DVQVAE.forward eval --------------------------------------------------------------------------
+def g8_dvqvae():
+    net = ref_dvq.DVQVAE(obj_inchannel=4)
+    load_synth(net, SEED + 8)
+    B = 3
+    obj = synth.synthetic_clouds(B, 512, seed=80)
+    hand = synth.synthetic_normal((B, 3, 778), SEED, "dvq/hand", 0.05)
+    with torch.no_grad():
+        emb_idx, obj_emb = net(obj, hand)
+    save("g8_dvqvae", emb_idx=emb_idx.squeeze(1), obj_emb=obj_emb)
+
+
+def main():
+    check_multinomial_equivalence()
+    sampler = RaceSampler()
+    torch.Tensor.multinomial = lambda self, n, *a, **k: sampler(self, n, *a, **k)   # (6)
+    g1_pointnet()
+    g2_vq()
+    g4_pixelcnn(sampler)
+    g6_decoder()
+    g7_gen(sampler)
+    g7_gen_juice(sampler)
+    g8_dvqvae()
+
+
+if __name__ == "__main__":
+    main()
