@@ -1,0 +1,98 @@
+// Internal declarations shared by the HIP translation units of libdvq_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/dvq.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void dvq_set_error(const char* fmt, ...);
+
+#define DVQ_REQUIRE(cond, ...)                      \
+    do {                                            \
+        if (!(cond)) {                              \
+            dvq_set_error(__VA_ARGS__);             \
+            return DVQ_EINVAL;                      \
+        }                                           \
+    } while (0)
+
+#define DVQ_CHECK_LAUNCH(what)                                                        \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess) {                                                      \
+            dvq_set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e__)); \
+            return DVQ_ELAUNCH;                                                       \
+        }                                                                             \
+    } while (0)
+
+#define DVQ_PROPAGATE(expr)        \
+    do {                           \
+        int rc__ = (expr);         \
+        if (rc__ != DVQ_OK) return rc__; \
+    } while (0)
+
+static inline bool dvq_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline size_t dvq_round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---------------------------------------------------------------- fp32 MFMA GEMM with fused epilogues
+enum GemmEpilogue {
+    EPI_BIAS = 0,    // out = act(acc + bias)
+    EPI_RESID = 1,   // out = acc + bias + resid
+    EPI_GATE = 2,    // out = tanh(a) * sigmoid(b) over gate-packed channel pairs (+ optional pre-gate store)
+    EPI_COLMAX = 3,  // per-tile column max over valid rows -> partial[tile_m][N]
+    EPI_ARGMIN = 4   // A = codebook, W = z rows: per z row, (min, argmin) of (zz+ee)-2*acc over the tile's entries
+};
+
+struct GemmSrc {
+    const float* A;
+    const float* W;
+    long lda, ldw;
+    int K;
+    int pad_;
+};
+
+struct GemmParams {
+    GemmSrc src[DVQ_MAX_SRC];
+    int nsrc;
+    int N;
+    long M;
+    const float* bias;   // [N] or null
+    float* out;          // EPI_BIAS/RESID: [M,N]; EPI_GATE: [M,N/2]
+    long ldo;
+    int relu;
+    // EPI_RESID
+    const float* resid;
+    long ldr;
+    // EPI_GATE
+    const float* cls;        // [n_classes][N] gate-packed, or null
+    const int64_t* label;    // [M]
+    float* pre;              // optional pre-gate output [M,N] (acc + bias, gate-packed order)
+    long ldpre;
+    // EPI_COLMAX
+    int rows_per_group;      // padded rows per sample (multiple of 128)
+    int valid_rows;          // real rows per sample
+    float* partial;          // [M/128][N]
+    // EPI_ARGMIN (A rows = codebook entries, W rows = z rows)
+    const float* row_norm;   // ee[M]
+    const float* col_norm;   // zz[N]
+    float* part_val;         // [tiles_m][N]
+    int* part_idx;           // [tiles_m][N]
+};
+
+// torch.argmin ordering: a NaN beats everything, among equals the lower index wins
+__device__ __forceinline__ bool dvq_argmin_better(float v, int i, float bv, int bi) {
+    const bool vn = v != v, bn = bv != bv;
+    if (vn || bn) return vn && (!bn || i < bi);
+    return v < bv || (v == bv && i < bi);
+}
+
+int dvq_launch_gemm(const GemmParams& p, GemmEpilogue epi, hipStream_t stream);
+
+// simple helpers implemented in misc.hip
+int dvq_launch_gather_rows(const float* table, const int64_t* idx, long idx_stride, long M, int K, int D,
+                           float* out, long ldo, int32_t* err_flag, hipStream_t stream);
+int dvq_launch_colmax_reduce(const float* partial, long groups, int tiles_per_group, int N, int relu,
+                             float* out, long ldo, hipStream_t stream);

@@ -1,0 +1,156 @@
+// Error plumbing and the small data-movement kernels of the path (gathers, concatenations, reductions).
+#include "dvq_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void dvq_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* dvq_last_error(void) { return g_err; }
+extern "C" int dvq_abi_version(void) { return 1; }
+extern "C" int dvq_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+namespace {
+
+// out[m, 0:D] = table[idx[m*idx_stride], 0:D]; out-of-range index -> zeros + error flag
+__global__ void gather_rows_kernel(const float* __restrict__ table, const int64_t* __restrict__ idx, long idx_stride,
+                                   long M, int K, int D, float* __restrict__ out, long ldo, int32_t* err_flag) {
+    const int lanes_per_row = D / 4;     // D % 4 == 0
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long m = gid / lanes_per_row;
+    const int c4 = (int)(gid % lanes_per_row);
+    if (m >= M) return;
+    const int64_t k = idx[m * idx_stride];
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (k >= 0 && k < K) {
+        v = *reinterpret_cast<const f32x4*>(table + k * D + c4 * 4);
+    } else if (c4 == 0 && err_flag) {
+        *err_flag = 1;
+    }
+    *reinterpret_cast<f32x4*>(out + m * ldo + c4 * 4) = v;
+}
+
+__global__ void colmax_reduce_kernel(const float* __restrict__ partial, long groups, int tiles, int N, int relu,
+                                     float* __restrict__ out, long ldo) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long g = gid / N;
+    const int n = (int)(gid % N);
+    if (g >= groups) return;
+    float mx = -INFINITY;
+    for (int t = 0; t < tiles; ++t) mx = fmaxf(mx, partial[(g * tiles + t) * N + n]);
+    if (relu) mx = fmaxf(mx, 0.f);
+    out[g * ldo + n] = mx;
+}
+
+__global__ void copy_cols_kernel(const float* __restrict__ src, long lds, long M, int W, float* __restrict__ out, long ldo) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int w4 = W / 4;
+    const long m = gid / w4;
+    const int c4 = (int)(gid % w4);
+    if (m >= M) return;
+    *reinterpret_cast<f32x4*>(out + m * ldo + c4 * 4) = *reinterpret_cast<const f32x4*>(src + m * lds + c4 * 4);
+}
+
+__global__ void assemble61_kernel(const float* __restrict__ recon, const float* __restrict__ pos, long B, float* __restrict__ out) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long b = gid / 61;
+    const int c = (int)(gid % 61);
+    if (b >= B) return;
+    float v;
+    if (c < 10) v = recon[b * 55 + c];
+    else if (c < 13) v = pos[b * 6 + (c - 10)];
+    else if (c < 58) v = recon[b * 55 + (c - 3)];
+    else v = pos[b * 6 + 3 + (c - 58)];
+    out[b * 61 + c] = v;
+}
+
+__global__ void transform_cloud_kernel(const float* __restrict__ pc, long pc_bstride, const float* __restrict__ R,
+                                       const float* __restrict__ t, long B, int C, int N, float* __restrict__ out) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long b = gid / N;
+    const int n = (int)(gid % N);
+    if (b >= B) return;
+    const float* src = pc + b * pc_bstride;
+    const float x = src[n], y = src[N + n], z = src[2 * N + n];
+    const float* r = R + b * 9;
+    float* dst = out + b * (long)C * N;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float v = r[i * 3 + 0] * x;
+        v = fmaf(r[i * 3 + 1], y, v);
+        v = fmaf(r[i * 3 + 2], z, v);
+        dst[i * N + n] = v + (t ? t[i] : 0.f);
+    }
+    for (int c = 3; c < C; ++c) dst[c * N + n] = src[c * N + n];
+}
+
+}  // namespace
+
+int dvq_launch_gather_rows(const float* table, const int64_t* idx, long idx_stride, long M, int K, int D, float* out,
+                           long ldo, int32_t* err_flag, hipStream_t stream) {
+    DVQ_REQUIRE(table && idx && out, "gather: null pointer");
+    DVQ_REQUIRE(D % 4 == 0 && ldo % 4 == 0 && dvq_aligned16(table) && dvq_aligned16(out), "gather: rows not 16-byte aligned");
+    if (M == 0) return DVQ_OK;
+    const long total = M * (D / 4);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, table, idx,
+                       idx_stride, M, K, D, out, ldo, err_flag);
+    DVQ_CHECK_LAUNCH("gather_rows");
+    return DVQ_OK;
+}
+
+int dvq_launch_colmax_reduce(const float* partial, long groups, int tiles_per_group, int N, int relu, float* out,
+                             long ldo, hipStream_t stream) {
+    const long total = groups * N;
+    hipLaunchKernelGGL(colmax_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, partial, groups,
+                       tiles_per_group, N, relu, out, ldo);
+    DVQ_CHECK_LAUNCH("colmax_reduce");
+    return DVQ_OK;
+}
+
+extern "C" int dvq_vq_lookup(const float* E, const int64_t* idx, int64_t idx_stride, int64_t M, int K, int D, float* out,
+                             int64_t ldo, int32_t* err_flag, dvq_stream_t stream) {
+    DVQ_REQUIRE(K > 0 && D > 0 && M >= 0 && idx_stride >= 1, "vq_lookup: bad shape M=%ld K=%d D=%d", (long)M, K, D);
+    return dvq_launch_gather_rows(E, idx, idx_stride, M, K, D, out, ldo, err_flag, (hipStream_t)stream);
+}
+
+extern "C" int dvq_copy_cols(const float* src, int64_t lds, int64_t M, int W, float* out, int64_t ldo, dvq_stream_t stream) {
+    DVQ_REQUIRE(src && out, "copy_cols: null pointer");
+    DVQ_REQUIRE(W % 4 == 0 && lds % 4 == 0 && ldo % 4 == 0 && dvq_aligned16(src) && dvq_aligned16(out),
+                "copy_cols: rows not 16-byte aligned");
+    if (M == 0) return DVQ_OK;
+    const long total = M * (W / 4);
+    hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       (long)lds, (long)M, W, out, (long)ldo);
+    DVQ_CHECK_LAUNCH("copy_cols");
+    return DVQ_OK;
+}
+
+extern "C" int dvq_assemble61(const float* recon, const float* recon_pos, int64_t B, float* out, dvq_stream_t stream) {
+    DVQ_REQUIRE(recon && recon_pos && out, "assemble61: null pointer");
+    if (B == 0) return DVQ_OK;
+    const long total = B * 61;
+    hipLaunchKernelGGL(assemble61_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, recon,
+                       recon_pos, (long)B, out);
+    DVQ_CHECK_LAUNCH("assemble61");
+    return DVQ_OK;
+}
+
+extern "C" int dvq_transform_cloud(const float* pc, int64_t pc_batch_stride, const float* R, const float* t, int64_t B,
+                                   int C, int N, float* out, dvq_stream_t stream) {
+    DVQ_REQUIRE(pc && R && out, "transform_cloud: null pointer");
+    DVQ_REQUIRE(C >= 3 && N > 0, "transform_cloud: bad shape C=%d N=%d", C, N);
+    if (B == 0) return DVQ_OK;
+    const long total = B * N;
+    hipLaunchKernelGGL(transform_cloud_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       pc, (long)pc_batch_stride, R, t, (long)B, C, N, out);
+    DVQ_CHECK_LAUNCH("transform_cloud");
+    return DVQ_OK;
+}

@@ -1,0 +1,287 @@
+// Gated PixelCNN prior on the 3x3 latent grid: cached (incremental) sampler and teacher-forced forward.
+// Reference: GatedPixelCNN.generate / .forward, network/pixelcnn/models.py:161-198 with
+// GatedMaskedConv2d.forward :65-88.  The network is exactly causal, so every grid position is evaluated
+// once: the vertical stack of row r (all layers, 3 columns) as soon as rows < r are sampled, then the
+// horizontal stack + head position by position.  Every conv tap is one K=dim source of a multi-source
+// fp32-MFMA GEMM whose epilogue applies bias + class-conditional bias + tanh*sigmoid gate (gate-packed
+// channels) or the residual add; taps that fall into the zero padding are simply skipped.
+//
+// Geometry (models.py:41-55): layer 0 has k=5 and mask 'A' (last kernel row of the vertical stack and
+// last kernel column of the horizontal stack are zero: applied by skipping those taps), layers >= 1
+// have k=3 (mask 'B').  vertical: kernel (k/2+1, k), pad (k/2, k/2), output row r sees rows r-k/2..r;
+// horizontal: kernel (1, k/2+1), pad (0, k/2), output col c sees cols c-k/2..c.
+#include "dvq_internal.h"
+
+namespace {
+
+constexpr int GRID = 3, NPOS = 9;
+
+__global__ void sanitize_labels_kernel(const int64_t* __restrict__ label, long B, int n_classes, int64_t* __restrict__ out,
+                                       int32_t* err_flag) {
+    const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int64_t l = label[b];
+    if (l < 0 || l >= n_classes) {
+        if (err_flag) *err_flag = 1;
+        l = 0;
+    }
+    out[b] = l;
+}
+
+// out = gate(bias + cls[label]) (and pre = bias) for a position with no in-range taps
+__global__ void bias_gate_kernel(const float* __restrict__ bias, const float* __restrict__ cls, const int64_t* __restrict__ label,
+                                 long M, int dim, float* __restrict__ out, float* __restrict__ pre) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long m = gid / dim;
+    const int c = (int)(gid % dim);
+    if (m >= M) return;
+    // gate-packed index of natural channel c: block c/64, wave (c%64)/32, lane c%32; sigmoid partner +32
+    const int na = (c / 64) * 128 + ((c % 64) / 32) * 64 + (c % 32);
+    const int nb = na + 32;
+    float a = bias[na], g = bias[nb];
+    if (pre) {
+        pre[m * 2 * dim + na] = a;
+        pre[m * 2 * dim + nb] = g;
+    }
+    const float* crow = cls + label[m] * 2 * dim;
+    a += crow[na];
+    g += crow[nb];
+    out[m * dim + c] = tanhf(a) * (1.0f / (1.0f + expf(-g)));
+}
+
+// One wave per sample: p = softmax(logits); code = argmax_k p_k / q_k (exponential race, lowest k on ties);
+// then the token embedding of the drawn code is written as level-0 activation of this position.
+__global__ void sample_kernel(const float* __restrict__ logits, const float* __restrict__ noise /* [B,9,n_in] at this chunk */,
+                              int pos, int n_in, long Bc, const int64_t* __restrict__ forced /* [B,9] or null */,
+                              int64_t* __restrict__ codes /* [B,9] */, const float* __restrict__ tok_emb, int dim,
+                              float* __restrict__ x0 /* [Bc,dim] */, float* __restrict__ logits_out /* [B,9,n_in] or null */,
+                              int32_t* err_flag) {
+    const int lane = threadIdx.x & 63;
+    const long b = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= Bc) return;
+    const float* lg = logits + b * n_in;
+    int64_t code;
+    if (logits_out)
+        for (int k = lane; k < n_in; k += 64) logits_out[(b * NPOS + pos) * n_in + k] = lg[k];
+    if (forced) {
+        code = forced[b * NPOS + pos];
+        if (code < 0 || code >= n_in) {
+            if (lane == 0 && err_flag) *err_flag = 1;
+            code = 0;
+        }
+    } else {
+        float mx = -INFINITY;
+        for (int k = lane; k < n_in; k += 64) mx = fmaxf(mx, lg[k]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+        for (int k = lane; k < n_in; k += 64) sum += expf(lg[k] - mx);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float* q = noise + (b * NPOS + pos) * n_in;
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int k = lane; k < n_in; k += 64) {
+            const float p = expf(lg[k] - mx) / sum;
+            const float s = p / q[k];
+            if (s > best || (s == best && k < bi)) { best = s; bi = k; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (bi == 0x7fffffff) bi = 0;      // all scores NaN: torch.argmax would return the first NaN; keep 0
+        code = bi;
+        if (lane == 0) codes[b * NPOS + pos] = code;
+    }
+    const float* e = tok_emb + code * dim;
+    for (int c = lane * 4; c < dim; c += 256) *reinterpret_cast<f32x4*>(x0 + b * dim + c) = *reinterpret_cast<const f32x4*>(e + c);
+}
+
+struct Plan {
+    long chunk;
+    int L, dim;
+    float *xv, *xh, *hv, *g, *hid, *lg;
+    int64_t* lab;
+    size_t bytes;
+    float* XV(int level, int pos) const { return xv + ((size_t)level * NPOS + pos) * chunk * dim; }
+    float* XH(int level, int pos) const { return level == 0 ? XV(0, pos) : xh + ((size_t)(level - 1) * NPOS + pos) * chunk * dim; }
+    float* HV(int layer, int col) const { return hv + ((size_t)layer * GRID + col) * chunk * 2 * dim; }
+};
+
+Plan make_plan(const dvq_pixelcnn_weights* w, int64_t B, void* ws) {
+    Plan p;
+    p.L = w->n_layers;
+    p.dim = w->dim;
+    long chunk = 16384;
+    if (const char* e = getenv("DVQ_PIXELCNN_CHUNK")) {
+        const long v = atol(e);
+        if (v > 0) chunk = v;
+    }
+    if (chunk > B) chunk = B;
+    if (chunk < 1) chunk = 1;
+    p.chunk = chunk;
+    char* c = (char*)ws;
+    auto take = [&](size_t n) { char* q = c; c += dvq_round_up(n, 256); return q; };
+    p.xv = (float*)take((size_t)(p.L + 1) * NPOS * chunk * p.dim * 4);
+    p.xh = (float*)take((size_t)p.L * NPOS * chunk * p.dim * 4);
+    p.hv = (float*)take((size_t)p.L * GRID * chunk * 2 * p.dim * 4);
+    p.g = (float*)take((size_t)chunk * p.dim * 4);
+    p.hid = (float*)take((size_t)chunk * w->n_hidden * 4);
+    p.lg = (float*)take((size_t)chunk * w->n_in * 4);
+    p.lab = (int64_t*)take((size_t)chunk * 8);
+    p.bytes = (size_t)(c - (char*)ws);
+    return p;
+}
+
+int check_weights(const dvq_pixelcnn_weights* w) {
+    DVQ_REQUIRE(w && w->layers_host && w->tok_emb && w->w0 && w->b0 && w->w2 && w->b2, "pixelcnn: null weights");
+    DVQ_REQUIRE(w->n_layers >= 1 && w->dim >= 64 && w->dim % 64 == 0, "pixelcnn: dim=%d must be a multiple of 64", w->dim);
+    DVQ_REQUIRE(w->n_hidden % 32 == 0 && w->n_in >= 1 && w->n_classes >= 1, "pixelcnn: bad head sizes");
+    return DVQ_OK;
+}
+
+int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise, const int64_t* forced, int64_t B,
+        int64_t* codes, float* logits_out, int32_t* err_flag, void* ws, size_t ws_bytes, hipStream_t st) {
+    DVQ_PROPAGATE(check_weights(w));
+    DVQ_REQUIRE(B >= 0, "pixelcnn: negative batch");
+    if (B == 0) return DVQ_OK;
+    DVQ_REQUIRE(label && (forced || (noise && codes)), "pixelcnn: null input");
+    DVQ_REQUIRE(ws && dvq_aligned16(ws), "pixelcnn: null/unaligned workspace");
+    const Plan pl = make_plan(w, B, ws);
+    if (ws_bytes < pl.bytes) {
+        dvq_set_error("pixelcnn: workspace %zu < %zu bytes", ws_bytes, pl.bytes);
+        return DVQ_EWORKSPACE;
+    }
+    const int dim = w->dim, L = w->n_layers;
+    for (int64_t b0 = 0; b0 < B; b0 += pl.chunk) {
+        const long Bc = (long)((B - b0 < pl.chunk) ? (B - b0) : pl.chunk);
+        hipLaunchKernelGGL(sanitize_labels_kernel, dim3((unsigned)((Bc + 255) / 256)), dim3(256), 0, st, label + b0, Bc,
+                           w->n_classes, pl.lab, err_flag);
+        DVQ_CHECK_LAUNCH("sanitize_labels");
+        if (forced)   // teacher forcing: level-0 activations of all nine positions are known up front
+            for (int pos = 0; pos < NPOS; ++pos)
+                DVQ_PROPAGATE(dvq_launch_gather_rows(w->tok_emb, forced + b0 * NPOS + pos, NPOS, Bc, w->n_in, dim,
+                                                     pl.XV(0, pos), dim, err_flag, st));
+        for (int r = 0; r < GRID; ++r) {
+            // ---- vertical stack of row r, all layers (depends on rows < r only)
+            for (int l = 0; l < L; ++l) {
+                const dvq_pixelcnn_layer& ly = w->layers_host[l];
+                const int k = (l == 0) ? 5 : 3, pad = k / 2, KR = k / 2 + 1;
+                for (int c = 0; c < GRID; ++c) {
+                    GemmParams g = {};
+                    int ns = 0;
+                    for (int kr = 0; kr < KR; ++kr) {
+                        if (l == 0 && kr == KR - 1) continue;            // mask 'A': last kernel row
+                        const int ir = r - pad + kr;
+                        if (ir < 0) continue;
+                        for (int kc = 0; kc < k; ++kc) {
+                            const int ic = c - pad + kc;
+                            if (ic < 0 || ic >= GRID) continue;
+                            g.src[ns++] = GemmSrc{pl.XV(l, ir * GRID + ic), ly.wv + (size_t)(kr * k + kc) * 2 * dim * dim,
+                                                  (long)dim, (long)dim, dim, 0};
+                        }
+                    }
+                    float* out = pl.XV(l + 1, r * GRID + c);
+                    float* pre = pl.HV(l, c);
+                    if (ns == 0) {
+                        const long tot = Bc * dim;
+                        hipLaunchKernelGGL(bias_gate_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, ly.bv,
+                                           ly.cls, pl.lab, Bc, dim, out, pre);
+                        DVQ_CHECK_LAUNCH("bias_gate");
+                        continue;
+                    }
+                    g.nsrc = ns;
+                    g.M = Bc;
+                    g.N = 2 * dim;
+                    g.bias = ly.bv;
+                    g.cls = ly.cls;
+                    g.label = pl.lab;
+                    g.out = out;
+                    g.ldo = dim;
+                    g.pre = pre;
+                    g.ldpre = 2 * dim;
+                    DVQ_PROPAGATE(dvq_launch_gemm(g, EPI_GATE, st));
+                }
+            }
+            // ---- horizontal stack + head + draw, position by position
+            for (int c = 0; c < GRID; ++c) {
+                const int pos = r * GRID + c;
+                for (int l = 0; l < L; ++l) {
+                    const dvq_pixelcnn_layer& ly = w->layers_host[l];
+                    const int k = (l == 0) ? 5 : 3, pad = k / 2, KC = k / 2 + 1;
+                    GemmParams g = {};
+                    int ns = 0;
+                    g.src[ns++] = GemmSrc{pl.HV(l, c), ly.wv2h, (long)2 * dim, (long)2 * dim, 2 * dim, 0};
+                    for (int kc = 0; kc < KC; ++kc) {
+                        if (l == 0 && kc == KC - 1) continue;            // mask 'A': last kernel column
+                        const int ic = c - pad + kc;
+                        if (ic < 0) continue;
+                        g.src[ns++] = GemmSrc{pl.XH(l, r * GRID + ic), ly.wh + (size_t)kc * 2 * dim * dim, (long)dim, (long)dim,
+                                              dim, 0};
+                    }
+                    g.nsrc = ns;
+                    g.M = Bc;
+                    g.N = 2 * dim;
+                    g.bias = ly.bh;
+                    g.cls = ly.cls;
+                    g.label = pl.lab;
+                    g.out = pl.g;
+                    g.ldo = dim;
+                    DVQ_PROPAGATE(dvq_launch_gemm(g, EPI_GATE, st));
+                    GemmParams q = {};
+                    q.src[0] = GemmSrc{pl.g, ly.wr, (long)dim, (long)dim, dim, 0};
+                    q.nsrc = 1;
+                    q.M = Bc;
+                    q.N = dim;
+                    q.bias = ly.br;
+                    q.out = pl.XH(l + 1, pos);
+                    q.ldo = dim;
+                    if (l > 0) {                                        // residual only for layers >= 1 (:82-86)
+                        q.resid = pl.XH(l, pos);
+                        q.ldr = dim;
+                        DVQ_PROPAGATE(dvq_launch_gemm(q, EPI_RESID, st));
+                    } else {
+                        DVQ_PROPAGATE(dvq_launch_gemm(q, EPI_BIAS, st));
+                    }
+                }
+                GemmParams h0 = {};
+                h0.src[0] = GemmSrc{pl.XH(L, pos), w->w0, (long)dim, (long)dim, dim, 0};
+                h0.nsrc = 1; h0.M = Bc; h0.N = w->n_hidden; h0.bias = w->b0; h0.out = pl.hid; h0.ldo = w->n_hidden; h0.relu = 1;
+                DVQ_PROPAGATE(dvq_launch_gemm(h0, EPI_BIAS, st));
+                GemmParams h2 = {};
+                h2.src[0] = GemmSrc{pl.hid, w->w2, (long)w->n_hidden, (long)w->n_hidden, w->n_hidden, 0};
+                h2.nsrc = 1; h2.M = Bc; h2.N = w->n_in; h2.bias = w->b2; h2.out = pl.lg; h2.ldo = w->n_in;
+                DVQ_PROPAGATE(dvq_launch_gemm(h2, EPI_BIAS, st));
+                hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((Bc + 3) / 4)), dim3(256), 0, st, pl.lg,
+                                   noise ? noise + b0 * NPOS * w->n_in : nullptr, pos, w->n_in, Bc,
+                                   forced ? forced + b0 * NPOS : nullptr, codes ? codes + b0 * NPOS : nullptr, w->tok_emb, dim,
+                                   pl.XV(0, pos), logits_out ? logits_out + b0 * NPOS * w->n_in : nullptr, err_flag);
+                DVQ_CHECK_LAUNCH("pixelcnn_sample_step");
+            }
+        }
+    }
+    return DVQ_OK;
+}
+
+}  // namespace
+
+extern "C" size_t dvq_pixelcnn_workspace_bytes(const dvq_pixelcnn_weights* w, int64_t B) {
+    if (!w || B <= 0) return 256;
+    return make_plan(w, B, nullptr).bytes;
+}
+
+extern "C" int dvq_pixelcnn_sample(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise, int64_t B,
+                                   int64_t* codes, float* logits_out, int32_t* err_flag, void* workspace,
+                                   size_t workspace_bytes, dvq_stream_t stream) {
+    return run(w, label, noise, nullptr, B, codes, logits_out, err_flag, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int dvq_pixelcnn_forward(const dvq_pixelcnn_weights* w, const int64_t* x, const int64_t* label, int64_t B,
+                                    float* logits, int32_t* err_flag, void* workspace, size_t workspace_bytes,
+                                    dvq_stream_t stream) {
+    DVQ_REQUIRE(x && logits, "pixelcnn_forward: null pointer");
+    return run(w, label, nullptr, x, B, nullptr, logits, err_flag, workspace, workspace_bytes, (hipStream_t)stream);
+}

@@ -1,0 +1,98 @@
+"""GenNet mirror (reference: network/gen_net.py:13-125): the batched grasp-generation graph.
+
+Batched semantics = B independent B=1 reference calls (the reference's own ``gen`` only works for B=1:
+per-sample label instead of ``idx6[:,0,0]`` of sample 0, row-gather lookup instead of ``view(1,dim)``)."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .DVQVAE import Decoder, _codebooks
+from .pixelcnn.models import GatedPixelCNN
+from .pointnet_encoder import PointNetEncoder
+
+CODE_SLOTS = ((0, 1), (0, 2), (1, 1), (1, 2), (2, 1), (2, 2))     # grid position -> vqvae0..5 (gen_net.py:95-100)
+
+
+class GenNet(nn.Module):
+    def __init__(self, n_embeddings=128, prior_tokens=512, prior_dim=512, prior_layers=15, prior_classes=128):
+        """Defaults are the reference's fixed sizes (gen_net.py:17-34).  ``n_embeddings`` = 512 builds the
+        K=512 codebooks of the synthetic benchmark (prior emits 512 classes, checkpoint codebooks 128)."""
+        super().__init__()
+        self.obj_encoder_type = PointNetEncoder(global_feat=True, feature_transform=False, channel=4)
+        self.obj_encoder_pos = PointNetEncoder(global_feat=True, feature_transform=False, channel=4)
+        _codebooks(self, n_embeddings)
+        self.decoder = Decoder(layer_sizes=[1024, 256, 55], latent_size=2560)
+        self.num = 0
+        self.rh_mano = None
+        self.recon_encoder = PointNetEncoder(global_feat=True, feature_transform=False, channel=3)
+        self.pos_decoder = Decoder(layer_sizes=[1024, 128, 6], latent_size=2048)
+        self.GatedPixelCNN = GatedPixelCNN(prior_tokens, prior_dim, prior_layers, prior_classes)
+
+    def set_rh_mano(self, Rh_mano):
+        Rh_mano.eval()
+        self.rh_mano = Rh_mano
+
+    # ------------------------------------------------------------------------------------------
+    def _hand_vertices(self, recon):
+        """rh_mano(betas, global_orient=0, hand_pose, transl=0).vertices as [B,3,778] (gen_net.py:116-120)."""
+        m = self.rh_mano
+        if m is None:
+            raise RuntimeError("GenNet.gen: call set_rh_mano(layer) first (gen_diverse_grasp_obman.py:361)")
+        if hasattr(m, "vertices_channel_major"):
+            return m.vertices_channel_major(recon[:, :10], recon[:, 10:55])
+        zero = torch.zeros(recon.shape[0], 3, device=recon.device)
+        v = m(betas=recon[:, :10], global_orient=zero, hand_pose=recon[:, 10:55], transl=zero).vertices
+        return v.detach().permute(0, 2, 1).contiguous()
+
+    def _decode(self, codes, feat_type, feat_pos_into, err):
+        """codes [B,3,3] + object feature -> recon [B,55]; shared by gen and gen_byid."""
+        B, dev = codes.shape[0], codes.device
+        z_out = feat_type["z_out"]
+        flat = codes.view(B, 9)
+        for k, (i, j) in enumerate(CODE_SLOTS):
+            E = getattr(self, f"vqvae{k}").vector_quantization.embedding.weight.detach()
+            ops.vq_lookup(E, flat[:, i * 3 + j], out=z_out[:, 256 * k: 256 * (k + 1)], err=err)
+        return self.decoder(z_out).view(B, 55)
+
+    @torch.no_grad()
+    def gen(self, obj, noise=None, return_aux=False):
+        """obj [B,4,N] f32 on the GPU -> (recon [B,55], recon_pos [B,6]).
+        ``noise`` [B,9,prior_tokens] ~ Exp(1) fixes the prior's draws (parity runs); sampled on device if None."""
+        if obj.dim() != 3:
+            raise RuntimeError(f"gen: expected obj [B,4,N], got {tuple(obj.shape)}")
+        B, dev = obj.shape[0], obj.device
+        obj = obj.contiguous()
+        z_out = torch.empty(B, 2560, device=dev, dtype=torch.float32)      # [emb0..5 | obj_type_feature] (:109)
+        z_pos = torch.empty(B, 2048, device=dev, dtype=torch.float32)      # [hand_feat | obj_pos_feature]  (:121)
+        self.obj_encoder_type(obj, out=z_out[:, 1536:])                    # :81 written in place
+        self.obj_encoder_pos(obj, out=z_pos[:, 1024:])                     # :82
+        feat_type = z_out[:, 1536:]
+        idx6, _ = self.vqvae6.inference(feat_type)                         # :83 (obj_emb unused, as in the reference)
+        label = idx6[:, 0].contiguous()                                    # per-sample label
+        err = ops.new_err_flag(dev)
+        pk = self.GatedPixelCNN.packed()
+        if noise is None:
+            noise = torch.empty(B, 9, pk.n_in, device=dev, dtype=torch.float32).exponential_(1.0)
+        codes = ops.pixelcnn_sample(pk, label, noise.contiguous(), err=err)   # :92
+        recon = self._decode(codes, {"z_out": z_out}, None, err)           # :95-113
+        verts = self._hand_vertices(recon)                                 # :116-118
+        self.recon_encoder(verts, out=z_pos[:, :1024])                     # :120
+        recon_pos = self.pos_decoder(z_pos).view(B, 6)                     # :122-123
+        if int(err.item()) != 0:
+            raise RuntimeError("GenNet.gen: code or label index out of range (prior classes vs codebook rows, "
+                               "gen_net.py:20-34); build GenNet(n_embeddings=...) to match the prior")
+        if return_aux:
+            return recon, recon_pos, dict(idx6=idx6, codes=codes, feat_type=feat_type, feat_pos=z_pos[:, 1024:],
+                                          verts=verts, hand_feat=z_pos[:, :1024])
+        return recon, recon_pos
+
+    @torch.no_grad()
+    def gen_byid(self, idx6, noise=None):
+        """Debug variant (gen_net.py:41-75): samples codes for a given object code, then decodes an all-zero
+        latent (as the reference does) and returns zero wrist parameters."""
+        idx6 = idx6.reshape(-1).contiguous()
+        B, dev = idx6.shape[0], idx6.device
+        self.vqvae6.get_embbeding(idx6, 1024)                              # range check, value unused (:45)
+        self.GatedPixelCNN.generate(None, idx6, shape=(3, 3), batch_size=B, noise=noise)
+        recon = self.decoder(torch.zeros(B, 2560, device=dev)).view(B, 55)
+        return recon, torch.zeros(B, 6, device=dev)

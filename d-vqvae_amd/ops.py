@@ -1,0 +1,310 @@
+"""Tensor-level wrappers over the C ABI (include/dvq.h).
+
+PyTorch is used for device memory and streams only: every op validates its tensors (device, dtype,
+contiguity -> RuntimeError, the reference's error convention), allocates outputs/scratch through the
+torch caching allocator and enqueues the HIP work on torch's *current* stream.  No host sync inside.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+Tensor = torch.Tensor
+
+
+def _require_gpu(*ts: Tensor) -> torch.device:
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("dvq ops need tensors on a HIP device (there is no CPU fallback); got " + str(t.device))
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {t.device} vs {dev}")
+    return dev
+
+
+def _f32(t: Tensor, name: str) -> Tensor:
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+    return t
+
+
+def _i64(t: Tensor, name: str) -> Tensor:
+    if t.dtype != torch.int64:
+        raise RuntimeError(f"{name}: expected int64, got {t.dtype}")
+    return t
+
+
+def _rows(t: Tensor, name: str) -> Tuple[int, int]:
+    """(pointer, row stride) of a 2-D fp32 view whose rows are contiguous."""
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise RuntimeError(f"{name}: expected a 2-D tensor with contiguous rows, got shape {tuple(t.shape)} strides {t.stride()}")
+    return t.data_ptr(), (t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
+
+
+def _stream(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+_ws: Dict[Tuple[int, str], Tensor] = {}
+
+
+def workspace(nbytes: int, dev: torch.device, tag: str = "main") -> Tensor:
+    """Grow-only per-device scratch (stream-ordered reuse on torch's current stream)."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), tag)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        _ws.pop(key, None)
+        buf = None
+        buf = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=dev)
+        _ws[key] = buf
+    return buf
+
+
+def release_workspaces() -> None:
+    _ws.clear()
+
+
+def new_err_flag(dev: torch.device) -> Tensor:
+    return torch.zeros(1, dtype=torch.int32, device=dev)
+
+
+# ------------------------------------------------------------------------------------------ dense
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, relu: bool = False,
+           out: Optional[Tensor] = None) -> Tensor:
+    """y = act(x @ weight^T + bias) on the fp32 MFMA GEMM (dvq_linear)."""
+    return linear_multi([(x, weight)], bias, relu, out)
+
+
+def linear_multi(pairs: Sequence[Tuple[Tensor, Tensor]], bias: Optional[Tensor] = None, relu: bool = False,
+                 out: Optional[Tensor] = None) -> Tensor:
+    lib = _lib.load()
+    dev = _require_gpu(*[t for p in pairs for t in p], bias, out)
+    M = pairs[0][0].shape[0]
+    N = pairs[0][1].shape[0]
+    srcs = (_lib.GemmSrc * len(pairs))()
+    for i, (x, w) in enumerate(pairs):
+        _f32(x, "x"), _f32(w, "weight")
+        if x.shape[0] != M or w.shape[0] != N or x.shape[1] != w.shape[1]:
+            raise RuntimeError(f"linear: shape mismatch x{tuple(x.shape)} w{tuple(w.shape)}")
+        px, ldx = _rows(x, "x")
+        pw, ldw = _rows(w, "weight")
+        srcs[i] = _lib.GemmSrc(px, pw, ldx, ldw, x.shape[1], 0)
+    if bias is not None:
+        _f32(bias, "bias")
+        if bias.numel() != N or not bias.is_contiguous():
+            raise RuntimeError("linear: bias must be a contiguous [N] tensor")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=dev)
+    po, ldo = _rows(_f32(out, "out"), "out")
+    if out.shape[0] != M or out.shape[1] != N:
+        raise RuntimeError("linear: bad output shape")
+    with torch.cuda.device(dev):
+        check(lib.dvq_linear(srcs, len(pairs), M, N, bias.data_ptr() if bias is not None else None,
+                             1 if relu else 0, po, ldo, _stream(dev)), "dvq_linear")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ VQ
+def vq_argmin(z: Tensor, E: Tensor, return_dist: bool = False):
+    """idx[m] = argmin_k (|z_m|^2 + |E_k|^2) - 2 z_m.E_k, exact fp32, canonical order.  -> int64 [M]"""
+    lib = _lib.load()
+    dev = _require_gpu(z, E)
+    _f32(z, "z"), _f32(E, "E")
+    if not E.is_contiguous():
+        raise RuntimeError("vq_argmin: codebook must be contiguous")
+    pz, ldz = _rows(z, "z")
+    M, D = z.shape
+    K = E.shape[0]
+    if E.shape[1] != D:
+        raise RuntimeError(f"vq_argmin: z has D={D}, codebook has D={E.shape[1]}")
+    idx = torch.empty(M, dtype=torch.int64, device=dev)
+    dmin = torch.empty(M, dtype=torch.float32, device=dev) if return_dist else None
+    nws = lib.dvq_vq_argmin_workspace_bytes(M, K)
+    ws = workspace(nws, dev)
+    with torch.cuda.device(dev):
+        check(lib.dvq_vq_argmin(pz, ldz, E.data_ptr(), M, K, D, idx.data_ptr(), dmin.data_ptr() if return_dist else None,
+                                ws.data_ptr(), ws.numel(), _stream(dev)), "dvq_vq_argmin")
+    return (idx, dmin) if return_dist else idx
+
+
+def vq_lookup(E: Tensor, idx: Tensor, out: Optional[Tensor] = None, err: Optional[Tensor] = None) -> Tensor:
+    """out[m] = E[idx[m]] (row gather == one-hot @ E).  ``idx`` may be a strided 1-D view.
+    Out-of-range indices raise RuntimeError unless an ``err`` flag tensor is supplied (then the caller checks it)."""
+    lib = _lib.load()
+    dev = _require_gpu(E, idx, out, err)
+    _f32(E, "E"), _i64(idx, "idx")
+    if idx.dim() != 1 or not E.is_contiguous():
+        raise RuntimeError("vq_lookup: idx must be 1-D and the codebook contiguous")
+    M, (K, D) = idx.shape[0], E.shape
+    if out is None:
+        out = torch.empty(M, D, dtype=torch.float32, device=dev)
+    po, ldo = _rows(_f32(out, "out"), "out")
+    own_err = err is None
+    if own_err:
+        err = new_err_flag(dev)
+    with torch.cuda.device(dev):
+        check(lib.dvq_vq_lookup(E.data_ptr(), idx.data_ptr(), idx.stride(0) if M > 1 else 1, M, K, D, po, ldo,
+                                err.data_ptr(), _stream(dev)), "dvq_vq_lookup")
+    if own_err and int(err.item()) != 0:
+        raise RuntimeError(f"index out of bounds for codebook with {K} rows")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ PointNet
+def pointnet_encode(packed, pc: Tensor, out: Optional[Tensor] = None, want_trans: bool = True):
+    """packed: packing.PackedPointNet.  pc [B,C,N] -> (feat [B,1024] (or written into ``out``), trans [B,3,3])."""
+    lib = _lib.load()
+    dev = _require_gpu(pc, out)
+    _f32(pc, "pc")
+    if pc.dim() != 3 or not pc.is_contiguous() or pc.shape[1] != packed.C:
+        raise RuntimeError(f"pointnet_encode: expected a contiguous [B,{packed.C},N] tensor, got {tuple(pc.shape)}")
+    packed.to(dev)
+    B, _, N = pc.shape
+    if out is None:
+        out = torch.empty(B, 1024, dtype=torch.float32, device=dev)
+    po, ldo = _rows(_f32(out, "out"), "out")
+    if out.shape != (B, 1024):
+        raise RuntimeError("pointnet_encode: bad output shape")
+    trans = torch.empty(B, 3, 3, dtype=torch.float32, device=dev) if want_trans else None
+    nws = lib.dvq_pointnet_workspace_bytes(B, N)
+    ws = workspace(nws, dev)
+    with torch.cuda.device(dev):
+        check(lib.dvq_pointnet_encode(C.byref(packed.cstruct), pc.data_ptr(), B, N, po, ldo,
+                                      trans.data_ptr() if want_trans else None, ws.data_ptr(), ws.numel(), _stream(dev)),
+              "dvq_pointnet_encode")
+    return out, trans
+
+
+# ------------------------------------------------------------------------------------------ PixelCNN
+def pixelcnn_sample(packed, label: Tensor, noise: Tensor, return_logits: bool = False, err: Optional[Tensor] = None):
+    """label [B] int64, noise [B,9,n_in] Exp(1) -> codes [B,3,3] int64 (+ logits [B,9,n_in])."""
+    lib = _lib.load()
+    dev = _require_gpu(label, noise, err)
+    _i64(label, "label"), _f32(noise, "noise")
+    packed.to(dev)
+    B = label.shape[0]
+    if label.dim() != 1 or not label.is_contiguous():
+        raise RuntimeError("pixelcnn_sample: label must be a contiguous [B] tensor")
+    if tuple(noise.shape) != (B, 9, packed.n_in) or not noise.is_contiguous():
+        raise RuntimeError(f"pixelcnn_sample: noise must be contiguous [B,9,{packed.n_in}], got {tuple(noise.shape)}")
+    codes = torch.empty(B, 3, 3, dtype=torch.int64, device=dev)
+    logits = torch.empty(B, 9, packed.n_in, dtype=torch.float32, device=dev) if return_logits else None
+    own_err = err is None
+    if own_err:
+        err = new_err_flag(dev)
+    nws = lib.dvq_pixelcnn_workspace_bytes(C.byref(packed.cstruct), B)
+    ws = workspace(nws, dev)
+    with torch.cuda.device(dev):
+        check(lib.dvq_pixelcnn_sample(C.byref(packed.cstruct), label.data_ptr(), noise.data_ptr(), B, codes.data_ptr(),
+                                      logits.data_ptr() if return_logits else None, err.data_ptr(), ws.data_ptr(),
+                                      ws.numel(), _stream(dev)), "dvq_pixelcnn_sample")
+    if own_err and int(err.item()) != 0:
+        raise RuntimeError(f"label out of range for the prior's {packed.n_classes} classes")
+    return (codes, logits) if return_logits else codes
+
+
+def pixelcnn_forward(packed, x: Tensor, label: Tensor) -> Tensor:
+    """x [B,3,3] int64 tokens, label [B] -> logits [B,n_in,3,3] (GatedPixelCNN.forward)."""
+    lib = _lib.load()
+    dev = _require_gpu(x, label)
+    _i64(x, "x"), _i64(label, "label")
+    packed.to(dev)
+    B = x.shape[0]
+    if tuple(x.shape[1:]) != (3, 3):
+        raise RuntimeError("pixelcnn_forward: only the 3x3 latent grid of the grasp path is supported")
+    x = x.contiguous()
+    label = label.contiguous()
+    logits = torch.empty(B, 9, packed.n_in, dtype=torch.float32, device=dev)
+    err = new_err_flag(dev)
+    nws = lib.dvq_pixelcnn_workspace_bytes(C.byref(packed.cstruct), B)
+    ws = workspace(nws, dev)
+    with torch.cuda.device(dev):
+        check(lib.dvq_pixelcnn_forward(C.byref(packed.cstruct), x.data_ptr(), label.data_ptr(), B, logits.data_ptr(),
+                                       err.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)), "dvq_pixelcnn_forward")
+    if int(err.item()) != 0:
+        raise RuntimeError("index out of range in self (token or class label)")
+    return logits.view(B, 3, 3, packed.n_in).permute(0, 3, 1, 2)
+
+
+# ------------------------------------------------------------------------------------------ MANO
+def mano_forward(packed, betas: Tensor, hand_pose: Tensor, global_orient: Optional[Tensor] = None,
+                 transl: Optional[Tensor] = None, channel_major: bool = False, want_joints: bool = False):
+    """-> verts [B,778,3] (or [B,3,778] when channel_major), optional joints [B,16,3]."""
+    lib = _lib.load()
+    dev = _require_gpu(betas, hand_pose, global_orient, transl)
+    packed.to(dev)
+    B = betas.shape[0]
+    pb, ldb = _rows(_f32(betas, "betas"), "betas")
+    pp, ldp = _rows(_f32(hand_pose, "hand_pose"), "hand_pose")
+    if betas.shape[1] != 10 or hand_pose.shape[1] != 45 or hand_pose.shape[0] != B:
+        raise RuntimeError("mano_forward: expected betas [B,10] and hand_pose [B,45]")
+    pg = ldg = pt = ldt = 0
+    if global_orient is not None:
+        pg, ldg = _rows(_f32(global_orient, "global_orient"), "global_orient")
+    if transl is not None:
+        pt, ldt = _rows(_f32(transl, "transl"), "transl")
+    verts = torch.empty((B, 3, 778) if channel_major else (B, 778, 3), dtype=torch.float32, device=dev)
+    joints = torch.empty(B, 16, 3, dtype=torch.float32, device=dev) if want_joints else None
+    with torch.cuda.device(dev):
+        check(lib.dvq_mano_forward(C.byref(packed.cstruct), pb, ldb, pp, ldp, pg or None, ldg, pt or None, ldt, B,
+                                   verts.data_ptr(), 1 if channel_major else 0,
+                                   joints.data_ptr() if want_joints else None, _stream(dev)), "dvq_mano_forward")
+    return (verts, joints) if want_joints else verts
+
+
+# ------------------------------------------------------------------------------------------ data movement
+def copy_cols(src: Tensor, out: Tensor) -> Tensor:
+    lib = _lib.load()
+    dev = _require_gpu(src, out)
+    ps, lds = _rows(_f32(src, "src"), "src")
+    po, ldo = _rows(_f32(out, "out"), "out")
+    if src.shape != out.shape:
+        raise RuntimeError("copy_cols: shape mismatch")
+    with torch.cuda.device(dev):
+        check(lib.dvq_copy_cols(ps, lds, src.shape[0], src.shape[1], po, ldo, _stream(dev)), "dvq_copy_cols")
+    return out
+
+
+def assemble61(recon: Tensor, recon_pos: Tensor) -> Tensor:
+    lib = _lib.load()
+    dev = _require_gpu(recon, recon_pos)
+    B = recon.shape[0]
+    if tuple(recon.shape) != (B, 55) or tuple(recon_pos.shape) != (B, 6) or not recon.is_contiguous() or not recon_pos.is_contiguous():
+        raise RuntimeError("assemble61: expected contiguous recon [B,55] and recon_pos [B,6]")
+    out = torch.empty(B, 61, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.dvq_assemble61(_f32(recon, "recon").data_ptr(), _f32(recon_pos, "recon_pos").data_ptr(), B,
+                                 out.data_ptr(), _stream(dev)), "dvq_assemble61")
+    return out
+
+
+def transform_cloud(pc: Tensor, R: Tensor, t: Optional[Tensor] = None) -> Tensor:
+    """pc [C,N] (one object, broadcast) or [B,C,N]; R [B,3,3]; t [3] -> [B,C,N] with xyz' = R xyz + t."""
+    lib = _lib.load()
+    dev = _require_gpu(pc, R, t)
+    _f32(pc, "pc"), _f32(R, "R")
+    B = R.shape[0]
+    if not pc.is_contiguous() or not R.is_contiguous() or tuple(R.shape[1:]) != (3, 3):
+        raise RuntimeError("transform_cloud: expected contiguous pc and R [B,3,3]")
+    if pc.dim() == 2:
+        Cc, N = pc.shape
+        bstride = 0
+    else:
+        if pc.shape[0] != B:
+            raise RuntimeError("transform_cloud: batch mismatch")
+        _, Cc, N = pc.shape
+        bstride = Cc * N
+    out = torch.empty(B, Cc, N, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.dvq_transform_cloud(pc.data_ptr(), bstride, R.data_ptr(), t.data_ptr() if t is not None else None, B, Cc,
+                                      N, out.data_ptr(), _stream(dev)), "dvq_transform_cloud")
+    return out

@@ -1,0 +1,180 @@
+"""One-time weight packing: reference ``state_dict`` tensors -> the layouts the HIP kernels consume.
+
+* eval-mode BatchNorm is folded into the preceding conv/linear in fp64 and rounded once
+  (pointnet_encoder.py:29-37,150-162; eps = 1e-5);
+* the STN's "+ identity" (pointnet_encoder.py:39-43) is folded into fc3's bias;
+* PixelCNN conv kernels are split into per-tap [out,in] matrices; mask 'A' (models.py:61-63) is applied by
+  never referencing the masked taps; the 2*dim output channels are *gate-packed* so that a tanh channel
+  and its sigmoid partner land in the same MFMA accumulator position of adjacent 32-column tiles:
+  packed row p -> natural row  (p//128)*64 + ((p%128)//64)*32 + p%32  +  dim * ((p%64)//32).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Mapping, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+Tensor = torch.Tensor
+BN_EPS = 1e-5
+
+
+def _dev(t: Tensor, device) -> Tensor:
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def fold_bn(w: Tensor, b: Tensor, sd: Mapping[str, Tensor], bn: str):
+    """(W', b') with BN(Wx + b) == W'x + b' (eval mode), computed in fp64."""
+    w64 = w.detach().double().cpu().reshape(w.shape[0], -1)
+    b64 = b.detach().double().cpu()
+    g, beta = sd[bn + ".weight"].detach().double().cpu(), sd[bn + ".bias"].detach().double().cpu()
+    mu, var = sd[bn + ".running_mean"].detach().double().cpu(), sd[bn + ".running_var"].detach().double().cpu()
+    s = g / torch.sqrt(var + BN_EPS)
+    return (w64 * s[:, None]).float(), ((b64 - mu) * s + beta).float()
+
+
+class _Packed:
+    """Holds device tensors + the ctypes struct that points at them; re-homed lazily with .to(device)."""
+
+    def __init__(self):
+        self.tensors: Dict[str, Tensor] = {}
+        self.device = None
+        self.cstruct = None
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if self.device == device:
+            return self
+        self.tensors = {k: _dev(v, device) for k, v in self.tensors.items()}
+        self.device = device
+        self._bind()
+        return self
+
+    def _bind(self):
+        raise NotImplementedError
+
+
+class PackedPointNet(_Packed):
+    def __init__(self, sd: Mapping[str, Tensor], prefix: str = ""):
+        super().__init__()
+        g = lambda k: sd[prefix + k]
+        self.C = int(g("conv1.weight").shape[1])
+        if self.C not in (3, 4):
+            raise RuntimeError(f"PointNetEncoder with channel={self.C} is not supported by the HIP path (3 or 4)")
+        t = self.tensors
+        local = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+        for pre, tag in (("stn.", "s_"), ("", "")):
+            for i in (1, 2, 3):
+                w, b = fold_bn(g(f"{pre}conv{i}.weight"), g(f"{pre}conv{i}.bias"), local, f"{pre}bn{i}")
+                if i == 1:                      # pad the C (3 or 4) input channels to 4
+                    w4 = torch.zeros(64, 4)
+                    w4[:, : self.C] = w
+                    w = w4
+                t[f"{tag}w{i}"], t[f"{tag}b{i}"] = w, b
+        t["s_f1"], t["s_c1"] = fold_bn(g("stn.fc1.weight"), g("stn.fc1.bias"), local, "stn.bn4")
+        t["s_f2"], t["s_c2"] = fold_bn(g("stn.fc2.weight"), g("stn.fc2.bias"), local, "stn.bn5")
+        t["s_f3"] = g("stn.fc3.weight").detach().float().cpu()
+        t["s_c3"] = g("stn.fc3.bias").detach().float().cpu() + torch.eye(3).reshape(9)
+
+    def _bind(self):
+        s = _lib.PointnetWeights()
+        s.C = self.C
+        for name, _ in _lib.PointnetWeights._fields_[2:]:
+            setattr(s, name, self.tensors[name].data_ptr())
+        self.cstruct = s
+
+
+def gate_perm(dim: int) -> Tensor:
+    p = torch.arange(2 * dim)
+    return (p // 128) * 64 + ((p % 128) // 64) * 32 + (p % 32) + dim * ((p % 64) // 32)
+
+
+class PackedPixelCNN(_Packed):
+    def __init__(self, sd: Mapping[str, Tensor], prefix: str = ""):
+        super().__init__()
+        g = lambda k: sd[prefix + k].detach().float().cpu()
+        emb = g("embedding.weight")
+        self.n_in, self.dim = int(emb.shape[0]), int(emb.shape[1])
+        if self.dim % 64 != 0:
+            raise RuntimeError(f"GatedPixelCNN dim={self.dim}: the HIP path needs a multiple of 64")
+        n = 0
+        while f"{prefix}layers.{n}.vert_stack.weight" in sd:
+            n += 1
+        self.n_layers = n
+        self.n_classes = int(g("layers.0.class_cond_embedding.weight").shape[0])
+        self.n_hidden = int(g("output_conv.0.weight").shape[0])
+        self.n_out = int(g("output_conv.2.weight").shape[0])
+        if self.n_out != self.n_in:
+            raise RuntimeError("GatedPixelCNN: output classes != input tokens")
+        P = gate_perm(self.dim)
+        t = self.tensors
+        t["tok_emb"] = emb
+        for i in range(n):
+            lp = f"layers.{i}."
+            wv = g(lp + "vert_stack.weight")            # [2d, d, KR, k]
+            KR, k = wv.shape[2], wv.shape[3]
+            assert k == (5 if i == 0 else 3) and KR == k // 2 + 1, "unexpected PixelCNN kernel geometry"
+            t[f"wv{i}"] = wv.permute(2, 3, 0, 1)[:, :, P, :].reshape(KR * k, 2 * self.dim, self.dim)
+            t[f"bv{i}"] = g(lp + "vert_stack.bias")[P]
+            wh = g(lp + "horiz_stack.weight")           # [2d, d, 1, KC]
+            t[f"wh{i}"] = wh[:, :, 0, :].permute(2, 0, 1)[:, P, :]
+            t[f"wv2h{i}"] = g(lp + "vert_to_horiz.weight")[:, :, 0, 0][P][:, P]
+            t[f"bh{i}"] = (g(lp + "horiz_stack.bias") + g(lp + "vert_to_horiz.bias"))[P]
+            t[f"cls{i}"] = g(lp + "class_cond_embedding.weight")[:, P]
+            t[f"wr{i}"] = g(lp + "horiz_resid.weight")[:, :, 0, 0]
+            t[f"br{i}"] = g(lp + "horiz_resid.bias")
+        t["w0"], t["b0"] = g("output_conv.0.weight")[:, :, 0, 0], g("output_conv.0.bias")
+        t["w2"], t["b2"] = g("output_conv.2.weight")[:, :, 0, 0], g("output_conv.2.bias")
+
+    def _bind(self):
+        t = self.tensors
+        self._layers = (_lib.PixelcnnLayer * self.n_layers)()
+        for i in range(self.n_layers):
+            for name, _ in _lib.PixelcnnLayer._fields_:
+                setattr(self._layers[i], name, t[f"{name}{i}"].data_ptr())
+        s = _lib.PixelcnnWeights()
+        s.n_layers, s.dim, s.n_in, s.n_classes, s.n_hidden = self.n_layers, self.dim, self.n_in, self.n_classes, self.n_hidden
+        s.tok_emb = t["tok_emb"].data_ptr()
+        s.layers_host = C.cast(self._layers, C.POINTER(_lib.PixelcnnLayer))
+        s.w0, s.b0, s.w2, s.b2 = (t[k].data_ptr() for k in ("w0", "b0", "w2", "b2"))
+        self.cstruct = s
+
+
+class PackedMano(_Packed):
+    """arrays: v_template [778,3], shapedirs [778,3,10], posedirs [778,3,135], J_regressor [16,778],
+    weights [778,16], hands_components [45,45], hands_mean [45], parents [16]."""
+
+    def __init__(self, arrays: Mapping[str, np.ndarray], flat_hand_mean: bool = True, n_comps: int = 45):
+        super().__init__()
+        if n_comps != 45:
+            raise RuntimeError("the grasp path uses num_pca_comps=45 (gen_diverse_grasp_obman.py:358)")
+        f64 = lambda k: np.asarray(arrays[k], dtype=np.float64)
+        vt, sh, po = f64("v_template"), f64("shapedirs")[:, :, :10], f64("posedirs")
+        jr = f64("J_regressor")
+        t = self.tensors
+        tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+        t["v_template"] = tt(vt)
+        t["shapedirs"] = tt(sh.reshape(778 * 3, 10).T)
+        t["posedirs"] = tt(po.reshape(778 * 3, 135).T)
+        t["j_template"] = tt(jr @ vt)
+        t["j_shapedirs"] = tt(np.einsum("jv,vkl->ljk", jr, sh).reshape(10, 48))
+        t["weights"] = tt(f64("weights"))
+        t["comps"] = tt(f64("hands_components")[:45])
+        mean = np.zeros(45) if flat_hand_mean else f64("hands_mean")
+        t["pose_mean"] = tt(np.concatenate([np.zeros(3), mean]))
+        self.parents = [int(p) for p in np.asarray(arrays["parents"]).reshape(-1)]
+        self.parents[0] = -1
+        self.faces = np.asarray(arrays.get("faces", np.zeros((0, 3), dtype=np.int64)))
+
+    def _bind(self):
+        s = _lib.ManoModel()
+        for name, _ in _lib.ManoModel._fields_[:-1]:
+            setattr(s, name, self.tensors[name].data_ptr())
+        for j, p in enumerate(self.parents):
+            s.parents[j] = p
+        self.cstruct = s

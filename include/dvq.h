@@ -1,0 +1,184 @@
+/*
+ * dvq.h -- C ABI of libdvq_hip.so: the MI355X (gfx950) implementation of the D-VQVAE batched
+ * grasp-generation hot path (reference: network/gen_net.py:78-125, `GenNet.gen`).
+ *
+ * The reference is pure Python/PyTorch and has NO FFI/plugin layer: its "operator
+ * interface" for this path is the set of nn.Module methods cited on each entry point below.  These
+ * entry points are what a ctypes binding added to the reference would call (INTEGRATION.md shows the
+ * stub); the host-side mirror in d-vqvae_amd/network/ is exactly such a binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HIP global memory) unless the name ends in _host;
+ *   - tensors are dense row-major fp32 / int64 exactly as the reference holds them;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises,
+ *     nothing allocates: scratch comes from the caller (`*_workspace_bytes` tells how much);
+ *   - return value: 0 = DVQ_OK, otherwise a dvq_status; dvq_last_error() gives the text
+ *     (thread-local).  Invalid shapes/alignments are rejected (never silently clamped).
+ *   - out-of-range code indices (>= K) are reported through a device-side error flag that the host
+ *     mirror turns into the reference's RuntimeError (quantizer.py:72 scatter_ bounds).
+ */
+#ifndef DVQ_H
+#define DVQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dvq_stream_t; /* hipStream_t */
+
+typedef enum {
+    DVQ_OK = 0,
+    DVQ_EINVAL = 1,   /* bad shape / alignment / null pointer */
+    DVQ_EWORKSPACE = 2, /* workspace too small */
+    DVQ_ELAUNCH = 3,  /* HIP launch error */
+    DVQ_ENODEVICE = 4
+} dvq_status;
+
+int dvq_abi_version(void);
+const char* dvq_last_error(void);
+/* number of visible HIP devices, or -1; does not create a context */
+int dvq_device_count(void);
+
+/* ------------------------------------------------------------------ generic dense layer (MFMA fp32)
+ * y[M,N] = act( sum_s x_s[M,K_s] @ w_s[N,K_s]^T + bias[N] ) -- nn.Linear / 1x1 conv / conv taps.
+ * Replaces: Decoder.forward (network/DVQVAE.py:183-185), STN3d fc1..fc3 (pointnet_encoder.py:35-37),
+ * Encoder.forward (DVQVAE.py:161-166).  K_s % 32 == 0, 16-byte aligned rows. */
+typedef struct {
+    const float* x; /* [M, K] row stride ldx */
+    const float* w; /* [N, K] row stride ldw */
+    int64_t ldx, ldw;
+    int32_t K;
+    int32_t _pad;
+} dvq_gemm_src;
+
+#define DVQ_MAX_SRC 8
+#define DVQ_ACT_NONE 0
+#define DVQ_ACT_RELU 1
+
+int dvq_linear(const dvq_gemm_src* src_host, int nsrc, int64_t M, int N, const float* bias,
+               int act, float* y, int64_t ldy, dvq_stream_t stream);
+
+/* ------------------------------------------------------------------ VQ codebook nearest neighbour
+ * VectorQuantizer.forward(z, istrain=False), network/vqvae/quantizer.py:46-49:
+ *   d[m,k] = (sum_j z[m,j]^2 + sum_j E[k,j]^2) - 2 * sum_j z[m,j] E[k,j];  idx[m] = argmin_k d[m,k]
+ * evaluated in fp32 in that association, every sum a k-ordered fmaf chain (the "canonical order",
+ * oracle/vq_canonical.c); first minimum wins, a NaN distance wins over everything (torch.argmin).
+ * dvq_vq_argmin is the exact fp32 kernel for any K and D % 32 == 0 (fp32 MFMA, canonical order).
+ * workspace: dvq_vq_argmin_workspace_bytes(M, K). dmin (optional, [M]) receives the winning distance. */
+size_t dvq_vq_argmin_workspace_bytes(int64_t M, int K);
+int dvq_vq_argmin(const float* z, int64_t ldz, const float* E, int64_t M, int K, int D,
+                  int64_t* idx, float* dmin, void* workspace, size_t workspace_bytes,
+                  dvq_stream_t stream);
+
+/* VectorQuantizer.get_emb / one-hot @ E (quantizer.py:50-53,68-75): out[m, :] = E[idx[m], :].
+ * *err_flag (device int32, caller zeroes it) is set to 1 if any idx is outside [0,K). */
+int dvq_vq_lookup(const float* E, const int64_t* idx, int64_t idx_stride, int64_t M, int K, int D,
+                  float* out, int64_t ldo, int32_t* err_flag, dvq_stream_t stream);
+
+/* ------------------------------------------------------------------ PointNet encoder
+ * PointNetEncoder.forward (global_feat=True, feature_transform=False), pointnet_encoder.py:140-169
+ * with STN3d.forward :27-45.  BatchNorm (eval) is folded into the preceding conv/fc by the host
+ * packer in fp64; fc3's bias has the 3x3 identity folded in. */
+typedef struct {
+    int32_t C; /* 3 or 4 input channels */
+    int32_t _pad;
+    /* STN trunk */
+    const float *s_w1, *s_b1; /* [64,4]  (C padded to 4 with zeros) */
+    const float *s_w2, *s_b2; /* [128,64] */
+    const float *s_w3, *s_b3; /* [1024,128] */
+    const float *s_f1, *s_c1; /* [512,1024] */
+    const float *s_f2, *s_c2; /* [256,512] */
+    const float *s_f3, *s_c3; /* [9,256], bias + identity */
+    /* main trunk */
+    const float *w1, *b1;     /* [64,4] */
+    const float *w2, *b2;     /* [128,64] */
+    const float *w3, *b3;     /* [1024,128] */
+} dvq_pointnet_weights;
+
+size_t dvq_pointnet_workspace_bytes(int64_t B, int N);
+/* pc [B,C,N] (channel-major per sample, as the datasets emit it) -> feat [B,1024], trans [B,3,3] */
+int dvq_pointnet_encode(const dvq_pointnet_weights* w_host, const float* pc, int64_t B, int N,
+                        float* feat, int64_t ld_feat, float* trans /* optional */,
+                        void* workspace, size_t workspace_bytes, dvq_stream_t stream);
+
+/* ------------------------------------------------------------------ gated PixelCNN prior sampler
+ * GatedPixelCNN.generate (network/pixelcnn/models.py:176-198) on the 3x3 latent grid, as an
+ * incremental (cached) sampler: the network is exactly causal, so each grid position is evaluated
+ * once (1/9 of the reference's FLOPs, identical math).  The draw at each position is
+ * argmax_k softmax(logits)_k / q_k with q ~ Exp(1) supplied by the caller -- the exponential race
+ * torch.multinomial(1) evaluates (models.py:195).  Packed layout: d-vqvae_amd/packing.py. */
+typedef struct {
+    const float* wv;   /* vertical taps   [n_vtaps][2*dim (gate-packed)][dim]            */
+    const float* bv;   /* [2*dim] gate-packed                                              */
+    const float* wh;   /* horizontal taps [n_htaps][2*dim (gate-packed)][dim]              */
+    const float* wv2h; /* [2*dim (gate-packed)][2*dim (gate-packed input order)]           */
+    const float* bh;   /* horiz_stack.bias + vert_to_horiz.bias, gate-packed               */
+    const float* cls;  /* class_cond_embedding [n_classes][2*dim] gate-packed              */
+    const float* wr;   /* horiz_resid [dim][dim]                                           */
+    const float* br;   /* [dim]                                                            */
+} dvq_pixelcnn_layer;
+
+typedef struct {
+    int32_t n_layers, dim, n_in /* tokens */, n_classes, n_hidden /* 2048 */;
+    int32_t _pad;
+    const float* tok_emb;       /* embedding.weight [n_in][dim] */
+    const dvq_pixelcnn_layer* layers_host; /* host array [n_layers]; layer 0: mask A applied, k=5 */
+    const float *w0, *b0;       /* output_conv.0 [n_hidden][dim] */
+    const float *w2, *b2;       /* output_conv.2 [n_in][n_hidden] */
+} dvq_pixelcnn_weights;
+
+size_t dvq_pixelcnn_workspace_bytes(const dvq_pixelcnn_weights* w_host, int64_t B);
+/* label [B] int64 in [0,n_classes), noise q [B,9,n_in] -> codes [B,9] int64 (raster order).
+ * logits_out (optional) [B,9,n_in] receives the logits each draw was made from. */
+int dvq_pixelcnn_sample(const dvq_pixelcnn_weights* w_host, const int64_t* label, const float* noise,
+                        int64_t B, int64_t* codes, float* logits_out, int32_t* err_flag,
+                        void* workspace, size_t workspace_bytes, dvq_stream_t stream);
+/* GatedPixelCNN.forward (models.py:161-174) for given tokens x [B,9] (raster order): logits [B,9,n_in]
+ * (position-major; the host mirror permutes to the reference's [B,n_in,3,3]) */
+int dvq_pixelcnn_forward(const dvq_pixelcnn_weights* w_host, const int64_t* x, const int64_t* label,
+                         int64_t B, float* logits /* [B,9,n_in] */, int32_t* err_flag,
+                         void* workspace, size_t workspace_bytes, dvq_stream_t stream);
+
+/* ------------------------------------------------------------------ MANO layer (third-party `mano`
+ * package at network/gen_net.py:116-118 and gen_diverse_grasp_obman.py:252-253; restated, unpinned)
+ * use_pca=True, 45 comps, flat_hand_mean folded into pose_mean by the packer. */
+typedef struct {
+    const float* v_template;  /* [778,3] */
+    const float* shapedirs;   /* [10][2334]  (beta-major) */
+    const float* posedirs;    /* [135][2334] */
+    const float* j_template;  /* [16,3]   J_regressor @ v_template */
+    const float* j_shapedirs; /* [10][48] J_regressor @ shapedirs */
+    const float* weights;     /* [778,16] */
+    const float* comps;       /* [45,45] hands_components */
+    const float* pose_mean;   /* [48] */
+    int32_t parents[16];
+} dvq_mano_model;
+
+/* betas [B,10] (row stride ldb), pose [B,45] (ldp), optional global_orient [B,3] (ldg) and transl
+ * [B,3] (ldt) -> verts; layout 0: [B,778,3] (the mano layer's), 1: [B,3,778] (PointNet input). */
+int dvq_mano_forward(const dvq_mano_model* m_host, const float* betas, int64_t ldb, const float* pose,
+                     int64_t ldp, const float* global_orient, int64_t ldg, const float* transl,
+                     int64_t ldt, int64_t B, float* verts, int layout, float* joints /* optional [B,16,3] */,
+                     dvq_stream_t stream);
+
+/* ------------------------------------------------------------------ small data movement
+ * out[m, col0:col0+W] = src[m, 0:W]  (concatenations of gen_net.py:109,121) */
+int dvq_copy_cols(const float* src, int64_t lds, int64_t M, int W, float* out, int64_t ldo,
+                  dvq_stream_t stream);
+/* 61-parameter assembly, gen_diverse_grasp_obman.py:243-247:
+ * [betas(10) | global_orient(3)=pos[:, :3] | pca_pose(45) | transl(3)=pos[:, 3:6]] */
+int dvq_assemble61(const float* recon /* [B,55] */, const float* recon_pos /* [B,6] */, int64_t B,
+                   float* out /* [B,61] */, dvq_stream_t stream);
+/* per-grasp random object rotation pre-step, gen_diverse_grasp_ho3d.py:213-230:
+ * out[b,:3,:] = R[b] @ pc[:3,:] + t ; extra channels copied */
+int dvq_transform_cloud(const float* pc /* [C,N] or [B,C,N] */, int64_t pc_batch_stride, const float* R /* [B,3,3] */,
+                        const float* t /* [3] */, int64_t B, int C, int N, float* out /* [B,C,N] */,
+                        dvq_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVQ_H */

@@ -1,0 +1,354 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, the committed golden vectors
+(produced by the real reference) and size-independent properties.  Indices bit-exact; floats within the
+tolerance BASELINE.json states for the path (1e-5 abs on MANO pose/shape)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import SEED
+from util import assert_close, load_synth
+from dvqvae_amd import mano as dmano
+from dvqvae_amd import ops, packing, synth
+from oracle import dvq_oracle as O
+from oracle import mano_oracle, vq_canonical
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-5
+
+
+def gpu(t):
+    return t.to(DEV)
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(1, 9, 256), (128, 128, 32), (130, 55, 2560), (777, 1024, 512), (4096, 6, 128)])
+def test_linear(M, N, K):
+    x = synth.synthetic_normal((M, K), 1, f"lin/x/{M}/{K}")
+    w = synth.synthetic_normal((N, K), 1, f"lin/w/{N}/{K}", 1.0 / np.sqrt(K))
+    b = synth.synthetic_normal((N,), 1, f"lin/b/{N}")
+    for relu in (False, True):
+        y = ops.linear(gpu(x), gpu(w), gpu(b), relu=relu)
+        ref = x.double() @ w.double().t() + b.double()
+        if relu:
+            ref = ref.clamp_min(0)
+        assert_close(y, ref.float(), atol=2e-5, rtol=1e-5)
+
+
+def test_linear_multi_source_and_strided_views():
+    M = 300
+    xs = [synth.synthetic_normal((M, k), 2, f"lm/x/{i}") for i, k in enumerate((64, 512, 1024))]
+    ws = [synth.synthetic_normal((200, k), 2, f"lm/w/{i}", 0.05) for i, k in enumerate((64, 512, 1024))]
+    big = torch.zeros(M, 1600, device=DEV)
+    big[:, 0:64], big[:, 64:576], big[:, 576:1600] = gpu(xs[0]), gpu(xs[1]), gpu(xs[2])
+    out = torch.full((M, 456), -7.0, device=DEV)
+    ops.linear_multi([(big[:, 0:64], gpu(ws[0])), (big[:, 64:576], gpu(ws[1])), (big[:, 576:1600], gpu(ws[2]))],
+                     out=out[:, 256:456])
+    ref = sum(x.double() @ w.double().t() for x, w in zip(xs, ws)).float()
+    assert_close(out[:, 256:456], ref, atol=3e-5)
+    assert torch.all(out[:, :256] == -7.0)
+
+
+def test_linear_rejects_bad_inputs():
+    with pytest.raises(RuntimeError):
+        ops.linear(torch.zeros(4, 48, device=DEV), torch.zeros(8, 48, device=DEV))       # K % 32 != 0
+    with pytest.raises(RuntimeError):
+        ops.linear(torch.zeros(4, 64, device=DEV), torch.zeros(8, 32, device=DEV))       # K mismatch
+
+
+# ------------------------------------------------------------------------------------------ VQ
+@pytest.mark.parametrize("K,D", [(128, 256), (128, 1024), (512, 256)])
+def test_vq_argmin_golden_and_canonical(golden, K, D):
+    g = golden("g2_vq")
+    E = synth.synthetic_normal((K, D), SEED, f"vq/E/{K}/{D}")
+    for M in (1, 7, 4096):
+        z = synth.synthetic_normal((M, D), SEED, f"vq/z/{K}/{D}/{M}")
+        idx, dmin = ops.vq_argmin(gpu(z), gpu(E), return_dist=True)
+        ci, cd = vq_canonical.argmin(z.numpy(), E.numpy())
+        assert np.array_equal(idx.cpu().numpy(), ci), "HIP != canonical oracle (indices)"
+        assert np.array_equal(dmin.cpu().numpy().view(np.uint32), cd.view(np.uint32)), "HIP != canonical oracle (distance bits)"
+        tag = f"K{K}_D{D}_M{M}"
+        safe = g[tag + "_gap"] > 1e-3
+        assert np.array_equal(idx.cpu().numpy()[safe], g[tag + "_idx"][safe]), "HIP != reference golden"
+        print(f"{tag}: match rate vs reference {np.mean(idx.cpu().numpy() == g[tag + '_idx']):.6f}")
+    # reference-init regime (tie-prone)
+    Eu = synth.synthetic_uniform((K, D), SEED, f"vq/Eu/{K}/{D}", -1.0 / K, 1.0 / K)
+    z = synth.synthetic_normal((512, D), SEED, f"vq/zu/{K}/{D}")
+    idx = ops.vq_argmin(gpu(z), gpu(Eu)).cpu().numpy()
+    ci, _ = vq_canonical.argmin(z.numpy(), Eu.numpy())
+    assert np.array_equal(idx, ci)
+    safe = g[f"K{K}_D{D}_uinit_gap"] > 1e-3
+    assert np.array_equal(idx[safe], g[f"K{K}_D{D}_uinit_idx"][safe])
+
+
+def test_vq_crafted_ties_nan_inf(golden):
+    g = golden("g2_vq")
+    E, z = torch.from_numpy(g["crafted_E"]), torch.from_numpy(g["crafted_z"])
+    idx = ops.vq_argmin(gpu(z), gpu(E)).cpu().numpy()
+    assert idx.tolist() == g["crafted_idx"].tolist()
+    ci, _ = vq_canonical.argmin(z.numpy(), E.numpy())
+    assert idx.tolist() == ci.tolist()
+
+
+@pytest.mark.parametrize("K,D,M", [(5, 32, 3), (130, 64, 257), (512, 256, 1000)])
+def test_vq_ragged_shapes(K, D, M):
+    E = synth.synthetic_normal((K, D), 3, f"vqr/E/{K}")
+    z = synth.synthetic_normal((M, D), 3, f"vqr/z/{M}")
+    idx, dmin = ops.vq_argmin(gpu(z), gpu(E), return_dist=True)
+    ci, cd = vq_canonical.argmin(z.numpy(), E.numpy())
+    assert np.array_equal(idx.cpu().numpy(), ci)
+    assert np.array_equal(dmin.cpu().numpy().view(np.uint32), cd.view(np.uint32))
+
+
+def test_vq_empty_and_lookup():
+    E = gpu(synth.synthetic_normal((128, 256), 4, "vql/E"))
+    assert ops.vq_argmin(torch.zeros(0, 256, device=DEV), E).shape == (0,)
+    idx = torch.tensor([0, 127, 5, 5], device=DEV)
+    assert torch.equal(ops.vq_lookup(E, idx), E[idx])
+    with pytest.raises(RuntimeError, match="out of bounds"):
+        ops.vq_lookup(E, torch.tensor([128], device=DEV))
+    with pytest.raises(RuntimeError, match="out of bounds"):
+        ops.vq_lookup(E, torch.tensor([-1], device=DEV))
+
+
+def test_vq_full_size_properties():
+    """BASELINE config 2 sizes (M=65536, K=512, D=256): properties that need no oracle pass."""
+    K, D, M = 512, 256, 65536
+    E = gpu(synth.synthetic_normal((K, D), 5, "vqf/E"))
+    z = gpu(synth.synthetic_normal((M, D), 5, "vqf/z"))
+    idx, dmin = ops.vq_argmin(z, E, return_dist=True)
+    # (1) idempotence: quantising the codebook rows themselves returns their own index
+    assert torch.equal(ops.vq_argmin(E, E), torch.arange(K, device=DEV))
+    assert torch.equal(ops.vq_argmin(ops.vq_lookup(E, idx), E), idx)
+    # (2) permutation equivariance of the codebook
+    perm = torch.randperm(K, generator=torch.Generator().manual_seed(0)).to(DEV)
+    idx_p = ops.vq_argmin(z, E[perm].contiguous())
+    assert torch.equal(perm[idx_p], idx)
+    # (3) the winner is no worse than 64 random entries, in fp64
+    rnd = torch.randint(0, K, (M, 64), device=DEV, generator=None)
+    dw = ((z.double() - E[idx].double()) ** 2).sum(1)
+    dr = ((z.double()[:, None, :] - E[rnd].double()) ** 2).sum(-1).min(1)[0]
+    assert torch.all(dw <= dr + 1e-3)
+    # (4) a sample of rows against the canonical oracle
+    rows = torch.arange(0, M, 64)
+    ci, _ = vq_canonical.argmin(z[rows].cpu().numpy(), E.cpu().numpy())
+    assert np.array_equal(idx[rows].cpu().numpy(), ci)
+
+
+# ------------------------------------------------------------------------------------------ PointNet
+def _pointnet(C, seed):
+    from dvqvae_amd.network.pointnet_encoder import PointNetEncoder
+    net = PointNetEncoder(channel=C)
+    sd = load_synth(net, seed)
+    return net.to(DEV), sd
+
+
+@pytest.mark.parametrize("C,N,B", [(4, 64, 4), (4, 1024, 1), (4, 1024, 4), (4, 3000, 1), (3, 778, 4), (3, 100, 2)])
+def test_pointnet_golden(golden, C, N, B):
+    g = golden("g1_pointnet")
+    net, sd = _pointnet(C, SEED + C)
+    x = synth.synthetic_clouds(B, N, seed=100 + N, channels=C)
+    feat, trans, none = net(gpu(x))
+    assert none is None
+    tag = f"C{C}_N{N}_B{B}"
+    assert_close(trans, g[tag + "_trans"], atol=TOL, what="trans vs reference golden")
+    assert_close(feat, g[tag + "_feat"], atol=TOL, what="feat vs reference golden")
+    of, ot = O.pointnet_encode(sd, "", x)
+    assert_close(feat, of, atol=TOL)
+    assert_close(trans, ot, atol=TOL)
+
+
+def test_pointnet_batched_equals_loop_and_strided_output():
+    net, _ = _pointnet(4, SEED + 4)
+    x = gpu(synth.synthetic_clouds(5, 333, seed=9))
+    out = torch.zeros(5, 2048, device=DEV)
+    net(x, out=out[:, 1024:])
+    loop = torch.cat([net(x[b:b + 1])[0] for b in range(5)])
+    assert torch.equal(out[:, 1024:], loop), "batched != loop of B=1 (canonical accumulation order should make them identical)"
+    assert torch.all(out[:, :1024] == 0)
+
+
+def test_pointnet_needs_eval_and_supported_config():
+    from dvqvae_amd.network.pointnet_encoder import PointNetEncoder
+    net = PointNetEncoder(channel=4).to(DEV).train()
+    with pytest.raises(RuntimeError, match="eval"):
+        net(torch.zeros(1, 4, 16, device=DEV))
+    with pytest.raises(NotImplementedError):
+        PointNetEncoder(feature_transform=True)
+
+
+# ------------------------------------------------------------------------------------------ PixelCNN
+def _prior(cfg, seed):
+    from dvqvae_amd.network.pixelcnn.models import GatedPixelCNN
+    net = GatedPixelCNN(*cfg)
+    sd = load_synth(net, seed)
+    return net.to(DEV), sd
+
+
+def test_pixelcnn_small_golden(golden):
+    g = golden("g4_pixelcnn")
+    net, sd = _prior((32, 64, 3, 16), SEED + 1)
+    x, lab = torch.from_numpy(g["small_x"]), torch.from_numpy(g["small_label"])
+    logits = net(gpu(x), gpu(lab))
+    assert tuple(logits.shape) == (5, 32, 3, 3)
+    assert_close(logits, g["small_logits"], atol=TOL)
+    codes = net.generate(None, gpu(lab), shape=(3, 3), batch_size=5, noise=gpu(synth.exp1_noise(5, 9, 32, seed=5)))
+    assert np.array_equal(codes.cpu().numpy(), g["small_codes"])
+
+
+def test_pixelcnn_full_golden(golden):
+    g = golden("g4_pixelcnn")
+    net, sd = _prior((512, 512, 15, 128), SEED + 2)
+    x, lab = torch.from_numpy(g["full_x"]), torch.from_numpy(g["full_label"])
+    assert_close(net(gpu(x), gpu(lab)), g["full_logits"], atol=2e-5)
+    labs = torch.from_numpy(g["full_gen_label"])
+    q = synth.exp1_noise(4, 9, 512, seed=6)
+    codes, logits = net.generate(None, gpu(labs), batch_size=4, noise=gpu(q), return_logits=True)   # one batched call
+    assert np.array_equal(codes.cpu().numpy(), g["full_codes"]), "batched sampling != 4 reference B=1 calls"
+    # the logits every draw was made from must equal a teacher-forced forward on the drawn codes
+    tf = net(codes, gpu(labs)).permute(0, 2, 3, 1).reshape(4, 9, 512)
+    assert torch.equal(tf, logits)
+
+
+def test_pixelcnn_label_out_of_range():
+    net, _ = _prior((32, 64, 3, 16), SEED + 1)
+    with pytest.raises(RuntimeError, match="out of range"):
+        net.generate(None, torch.tensor([16], device=DEV), batch_size=1)
+
+
+# ------------------------------------------------------------------------------------------ decoders
+def test_decoders_golden(golden):
+    from dvqvae_amd.network.DVQVAE import Decoder
+    g = golden("g6_decoder")
+    for tag, sizes, lat in [("dec", [1024, 256, 55], 2560), ("pos", [1024, 128, 6], 2048)]:
+        dec = Decoder(layer_sizes=sizes, latent_size=lat)
+        load_synth(dec, SEED + 3)
+        z = synth.synthetic_normal((5, lat), SEED, f"dec/z/{tag}")
+        assert_close(dec.to(DEV)(gpu(z)), g[tag + "_y"], atol=TOL)
+
+
+# ------------------------------------------------------------------------------------------ MANO
+def test_mano_vs_oracle():
+    arrays = dmano.synthetic_mano_arrays()
+    ref_arrays = mano_oracle.synthetic_mano_arrays()
+    for k in arrays:
+        assert np.array_equal(arrays[k], ref_arrays[k]), k
+    layer = dmano.ManoLayer(arrays).to(DEV)
+    oracle = mano_oracle.ManoOracle(ref_arrays)
+    B = 37
+    betas = synth.synthetic_normal((B, 10), 6, "mano/betas")
+    pose = synth.synthetic_normal((B, 45), 6, "mano/pose", 0.8)
+    go = synth.synthetic_normal((B, 3), 6, "mano/go")
+    tr = synth.synthetic_normal((B, 3), 6, "mano/tr", 0.3)
+    out = layer(betas=gpu(betas), global_orient=gpu(go), hand_pose=gpu(pose), transl=gpu(tr))
+    ov, oj = oracle(betas, pose, go, tr, return_joints=True)
+    assert_close(out.vertices, ov, atol=TOL)
+    assert_close(out.joints, oj, atol=TOL)
+    cm = layer.vertices_channel_major(gpu(betas), gpu(pose))
+    assert_close(cm.permute(0, 2, 1), oracle(betas, pose), atol=TOL)
+    # zero pose / zero shape -> the template
+    z = layer(betas=torch.zeros(1, 10, device=DEV), global_orient=torch.zeros(1, 3, device=DEV),
+              hand_pose=torch.zeros(1, 45, device=DEV), transl=torch.zeros(1, 3, device=DEV)).vertices
+    assert_close(z[0], arrays["v_template"].astype(np.float32), atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------ GenNet.gen
+def _gennet():
+    from dvqvae_amd.network.gen_net import GenNet
+    net = GenNet()
+    sd = synth.synthetic_state_dict(net.state_dict(), SEED)
+    sd["GatedPixelCNN.output_conv.2.bias"][128:] = -1e4           # restrict the prior to the K=128 codebooks
+    net.load_state_dict(sd, strict=True)
+    net.eval().to(DEV)
+    net.set_rh_mano(dmano.ManoLayer(dmano.synthetic_mano_arrays()).to(DEV))
+    return net, sd
+
+
+def test_gen_end_to_end_golden(golden):
+    """BASELINE config 1: 8 objects, the reference called with B=1 per object; here ONE batched call."""
+    g = golden("g7_gen")
+    net, sd = _gennet()
+    obj = synth.synthetic_clouds(8, int(g["n_points"]), seed=int(g["cloud_seed"]))
+    q = synth.exp1_noise(8, 9, 512, seed=int(g["noise_seed"]))
+    recon, pos, aux = net.gen(gpu(obj), noise=gpu(q), return_aux=True)
+    assert_close(aux["feat_type"], g["feat_type"], atol=TOL)
+    safe = g["idx6_gap"] > 0.05
+    idx6 = aux["idx6"][:, 0].cpu().numpy()
+    assert np.array_equal(idx6[safe], g["idx6"][safe])
+    codes = aux["codes"].cpu().numpy()
+    same = (idx6 == g["idx6"]) & np.all(codes.reshape(8, 9) == g["codes"].reshape(8, 9), axis=1)
+    print(f"idx6 match {np.mean(idx6 == g['idx6']):.3f}; code match {np.mean(codes == g['codes']):.3f}; "
+          f"samples with all codes equal: {same.sum()}/8")
+    assert same.sum() >= 7
+    s = torch.from_numpy(same)
+    assert_close(recon.cpu()[s], g["recon"][same], atol=TOL, what="MANO pose/shape vs reference")
+    assert_close(pos.cpu()[s], g["recon_pos"][same], atol=TOL, what="wrist params vs reference")
+    # 61-parameter assembly
+    p61 = ops.assemble61(recon, pos)
+    assert_close(p61, O.assemble61(recon.cpu(), pos.cpu()), atol=0)
+
+
+def test_gen_real_object_cloud(golden):
+    g = golden("g7_gen_juice")
+    net, _ = _gennet()
+    obj = torch.from_numpy(g["obj_f16"].astype(np.float32))
+    q = synth.exp1_noise(8, 9, 512, seed=43)[:1]
+    recon, pos = net.gen(gpu(obj), noise=gpu(q))
+    assert_close(recon, g["recon"], atol=TOL)
+    assert_close(pos, g["recon_pos"], atol=TOL)
+
+
+def test_gen_batched_equals_loop():
+    net, _ = _gennet()
+    obj = gpu(synth.synthetic_clouds(6, 512, seed=77))
+    q = gpu(synth.exp1_noise(6, 9, 512, seed=78))
+    r, p = net.gen(obj, noise=q)
+    for b in range(6):
+        rb, pb = net.gen(obj[b:b + 1], noise=q[b:b + 1])
+        assert torch.equal(rb, r[b:b + 1]) and torch.equal(pb, p[b:b + 1])
+
+
+def test_gen_raises_when_prior_exceeds_codebook():
+    from dvqvae_amd.network.gen_net import GenNet
+    net = GenNet()
+    load_synth(net, SEED)                 # unrestricted 512-class prior over K=128 codebooks
+    net.to(DEV)
+    net.set_rh_mano(dmano.ManoLayer(dmano.synthetic_mano_arrays()).to(DEV))
+    with pytest.raises(RuntimeError, match="out of range"):
+        net.gen(gpu(synth.synthetic_clouds(4, 256, seed=1)))
+
+
+# ------------------------------------------------------------------------------------------ DVQVAE eval
+def test_dvqvae_eval_golden(golden):
+    from dvqvae_amd.network.DVQVAE import DVQVAE
+    g = golden("g8_dvqvae")
+    net = DVQVAE(obj_inchannel=4)
+    load_synth(net, SEED + 8)
+    net.to(DEV)
+    obj = synth.synthetic_clouds(3, 512, seed=80)
+    hand = synth.synthetic_normal((3, 3, 778), SEED, "dvq/hand", 0.05)
+    emb_idx, obj_emb = net(gpu(obj), gpu(hand))
+    assert tuple(emb_idx.shape) == (21, 1) and emb_idx.dtype == torch.int64
+    assert np.array_equal(emb_idx[:, 0].cpu().numpy(), g["emb_idx"])
+    assert_close(obj_emb, g["obj_emb"], atol=0, what="obj_emb is an exact codebook row")
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(gpu(obj), gpu(hand))
+
+
+# ------------------------------------------------------------------------------------------ pre/post steps
+def test_transform_cloud_matches_numpy():
+    pc = synth.synthetic_clouds(1, 300, seed=3)[0]
+    B = 5
+    ang = np.random.default_rng(0).uniform(0, 2 * np.pi, size=(B, 3))
+    Rs = []
+    for a in ang:
+        cx, sx, cy, sy, cz, sz = np.cos(a[0]), np.sin(a[0]), np.cos(a[1]), np.sin(a[1]), np.cos(a[2]), np.sin(a[2])
+        Rs.append(np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+                  @ np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]))
+    R = torch.tensor(np.stack(Rs), dtype=torch.float32)
+    t = torch.tensor([-0.0793, 0.0208, -0.6924])
+    out = ops.transform_cloud(gpu(pc), gpu(R), gpu(t)).cpu()
+    ref = torch.einsum("bij,jn->bin", R.double(), pc[:3].double()) + t.double()[None, :, None]
+    assert_close(out[:, :3], ref.float(), atol=1e-6)
+    assert torch.equal(out[:, 3], pc[3].expand(B, -1))
