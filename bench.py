@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Headline benchmark: grasps/s of the batched grasp-generation path (GenNet.gen) on MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` (N>1 is launched through
+``python -m torch.distributed.run``); one JSON line on rank 0.
+
+Workload at every N (weak scaling): each rank generates ``--batch`` (default 65536 = BASELINE.json's batch)
+grasps per step from synthetic N=1024-point clouds with K=512 codebooks; a step is one full pass of the hot
+path over that batch (PointNet x2 -> VQ argmin -> cached PixelCNN sampling -> decoder -> MANO -> PointNet ->
+pos decoder -> 61-parameter assembly) followed by the all-gather of the [B,61] parameters over RCCL.
+Inputs, weights and noise are resident in HBM before the timed region.
+
+Extra objects in the JSON line:
+  roofline            dominant kernel of the step (fp32 MFMA GEMM), algorithmic FLOPs / HIP-event launch time
+  roofline_vq_argmin  BASELINE config 2 (VectorQuantizer K=512 D=256 argmin-only, M=65536) against HBM peak
+  cpu_baseline        the CPU oracle (a port of the reference) timed on this box's host cores, bounded sample
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = fp32 vector peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=65536, help="grasps per rank per step")
+    ap.add_argument("--points", type=int, default=1024)
+    ap.add_argument("--codebook", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-grasps", type=int, default=128, help="bounded CPU-baseline sample (grasps)")
+    ap.add_argument("--vq-iters", type=int, default=20)
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket kernel launches with HIP events")
+    return ap.parse_args()
+
+
+def relaunch_if_needed(args):
+    """`python bench.py --gpus N` without a launcher: start torchrun as a child (before any GPU use)."""
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+
+def prof_read(lib, _lib):
+    buf = (_lib.ProfEntry * 64)()
+    n = lib.dvq_prof_read(buf, 64)
+    return {buf[i].name.decode(): dict(count=int(buf[i].count), ms=float(buf[i].ms), flops=float(buf[i].flops),
+                                        bytes=float(buf[i].bytes)) for i in range(min(n, 64))}
+
+
+def cpu_baseline(sd, arrays, n_grasps, points, codebook):
+    """The CPU oracle (port of the reference's algorithm, naive 9-forward prior as the reference runs it),
+    batched B=64 -- a STRONGER baseline than the reference's own B=1 loop, which is also timed on 8 grasps."""
+    import torch
+    from dvqvae_amd import synth
+    from oracle import dvq_oracle, mano_oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    mano = mano_oracle.ManoOracle(arrays)
+    cpu_sd = {k: v.cpu() for k, v in sd.items()}
+    bsz = 64
+    obj = synth.synthetic_clouds(bsz, points, seed=4242)
+    q = synth.exp1_noise(bsz, 9, codebook, seed=4243)
+    with torch.no_grad():
+        dvq_oracle.gen(cpu_sd, obj[:2], q[:2], mano)                      # warm-up
+        t0 = time.perf_counter()
+        done = 0
+        while done < n_grasps:
+            dvq_oracle.gen(cpu_sd, obj, q, mano)
+            done += bsz
+        dt = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        for b in range(8):
+            dvq_oracle.gen(cpu_sd, obj[b:b + 1], q[b:b + 1], mano)
+        dt1 = time.perf_counter() - t1
+    return {"value": done / dt, "unit": "grasps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{done} grasps as batches of {bsz} (N={points}, K={codebook}, naive 9-forward prior), {dt:.1f} s; "
+                      f"reference-faithful B=1 loop on 8 grasps: {8 / dt1:.2f} grasps/s",
+            "b1_loop_grasps_per_s": 8 / dt1}
+
+
+def main():
+    args = parse()
+    relaunch_if_needed(args)
+    import torch
+    import dvqvae_amd
+    from dvqvae_amd import _lib, dist, mano as dmano, ops, synth
+    from dvqvae_amd.network.gen_net import GenNet
+
+    rank, local_rank, world = dist.init()
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    lib = _lib.load()
+
+    B, N, K = args.batch, args.points, args.codebook
+    net = GenNet(n_embeddings=K, prior_tokens=K, prior_classes=K)
+    sd = synth.synthetic_state_dict(net.state_dict(), 1234)
+    net.load_state_dict(sd)
+    net.eval().to(dev)
+    arrays = dmano.synthetic_mano_arrays()
+    net.set_rh_mano(dmano.ManoLayer(arrays).to(dev))
+
+    # per-rank shard of the global batch: rows [rank*B, (rank+1)*B), seeded by global row block
+    obj = synth.synthetic_clouds(min(B, 4096), N, seed=1000 + rank).to(dev)
+    if B > obj.shape[0]:                                   # tile a 4096-object pool (host RAM / time bound)
+        reps = (B + obj.shape[0] - 1) // obj.shape[0]
+        obj = obj.repeat(reps, 1, 1)[:B].contiguous()
+        obj += torch.randn(B, 1, 1, device=dev) * 1e-3     # de-duplicate the tiles
+    noise = torch.empty(B, 9, K, device=dev).exponential_(1.0)
+    gathered = None
+
+    def step():
+        nonlocal gathered
+        recon, pos = net.gen(obj, noise=noise)
+        p61 = ops.assemble61(recon, pos)
+        gathered = dist.all_gather_rows(p61)
+        return gathered
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if not args.no_prof:
+        lib.dvq_prof_reset()
+        lib.dvq_prof_enable(1)
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    elapsed = dist.max_over_ranks(time.perf_counter() - t0, dev)
+    kernels = {}
+    if not args.no_prof:
+        lib.dvq_prof_enable(0)
+        kernels = prof_read(lib, _lib)
+        lib.dvq_prof_reset()
+    assert gathered.shape == (B * world, 61) and bool(torch.isfinite(gathered).all())
+
+    out = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = B * world * args.steps / elapsed
+        out = {"metric": "grasps/sec at batch=65536, N=1024 pts, K=512", "value": value, "unit": "grasps/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"GenNet.gen full path, batch {B}/GPU, N={N} pts, K={K} codebooks, "
+                                      f"15-layer gated PixelCNN prior (cached sampler), synthetic weights",
+                          "global_batch": B * world, "points": N, "codebook": K, "parallelism": f"batch-shard x{world}"}}
+        if kernels:
+            gemm = {k: v for k, v in kernels.items() if k.startswith("gemm_") and k != "gemm_argmin"}
+            dom = max(kernels.items(), key=lambda kv: kv[1]["ms"])[0]
+            g_ms = sum(v["ms"] for v in gemm.values())
+            g_fl = sum(v["flops"] for v in gemm.values())
+            g_n = sum(v["count"] for v in gemm.values())
+            achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_kernel (all epilogues)", "achieved": achieved,
+                               "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TF,
+                               "traffic": None, "launches": g_n, "avg_launch_ms": g_ms / max(g_n, 1),
+                               "flops_per_launch": g_fl / max(g_n, 1), "dominant_kind": dom,
+                               "gemm_share_of_step": g_ms / (elapsed * 1e3)}
+            out["kernels"] = {k: {"count": v["count"], "ms": round(v["ms"], 3),
+                                  "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0}
+                              for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}
+
+        # ---- BASELINE config 2: VQ argmin-only microbench, M=65536, K=512, D=256 (HBM roofline)
+        M, D = 65536, 256
+        z = torch.randn(M, D, device=dev)
+        E = torch.randn(K, D, device=dev)
+        for _ in range(3):
+            idx = ops.vq_argmin(z, E)
+        torch.cuda.synchronize(dev)
+        lib.dvq_prof_reset(); lib.dvq_prof_enable(1)
+        for _ in range(args.vq_iters):
+            idx = ops.vq_argmin(z, E)
+        torch.cuda.synchronize(dev)
+        lib.dvq_prof_enable(0)
+        pk = prof_read(lib, _lib); lib.dvq_prof_reset()
+        vq = pk["vq_argmin_total"]
+        alg_bytes = M * D * 4 + K * D * 4 + M * 8
+        dur = vq["ms"] / vq["count"] * 1e-3
+        gbs = alg_bytes / dur / 1e9
+        ref_idx = torch.argmin((z ** 2).sum(1, keepdim=True) + (E ** 2).sum(1) - 2 * z @ E.t(), dim=1)
+        out["roofline_vq_argmin"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": gbs / HBM_PEAK_GBS, "traffic": None, "us_per_call": dur * 1e6,
+                                     "algorithmic_bytes": alg_bytes, "rows_per_s": M / dur,
+                                     "index_match_rate_vs_torch_gpu_expr": float((idx == ref_idx).float().mean()),
+                                     "workload": "VectorQuantizer K=512 D=256 argmin-only, M=65536 (all kernels of one call)"}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(sd, arrays, args.cpu_grasps, N, K)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -53,6 +53,11 @@ class ManoModel(C.Structure):
                                           "weights", "comps", "pose_mean")] + [("parents", C.c_int32 * 16)]
 
 
+class ProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("count", C.c_int64), ("ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
 # name -> (restype, argtypes); kept in the order of include/dvq.h
 SIGNATURES = {
     "dvq_abi_version": (C.c_int, []),
@@ -75,6 +80,9 @@ SIGNATURES = {
                                    C.c_int64, C.c_int64, c_f32p, C.c_int, c_f32p, c_stream]),
     "dvq_copy_cols": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int, c_f32p, C.c_int64, c_stream]),
     "dvq_assemble61": (C.c_int, [c_f32p, c_f32p, C.c_int64, c_f32p, c_stream]),
+    "dvq_prof_enable": (C.c_int, [C.c_int]),
+    "dvq_prof_reset": (C.c_int, []),
+    "dvq_prof_read": (C.c_int, [C.POINTER(ProfEntry), C.c_int]),
     "dvq_transform_cloud": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int, c_f32p, c_stream]),
 }
 

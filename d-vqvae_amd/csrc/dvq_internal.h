@@ -37,6 +37,18 @@ void dvq_set_error(const char* fmt, ...);
 static inline bool dvq_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline size_t dvq_round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// ---------------------------------------------------------------- optional per-launch timing (HIP events)
+// Off by default.  When enabled (dvq_prof_enable), every kernel launch of the library is bracketed by two
+// events on the launch stream; dvq_prof_read() resolves them into per-kernel totals.
+struct DvqProfScope {
+    int slot;
+    hipStream_t stream;
+    DvqProfScope(const char* kind, double flops, double bytes, hipStream_t st);
+    ~DvqProfScope();
+};
+extern bool g_dvq_prof_on;
+#define DVQ_PROF(kind, flops, bytes, st) DvqProfScope prof_scope__(kind, flops, bytes, st)
+
 // ---------------------------------------------------------------- fp32 MFMA GEMM with fused epilogues
 enum GemmEpilogue {
     EPI_BIAS = 0,    // out = act(acc + bias)

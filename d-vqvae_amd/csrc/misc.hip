@@ -1,5 +1,6 @@
 // Error plumbing and the small data-movement kernels of the path (gathers, concatenations, reductions).
 #include "dvq_internal.h"
+#include <string.h>
 
 static thread_local char g_err[512] = "";
 
@@ -15,6 +16,70 @@ extern "C" int dvq_abi_version(void) { return 1; }
 extern "C" int dvq_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+// ------------------------------------------------------------------ per-launch timing
+#include <string>
+#include <vector>
+#include <map>
+bool g_dvq_prof_on = false;
+namespace {
+struct ProfRec { int kind; hipEvent_t a, b; double flops, bytes; };
+std::vector<ProfRec> g_recs;
+std::vector<std::string> g_kinds;
+std::vector<hipEvent_t> g_pool;
+int kind_id(const char* name) {
+    for (size_t i = 0; i < g_kinds.size(); ++i) if (g_kinds[i] == name) return (int)i;
+    g_kinds.emplace_back(name);
+    return (int)g_kinds.size() - 1;
+}
+hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+DvqProfScope::DvqProfScope(const char* kind, double flops, double bytes, hipStream_t st) : slot(-1), stream(st) {
+    if (!g_dvq_prof_on) return;
+    ProfRec r{kind_id(kind), get_event(), get_event(), flops, bytes};
+    (void)hipEventRecord(r.a, st);
+    g_recs.push_back(r);
+    slot = (int)g_recs.size() - 1;
+}
+DvqProfScope::~DvqProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_recs[slot].b, stream);
+}
+
+extern "C" int dvq_prof_enable(int on) { g_dvq_prof_on = on != 0; return DVQ_OK; }
+extern "C" int dvq_prof_reset(void) {
+    for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
+    g_recs.clear();
+    return DVQ_OK;
+}
+extern "C" int dvq_prof_read(dvq_prof_entry* out, int max_entries) {
+    std::vector<dvq_prof_entry> acc(g_kinds.size());
+    for (size_t i = 0; i < g_kinds.size(); ++i) {
+        memset(&acc[i], 0, sizeof(dvq_prof_entry));
+        snprintf(acc[i].name, sizeof(acc[i].name), "%s", g_kinds[i].c_str());
+    }
+    for (auto& r : g_recs) {
+        if (hipEventSynchronize(r.b) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        acc[r.kind].count += 1;
+        acc[r.kind].ms += ms;
+        acc[r.kind].flops += r.flops;
+        acc[r.kind].bytes += r.bytes;
+    }
+    int n = 0;
+    for (auto& e : acc) {
+        if (e.count == 0) continue;
+        if (n < max_entries) out[n] = e;
+        ++n;
+    }
     return n;
 }
 
@@ -100,6 +165,7 @@ int dvq_launch_gather_rows(const float* table, const int64_t* idx, long idx_stri
     DVQ_REQUIRE(D % 4 == 0 && ldo % 4 == 0 && dvq_aligned16(table) && dvq_aligned16(out), "gather: rows not 16-byte aligned");
     if (M == 0) return DVQ_OK;
     const long total = M * (D / 4);
+    DVQ_PROF("gather_rows", 0, 2.0 * M * D * 4, stream);
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, table, idx,
                        idx_stride, M, K, D, out, ldo, err_flag);
     DVQ_CHECK_LAUNCH("gather_rows");
@@ -109,6 +175,7 @@ int dvq_launch_gather_rows(const float* table, const int64_t* idx, long idx_stri
 int dvq_launch_colmax_reduce(const float* partial, long groups, int tiles_per_group, int N, int relu, float* out,
                              long ldo, hipStream_t stream) {
     const long total = groups * N;
+    DVQ_PROF("colmax_reduce", 0, (double)groups * (tiles_per_group + 1) * N * 4, stream);
     hipLaunchKernelGGL(colmax_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, partial, groups,
                        tiles_per_group, N, relu, out, ldo);
     DVQ_CHECK_LAUNCH("colmax_reduce");

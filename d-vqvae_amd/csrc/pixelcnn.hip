@@ -255,10 +255,13 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
                 h2.src[0] = GemmSrc{pl.hid, w->w2, (long)w->n_hidden, (long)w->n_hidden, w->n_hidden, 0};
                 h2.nsrc = 1; h2.M = Bc; h2.N = w->n_in; h2.bias = w->b2; h2.out = pl.lg; h2.ldo = w->n_in;
                 DVQ_PROPAGATE(dvq_launch_gemm(h2, EPI_BIAS, st));
+                {
+                DVQ_PROF("pixelcnn_draw", 0, (double)Bc * (2.0 * w->n_in + dim) * 4, st);
                 hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((Bc + 3) / 4)), dim3(256), 0, st, pl.lg,
                                    noise ? noise + b0 * NPOS * w->n_in : nullptr, pos, w->n_in, Bc,
                                    forced ? forced + b0 * NPOS : nullptr, codes ? codes + b0 * NPOS : nullptr, w->tok_emb, dim,
                                    pl.XV(0, pos), logits_out ? logits_out + b0 * NPOS * w->n_in : nullptr, err_flag);
+                }
                 DVQ_CHECK_LAUNCH("pixelcnn_sample_step");
             }
         }

@@ -79,6 +79,7 @@ extern "C" int dvq_vq_argmin(const float* z, int64_t ldz, const float* E, int64_
         return DVQ_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
+    DVQ_PROF("vq_argmin_total", 2.0 * M * K * D, (double)M * D * 4 + (double)K * D * 4 + (double)M * 8, st);
     hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, z, (long)ldz, (long)M, D, s.zz);
     DVQ_CHECK_LAUNCH("rownorm(z)");
     hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, E, (long)D, (long)K, D, s.ee);

@@ -178,6 +178,20 @@ int dvq_transform_cloud(const float* pc /* [C,N] or [B,C,N] */, int64_t pc_batch
                         const float* t /* [3] */, int64_t B, int C, int N, float* out /* [B,C,N] */,
                         dvq_stream_t stream);
 
+/* ------------------------------------------------------------------ optional per-launch timing
+ * When enabled, every kernel launch of the library is bracketed by two HIP events on its stream.
+ * dvq_prof_read waits for the recorded events and returns per-kernel-kind totals (bench.py's roofline leg). */
+typedef struct {
+    char name[32];
+    int64_t count;
+    double ms;     /* summed launch durations */
+    double flops;  /* summed algorithmic FLOPs  */
+    double bytes;  /* summed algorithmic bytes  */
+} dvq_prof_entry;
+int dvq_prof_enable(int on);
+int dvq_prof_reset(void);
+int dvq_prof_read(dvq_prof_entry* out, int max_entries);
+
 #ifdef __cplusplus
 }
 #endif
