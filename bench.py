@@ -55,6 +55,22 @@ def relaunch_if_needed(args):
         sys.exit(subprocess.call(cmd))
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """Cores this process may actually run on: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def prof_read(lib, _lib):
     buf = (_lib.ProfEntry * 64)()
     n = lib.dvq_prof_read(buf, 64)
@@ -68,8 +84,9 @@ def cpu_baseline(sd, arrays, n_grasps, points, codebook):
     import torch
     from dvqvae_amd import synth
     from oracle import dvq_oracle, mano_oracle
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
+    log(f"cpu baseline on {cores} cores (os.cpu_count()={os.cpu_count()})")
     mano = mano_oracle.ManoOracle(arrays)
     cpu_sd = {k: v.cpu() for k, v in sd.items()}
     bsz = 64
@@ -79,9 +96,10 @@ def cpu_baseline(sd, arrays, n_grasps, points, codebook):
         dvq_oracle.gen(cpu_sd, obj[:2], q[:2], mano)                      # warm-up
         t0 = time.perf_counter()
         done = 0
-        while done < n_grasps:
+        while done < n_grasps and (done == 0 or time.perf_counter() - t0 < 30.0):     # bounded: <= ~30 s
             dvq_oracle.gen(cpu_sd, obj, q, mano)
             done += bsz
+            log(f"cpu baseline: {done} grasps in {time.perf_counter() - t0:.1f} s")
         dt = time.perf_counter() - t0
         t1 = time.perf_counter()
         for b in range(8):
@@ -131,9 +149,11 @@ def main():
         gathered = dist.all_gather_rows(p61)
         return gathered
 
+    log(f"rank {rank}/{world}: model and inputs resident (B={B}, N={N}, K={K}); warm-up")
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
+    log("timed region")
     if not args.no_prof:
         lib.dvq_prof_reset()
         lib.dvq_prof_enable(1)
@@ -145,6 +165,7 @@ def main():
     torch.cuda.synchronize(dev)
     dist.barrier()
     elapsed = dist.max_over_ranks(time.perf_counter() - t0, dev)
+    log(f"timed region done: {elapsed:.3f} s for {args.steps} steps")
     kernels = {}
     if not args.no_prof:
         lib.dvq_prof_enable(0)
@@ -178,6 +199,7 @@ def main():
                                   "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0}
                               for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}
 
+        log("vq_argmin microbench")
         # ---- BASELINE config 2: VQ argmin-only microbench, M=65536, K=512, D=256 (HBM roofline)
         M, D = 65536, 256
         z = torch.randn(M, D, device=dev)

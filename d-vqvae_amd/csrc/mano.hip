@@ -125,9 +125,11 @@ extern "C" int dvq_mano_forward(const dvq_mano_model* m, const float* betas, int
     DVQ_REQUIRE(B >= 0 && ldb >= 10 && ldp >= 45, "mano_forward: bad strides");
     for (int j = 0; j < 16; ++j) DVQ_REQUIRE(m->parents[j] < j, "mano_forward: parents[%d]=%d is not an ancestor index", j, m->parents[j]);
     if (B == 0) return DVQ_OK;
-    DVQ_PROF("mano_lbs", (double)B * 1.17e6, (double)B * (55 + 2334) * 4, (hipStream_t)stream);
-    hipLaunchKernelGGL(mano_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, *m, betas, (long)ldb, pose, (long)ldp,
-                       global_orient, (long)ldg, transl, (long)ldt, (long)B, verts, layout, joints);
+    {
+        DVQ_PROF("mano_lbs", (double)B * 1.17e6, (double)B * (55 + 2334) * 4, (hipStream_t)stream);
+        hipLaunchKernelGGL(mano_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, *m, betas, (long)ldb, pose, (long)ldp,
+                           global_orient, (long)ldg, transl, (long)ldt, (long)B, verts, layout, joints);
+    }
     DVQ_CHECK_LAUNCH("mano_forward");
     return DVQ_OK;
 }

@@ -165,9 +165,11 @@ int dvq_launch_gather_rows(const float* table, const int64_t* idx, long idx_stri
     DVQ_REQUIRE(D % 4 == 0 && ldo % 4 == 0 && dvq_aligned16(table) && dvq_aligned16(out), "gather: rows not 16-byte aligned");
     if (M == 0) return DVQ_OK;
     const long total = M * (D / 4);
-    DVQ_PROF("gather_rows", 0, 2.0 * M * D * 4, stream);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, table, idx,
-                       idx_stride, M, K, D, out, ldo, err_flag);
+    {
+        DVQ_PROF("gather_rows", 0, 2.0 * M * D * 4, stream);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, table, idx,
+                           idx_stride, M, K, D, out, ldo, err_flag);
+    }
     DVQ_CHECK_LAUNCH("gather_rows");
     return DVQ_OK;
 }
@@ -175,9 +177,11 @@ int dvq_launch_gather_rows(const float* table, const int64_t* idx, long idx_stri
 int dvq_launch_colmax_reduce(const float* partial, long groups, int tiles_per_group, int N, int relu, float* out,
                              long ldo, hipStream_t stream) {
     const long total = groups * N;
-    DVQ_PROF("colmax_reduce", 0, (double)groups * (tiles_per_group + 1) * N * 4, stream);
-    hipLaunchKernelGGL(colmax_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, partial, groups,
-                       tiles_per_group, N, relu, out, ldo);
+    {
+        DVQ_PROF("colmax_reduce", 0, (double)groups * (tiles_per_group + 1) * N * 4, stream);
+        hipLaunchKernelGGL(colmax_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, partial, groups,
+                           tiles_per_group, N, relu, out, ldo);
+    }
     DVQ_CHECK_LAUNCH("colmax_reduce");
     return DVQ_OK;
 }

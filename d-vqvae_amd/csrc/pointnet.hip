@@ -90,9 +90,11 @@ int trunk(const float* pc, int C, int N, long Bc, const float* trans, const floa
           hipStream_t st) {
     const long rows = Bc * s.Npad;
     const long threads = rows * 16;
-    DVQ_PROF("pn_layer1", 2.0 * rows * 64 * 4, (double)rows * (16 + 256), st);
-    hipLaunchKernelGGL(pn_layer1_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, pc, C, N, s.Npad, Bc,
-                       trans, w1, b1, s.h1);
+    {
+        DVQ_PROF("pn_layer1", 2.0 * rows * 64 * 4, (double)rows * (16 + 256), st);
+        hipLaunchKernelGGL(pn_layer1_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, pc, C, N, s.Npad, Bc,
+                           trans, w1, b1, s.h1);
+    }
     DVQ_CHECK_LAUNCH("pn_layer1");
     DVQ_PROPAGATE(dense(s.h1, 64, 64, w2, b2, rows, 128, 1, s.h2, 128, st));
     GemmParams p = {};
