@@ -12,10 +12,22 @@ class VectorQuantizer(nn.Module):
         self.embedding = nn.Embedding(n_e, e_dim)
         self.embedding.weight.data.uniform_(-1.0 / n_e, 1.0 / n_e)
 
+    def _packed_codebook(self, E):
+        """Fast-path image of the codebook, rebuilt whenever the parameter is replaced, moved or edited in place."""
+        if not ops.vq_fast_supported(self.n_e, self.e_dim):
+            return None
+        w = self.embedding.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        cached = getattr(self, "_pack_cache", None)
+        if cached is None or cached[0] != key:
+            cached = (key, ops.vq_pack(E))
+            object.__setattr__(self, "_pack_cache", cached)
+        return cached[1]
+
     def _quantize(self, z):
         E = self.embedding.weight.detach()
         zf = z.detach().reshape(-1, self.e_dim)
-        idx = ops.vq_argmin(zf if zf.is_contiguous() else zf.contiguous(), E)
+        idx = ops.vq_argmin(zf if zf.is_contiguous() else zf.contiguous(), E, packed=self._packed_codebook(E))
         z_q = ops.vq_lookup(E, idx).view(z.shape)
         return idx.unsqueeze(1), z_q
 

@@ -114,8 +114,34 @@ def linear_multi(pairs: Sequence[Tuple[Tensor, Tensor]], bias: Optional[Tensor] 
 
 
 # ------------------------------------------------------------------------------------------ VQ
-def vq_argmin(z: Tensor, E: Tensor, return_dist: bool = False):
-    """idx[m] = argmin_k (|z_m|^2 + |E_k|^2) - 2 z_m.E_k, exact fp32, canonical order.  -> int64 [M]"""
+def vq_fast_supported(K: int, D: int) -> bool:
+    return bool(_lib.load().dvq_vq_fast_supported(K, D))
+
+
+def vq_pack(E: Tensor) -> Tensor:
+    """Packed image of a codebook for the fast path (bf16 MFMA fragments of -2E, canonical |e_k|^2, max |e_k|).
+    Build it once per codebook state and pass it to ``vq_argmin(..., packed=)``; it is NOT cached here because a
+    raw pointer cannot tell a recycled allocation from the same codebook."""
+    lib = _lib.load()
+    _require_gpu(E)
+    K, D = E.shape
+    nbytes = lib.dvq_vq_pack_bytes(K, D)
+    if nbytes == 0:
+        raise RuntimeError(f"vq_pack: no fast path for K={K}, D={D}")
+    if not E.is_contiguous():
+        raise RuntimeError("vq_pack: codebook must be contiguous")
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=E.device)
+    with torch.cuda.device(E.device):
+        check(lib.dvq_vq_pack(_f32(E, "E").data_ptr(), K, D, packed.data_ptr(), nbytes, _stream(E.device)), "dvq_vq_pack")
+    return packed
+
+
+def vq_argmin(z: Tensor, E: Tensor, return_dist: bool = False, fast: Optional[bool] = None,
+              packed: Optional[Tensor] = None):
+    """idx[m] = argmin_k (|z_m|^2 + |E_k|^2) - 2 z_m.E_k in the canonical fp32 order -> int64 [M].
+    K=512/D=256 on dense rows takes the filter+refine kernels (same indices, bit for bit); everything else
+    (and ``return_dist``) the exact fp32-MFMA kernel.  ``fast`` forces the choice; ``packed`` = vq_pack(E) skips the
+    per-call codebook packing (two tiny kernels)."""
     lib = _lib.load()
     dev = _require_gpu(z, E)
     _f32(z, "z"), _f32(E, "E")
@@ -127,6 +153,20 @@ def vq_argmin(z: Tensor, E: Tensor, return_dist: bool = False):
     if E.shape[1] != D:
         raise RuntimeError(f"vq_argmin: z has D={D}, codebook has D={E.shape[1]}")
     idx = torch.empty(M, dtype=torch.int64, device=dev)
+    can_fast = bool(lib.dvq_vq_fast_supported(K, D)) and not return_dist and (M <= 1 or ldz == D) and pz % 16 == 0
+    if fast is None:
+        fast = can_fast
+    elif fast and not can_fast:
+        raise RuntimeError(f"vq_argmin: fast path unavailable for K={K}, D={D}, dense={ldz == D}, return_dist={return_dist}")
+    if fast and M > 0:
+        if packed is None:
+            packed = vq_pack(E)
+        nws = lib.dvq_vq_fast_workspace_bytes(M, K, D)
+        ws = workspace(nws, dev)
+        with torch.cuda.device(dev):
+            check(lib.dvq_vq_argmin_fast(pz, E.data_ptr(), packed.data_ptr(), M, K, D, idx.data_ptr(), ws.data_ptr(),
+                                         ws.numel(), _stream(dev)), "dvq_vq_argmin_fast")
+        return idx
     dmin = torch.empty(M, dtype=torch.float32, device=dev) if return_dist else None
     nws = lib.dvq_vq_argmin_workspace_bytes(M, K)
     ws = workspace(nws, dev)

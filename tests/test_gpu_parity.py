@@ -352,3 +352,70 @@ def test_transform_cloud_matches_numpy():
     ref = torch.einsum("bij,jn->bin", R.double(), pc[:3].double()) + t.double()[None, :, None]
     assert_close(out[:, :3], ref.float(), atol=1e-6)
     assert torch.equal(out[:, 3], pc[3].expand(B, -1))
+
+
+# ------------------------------------------------------------------------------------------ VQ fast path
+def _fast_vs_exact(z, E, what):
+    fast = ops.vq_argmin(z, E, fast=True)
+    exact = ops.vq_argmin(z, E, fast=False)
+    assert torch.equal(fast, exact), f"{what}: filter+refine != exact kernel on {(fast != exact).sum().item()} rows"
+    return fast
+
+
+@pytest.mark.parametrize("M", [1, 31, 32, 33, 1000, 4096])
+def test_vq_fast_equals_exact_and_canonical(M):
+    E = synth.synthetic_normal((512, 256), SEED, "vq/E/512/256")
+    z = synth.synthetic_normal((M, 256), SEED, f"vqfast/z/{M}")
+    idx = _fast_vs_exact(gpu(z), gpu(E), f"M={M}")
+    ci, _ = vq_canonical.argmin(z.numpy(), E.numpy())
+    assert np.array_equal(idx.cpu().numpy(), ci)
+
+
+def test_vq_fast_golden(golden):
+    g = golden("g2_vq")
+    E = synth.synthetic_normal((512, 256), SEED, "vq/E/512/256")
+    z = synth.synthetic_normal((4096, 256), SEED, "vq/z/512/256/4096")
+    idx = ops.vq_argmin(gpu(z), gpu(E), fast=True).cpu().numpy()
+    safe = g["K512_D256_M4096_gap"] > 1e-3
+    assert np.array_equal(idx[safe], g["K512_D256_M4096_idx"][safe])
+
+
+def test_vq_fast_adversarial_rows():
+    """Near-ties, exact ties (duplicated entries, > 8 duplicates -> full fallback), NaN / Inf rows, huge and tiny scales."""
+    K, D = 512, 256
+    E = synth.synthetic_normal((K, D), 9, "vqadv/E")
+    E[100] = E[7]; E[300] = E[7]                              # 3-way exact tie
+    for k in range(400, 412):                                  # 12 copies: candidate list overflows -> block fallback
+        E[k] = E[399]
+    E[50] = E[49] + 1e-6 * synth.synthetic_normal((D,), 9, "vqadv/eps")     # near tie below bf16 resolution
+    z = synth.synthetic_normal((256, D), 9, "vqadv/z")
+    z[0] = E[7]; z[1] = E[300]; z[2] = E[405]; z[3] = E[50]; z[4] = E[49]
+    z[5, 17] = float("nan"); z[6, 3] = float("inf"); z[7] = 0.0; z[8] = 1e18 * z[8]; z[9] = 1e-20 * z[9]
+    z[10] = 3e38; z[11] = -E[7]
+    z[12:64] = E[torch.arange(52) * 9] + 1e-3 * z[12:64]      # rows sitting almost on codebook entries
+    idx = _fast_vs_exact(gpu(z), gpu(E), "adversarial")
+    ci, _ = vq_canonical.argmin(z.numpy(), E.numpy())
+    assert np.array_equal(idx.cpu().numpy(), ci)
+    assert idx[0] == 7 and idx[1] == 7 and idx[2] == 399
+
+
+def test_vq_fast_scales_and_tie_prone_codebook():
+    for scale_z, scale_e in [(1.0, 1.0 / 512), (100.0, 0.01), (1e-3, 1e3), (30.0, 30.0)]:
+        E = synth.synthetic_uniform((512, 256), 10, f"vqs/E/{scale_e}", -scale_e, scale_e)
+        z = synth.synthetic_normal((2048, 256), 10, f"vqs/z/{scale_z}", scale_z)
+        _fast_vs_exact(gpu(z), gpu(E), f"scales {scale_z},{scale_e}")
+
+
+def test_vq_fast_full_size():
+    """BASELINE config 2 (M=65536, K=512, D=256): fast == exact on every row; a strided sample vs the C oracle."""
+    E = gpu(synth.synthetic_normal((512, 256), 5, "vqf/E"))
+    z = gpu(synth.synthetic_normal((65536, 256), 5, "vqf/z"))
+    packed = ops.vq_pack(E)
+    idx = ops.vq_argmin(z, E, packed=packed)
+    assert torch.equal(idx, ops.vq_argmin(z, E, fast=False))
+    rows = torch.arange(0, 65536, 97)
+    ci, _ = vq_canonical.argmin(z[rows].cpu().numpy(), E.cpu().numpy())
+    assert np.array_equal(idx[rows].cpu().numpy(), ci)
+    # repeatability (the prefetch ring must not leak stale tiles between launches)
+    for _ in range(3):
+        assert torch.equal(ops.vq_argmin(z, E, packed=packed), idx)
