@@ -419,3 +419,39 @@ def test_vq_fast_full_size():
     # repeatability (the prefetch ring must not leak stale tiles between launches)
     for _ in range(3):
         assert torch.equal(ops.vq_argmin(z, E, packed=packed), idx)
+
+
+# ------------------------------------------------------------------------------------------ generation plumbing
+def test_generate_for_object_and_sharding_equivalence(tmp_path):
+    from dvqvae_amd import generate
+    net, _ = _gennet()
+    obj = synth.synthetic_clouds(1, 700, seed=3)[0]
+    rng = np.random.default_rng(0)
+    q = gpu(synth.exp1_noise(6, 9, 512, seed=8))
+    out = generate.generate_for_object(net, obj, 6, True, rng, noise=q)
+    p = out["params"]
+    assert tuple(p.shape) == (6, 61) and tuple(out["vertices"].shape) == (6, 778, 3)
+    js = out["json"]
+    assert len(js["recon_params"]) == 6 and len(js["recon_params"][0]) == 1 and len(js["recon_params"][0][0]) == 61
+    assert np.asarray(js["R_list"]).shape == (6, 3, 4) and np.asarray(js["r_list"]).shape == (6, 3)
+    # batch sharding (what two ranks would compute) == the unsharded call: objects are independent
+    R = torch.as_tensor(np.asarray(js["R_list"])[:, :, :3], dtype=torch.float32, device=DEV)
+    t = torch.tensor(generate.CANONICAL_OFFSET, device=DEV)
+    batch = ops.transform_cloud(gpu(obj), R, t)
+    halves = [ops.assemble61(*net.gen(batch[lo:hi], noise=q[lo:hi])) for lo, hi in ((0, 3), (3, 6))]
+    assert torch.equal(torch.cat(halves), p)
+    # the final posed-MANO pass (gen_diverse_grasp_obman.py:252-253) against the oracle
+    oracle = mano_oracle.ManoOracle(mano_oracle.synthetic_mano_arrays())
+    pc = p.cpu()
+    ov = oracle(pc[:, :10], pc[:, 13:58], pc[:, 10:13], pc[:, 58:61])
+    assert_close(out["vertices"], ov, atol=TOL)
+
+
+def test_entry_point_writes_reference_json(tmp_path):
+    from dvqvae_amd import diversity, generate
+    out_dir = str(tmp_path / "ho3d")
+    paths = generate.main("ho3d", ["--num_grasp", "5", "--num_objects", "2", "--points", "300", "--out_dir", out_dir,
+                                   "--checkpoint", "/nonexistent", "--mano_model", "/nonexistent"])
+    assert len(paths) == 2
+    params = diversity.load_params(paths)
+    assert params.shape == (10, 61) and np.isfinite(params).all()

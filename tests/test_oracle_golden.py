@@ -135,3 +135,60 @@ def test_decoders(golden):
         sd = synth.synthetic_state_dict(t, SEED + 3)
         z = synth.synthetic_normal((5, lat), SEED, f"dec/z/{tag}")
         close(O.mlp_decoder(sd, "", z), g[tag + "_y"])
+
+
+def _gennet_sd():
+    from dvqvae_amd.network.gen_net import GenNet
+    sd = synth.synthetic_state_dict(GenNet().state_dict(), SEED)
+    sd["GatedPixelCNN.output_conv.2.bias"][128:] = -1e4
+    return sd
+
+
+def test_gen_end_to_end_vs_reference(golden):
+    """G7 / BASELINE config 1: oracle.gen batched over 8 objects == 8 reference GenNet.gen(B=1) calls."""
+    g = golden("g7_gen")
+    sd = _gennet_sd()
+    mano = mano_oracle.ManoOracle(mano_oracle.synthetic_mano_arrays())
+    obj = synth.synthetic_clouds(8, int(g["n_points"]), seed=int(g["cloud_seed"]))
+    q = synth.exp1_noise(8, 9, 512, seed=int(g["noise_seed"]))
+    with torch.no_grad():
+        recon, pos, aux = O.gen(sd, obj, q, mano, return_aux=True)
+    safe = g["idx6_gap"] > 0.05
+    assert np.array_equal(aux["idx6"][:, 0].numpy()[safe], g["idx6"][safe])
+    same = np.all(aux["codes"].numpy().reshape(8, 9) == g["codes"].reshape(8, 9), axis=1) & (aux["idx6"][:, 0].numpy() == g["idx6"])
+    assert same.sum() >= 7
+    close(recon[torch.from_numpy(same)], g["recon"][same])
+    close(pos[torch.from_numpy(same)], g["recon_pos"][same])
+    j = golden("g7_gen_juice")
+    with torch.no_grad():
+        r1, p1 = O.gen(sd, torch.from_numpy(j["obj_f16"].astype(np.float32)), q[:1], mano)
+    close(r1, j["recon"])
+    close(p1, j["recon_pos"])
+
+
+def test_dvqvae_eval_vs_reference(golden):
+    from dvqvae_amd.network.DVQVAE import DVQVAE, HAND_PARTS
+    g = golden("g8_dvqvae")
+    sd = synth.synthetic_state_dict(DVQVAE().state_dict(), SEED + 8)
+    obj = synth.synthetic_clouds(3, 512, seed=80)
+    hand = synth.synthetic_normal((3, 3, 778), SEED, "dvq/hand", 0.05)
+    with torch.no_grad():
+        emb_idx, obj_emb = O.dvqvae_eval_forward(sd, obj, hand, HAND_PARTS)
+    assert np.array_equal(emb_idx[:, 0].numpy(), g["emb_idx"])
+    close(obj_emb, g["obj_emb"], atol=0)
+    assert HAND_PARTS[0] == O._thumb_vertices() and sorted(set(sum(HAND_PARTS, []))) == list(range(778))
+
+
+def test_vq_canonical_vs_golden(golden):
+    """The canonical-order C oracle (what the HIP kernels match bit for bit) against the reference's indices."""
+    from oracle import vq_canonical
+    g = golden("g2_vq")
+    for K, D in [(128, 256), (128, 1024), (512, 256)]:
+        E = synth.synthetic_normal((K, D), SEED, f"vq/E/{K}/{D}")
+        z = synth.synthetic_normal((4096, D), SEED, f"vq/z/{K}/{D}/4096")[:512]
+        idx, dmin = vq_canonical.argmin(z.numpy(), E.numpy())
+        safe = g[f"K{K}_D{D}_M4096_gap"][:512] > 1e-3
+        assert np.array_equal(idx[safe], g[f"K{K}_D{D}_M4096_idx"][:512][safe])
+    E, z = g["crafted_E"], g["crafted_z"]
+    idx, _ = vq_canonical.argmin(z, E)
+    assert idx.tolist() == g["crafted_idx"].tolist()
