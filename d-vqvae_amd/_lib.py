@@ -27,25 +27,25 @@ c_stream = C.c_void_p
 
 class GemmSrc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("ldx", C.c_int64), ("ldw", C.c_int64),
-                ("K", C.c_int32), ("_pad", C.c_int32)]
+                ("K", C.c_int32), ("_pad", C.c_int32), ("wp", C.c_void_p), ("wp_plane", C.c_int64)]
 
 
 class PointnetWeights(C.Structure):
     _fields_ = [("C", C.c_int32), ("_pad", C.c_int32)] + [
         (n, C.c_void_p) for n in (
             "s_w1", "s_b1", "s_w2", "s_b2", "s_w3", "s_b3", "s_f1", "s_c1", "s_f2", "s_c2", "s_f3", "s_c3",
-            "w1", "b1", "w2", "b2", "w3", "b3")]
+            "w1", "b1", "w2", "b2", "w3", "b3", "s_w2p", "s_w3p", "s_f1p", "s_f2p", "s_f3p", "w2p", "w3p")]
 
 
 class PixelcnnLayer(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("wv", "bv", "wh", "wv2h", "bh", "cls", "wr", "br")]
+    _fields_ = [(n, C.c_void_p) for n in ("wv", "bv", "wh", "wv2h", "bh", "cls", "wr", "br", "wv_p", "wh_p", "wv2h_p", "wr_p")]
 
 
 class PixelcnnWeights(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("dim", C.c_int32), ("n_in", C.c_int32), ("n_classes", C.c_int32),
                 ("n_hidden", C.c_int32), ("_pad", C.c_int32), ("tok_emb", C.c_void_p),
                 ("layers_host", C.POINTER(PixelcnnLayer)), ("w0", C.c_void_p), ("b0", C.c_void_p),
-                ("w2", C.c_void_p), ("b2", C.c_void_p)]
+                ("w2", C.c_void_p), ("b2", C.c_void_p), ("w0_p", C.c_void_p), ("w2_p", C.c_void_p)]
 
 
 class ManoModel(C.Structure):
@@ -64,6 +64,7 @@ SIGNATURES = {
     "dvq_last_error": (C.c_char_p, []),
     "dvq_device_count": (C.c_int, []),
     "dvq_linear": (C.c_int, [C.POINTER(GemmSrc), C.c_int, C.c_int64, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int64, c_stream]),
+    "dvq_split_bf16x3": (C.c_int, [c_f32p, C.c_int64, C.c_void_p, c_stream]),
     "dvq_vq_argmin_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "dvq_vq_argmin": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_int, c_i64p, c_f32p, C.c_void_p,
                                 C.c_size_t, c_stream]),

@@ -64,6 +64,8 @@ struct GemmSrc {
     long lda, ldw;
     int K;
     int pad_;
+    const uint16_t* Wp;   // optional: W pre-split into three bf16 planes [3][N][ldw] (plane stride wp_plane elements)
+    long wp_plane;
 };
 
 struct GemmParams {
@@ -92,6 +94,7 @@ struct GemmParams {
     const float* col_norm;   // zz[N]
     float* part_val;         // [tiles_m][N]
     int* part_idx;           // [tiles_m][N]
+    int dbg_abl;             // diagnostics only (env DVQ_GEMM_ABL): 2 = no MFMAs
 };
 
 // torch.argmin ordering: a NaN beats everything, among equals the lower index wins
@@ -102,6 +105,9 @@ __device__ __forceinline__ bool dvq_argmin_better(float v, int i, float bv, int 
 }
 
 int dvq_launch_gemm(const GemmParams& p, GemmEpilogue epi, hipStream_t stream);
+int dvq_launch_gemm_bf16x3(const GemmParams& p, GemmEpilogue epi, hipStream_t stream);
+// 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split-bf16 (default); env DVQ_GEMM=fp32|bf16x3
+int dvq_gemm_mode();
 
 // simple helpers implemented in misc.hip
 int dvq_launch_gather_rows(const float* table, const int64_t* idx, long idx_stride, long M, int K, int D,

@@ -1,0 +1,306 @@
+// fp32-accurate GEMM on the bf16 matrix cores ("bf16x3"): every fp32 operand is split EXACTLY into three bf16
+// pieces  a = a1 + a2 + a3  (8 + 8 + 8 significant bits, truncation split: a1 = top 16 bits of a, a2 = top 16 bits of
+// a - a1, a3 = a - a1 - a2, all exact), and the product is evaluated as the six partial products of weight >= 2^-24
+//      a*b ~= a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1)          (dropped terms <= 2^-23 |a b|)
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  bf16 products are exact in fp32, so the result has the
+// accuracy of an fp32 GEMM (1e-7 relative) while the matrix pipe runs 6 x 32 = 192 cycles per 32x32x16 block instead
+// of 8 x 64 = 512 for v_mfma_f32_32x32x2_f32: 2.67x fewer MFMA cycles.  No scaling is needed (bf16 has fp32's
+// exponent range); non-finite inputs give NaN.
+//
+// Same tiling, block->tile map, multi-source K loop and epilogues as gemm_f32.hip (128x128 tile, 4 waves 2x2, BK = 32,
+// LDS rows of 32 bf16 padded to 80 B: ds_read_b128 conflict-free; ONE 60 KiB stage, 2 workgroups per CU whose
+// matrix / staging phases interleave; global -> register prefetch two K-tiles ahead).
+// Activations are split on the fly while they are staged (global fp32 -> registers -> 3 LDS planes); weights come
+// pre-split from the packer when GemmSrc::Wp is set (3 bf16 planes), else they are split on the fly too.
+// The accumulation order is still independent of the M tiling (batched == loop, bitwise).
+#include "dvq_internal.h"
+#include "gemm_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = 32;
+constexpr int ROWB = 80;                                   // bytes per LDS row (64 B of data + 16 B pad: 5r mod 16 distinct)
+constexpr int PLANE_B = 128 * ROWB;                        // one plane of one operand: 128 rows
+constexpr int STAGE_B = 6 * PLANE_B;                       // A planes 0..2, W planes 0..2
+constexpr size_t SMEM_BYTES = STAGE_B;                     // 61 440 B, single stage: 2 workgroups per CU
+
+// exact 3-way split of two floats; returns the three packed bf16 pairs (element 0 in the low half)
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+    const unsigned a0 = __float_as_uint(x0) & 0xffff0000u, a1 = __float_as_uint(x1) & 0xffff0000u;
+    const float r0 = x0 - __uint_as_float(a0), r1 = x1 - __uint_as_float(a1);
+    const unsigned b0 = __float_as_uint(r0) & 0xffff0000u, b1 = __float_as_uint(r1) & 0xffff0000u;
+    const float s0 = r0 - __uint_as_float(b0), s1 = r1 - __uint_as_float(b1);
+    p1 = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+    p2 = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+    p3 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+
+struct Staged {
+    f32x4 a[4];          // A: 4 x 4 consecutive k (rows r0 + 32 i, column chunk c4)
+    f32x4 w[4];          // W (fp32 path)
+    uint4 wp[6];         // W (pre-split path): 6 x 16 B
+};
+
+// Per-thread cursor over the flattened (source, K-tile) sequence.  Source parameters are read once per source and the
+// per-thread global pointers advance by BK afterwards (no kernarg reads / address rebuilds in the steady state).
+template <bool WPLANES>
+struct Cursor {
+    int s, k_left;
+    const float* a_ptr[4];
+    const float* w_ptr[4];
+    const uint16_t* wp_ptr[6];
+    unsigned ok;          // bit i: A row i valid; bit 4+i: W row i valid; bit 8+i: W plane chunk i valid
+
+    __device__ __forceinline__ void open(const GemmParams& p, int src_i, long m0, int n0, int tid) {
+        s = src_i;
+        if (s >= p.nsrc) { k_left = 0; return; }
+        const GemmSrc& src = p.src[s];
+        k_left = src.K;
+        const int c4 = tid & 7, r0 = tid >> 3;
+        ok = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long m = m0 + r0 + 32 * i;
+            const bool v = m < p.M;
+            ok |= v ? (1u << i) : 0u;
+            a_ptr[i] = src.A + (v ? m : 0) * src.lda + c4 * 4;
+        }
+        if constexpr (WPLANES) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {             // 128 rows x 4 chunks x 3 planes = 1536 chunks of 16 B
+                const int id = tid + 256 * i;
+                const int plane = id >> 9, row = (id >> 2) & 127, ch = id & 3;
+                const bool v = n0 + row < p.N;
+                ok |= v ? (1u << (8 + i)) : 0u;
+                wp_ptr[i] = src.Wp + plane * src.wp_plane + (long)(v ? n0 + row : 0) * src.ldw + ch * 8;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = n0 + r0 + 32 * i;
+                const bool v = n < p.N;
+                ok |= v ? (1u << (4 + i)) : 0u;
+                w_ptr[i] = src.W + (long)(v ? n : 0) * src.ldw + c4 * 4;
+            }
+        }
+    }
+    __device__ __forceinline__ bool valid() const { return k_left > 0; }
+    // issue the loads of the current tile into t, then step to the next tile
+    __device__ __forceinline__ void fetch(const GemmParams& p, long m0, int n0, int tid, Staged& t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            t.a[i] = (ok >> i & 1u) ? *reinterpret_cast<const f32x4*>(a_ptr[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            a_ptr[i] += BK;
+        }
+        if constexpr (WPLANES) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                t.wp[i] = (ok >> (8 + i) & 1u) ? *reinterpret_cast<const uint4*>(wp_ptr[i]) : uint4{0u, 0u, 0u, 0u};
+                wp_ptr[i] += BK;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                t.w[i] = (ok >> (4 + i) & 1u) ? *reinterpret_cast<const f32x4*>(w_ptr[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                w_ptr[i] += BK;
+            }
+        }
+        k_left -= BK;
+        if (k_left <= 0) open(p, s + 1, m0, n0, tid);
+    }
+};
+
+__device__ __forceinline__ void split_quad(const f32x4& v, uint2 (&out)[3]) {
+    unsigned lo1, lo2, lo3, hi1, hi2, hi3;
+    split3_pair(v[0], v[1], lo1, lo2, lo3);
+    split3_pair(v[2], v[3], hi1, hi2, hi3);
+    out[0] = uint2{lo1, hi1};
+    out[1] = uint2{lo2, hi2};
+    out[2] = uint2{lo3, hi3};
+}
+
+// split the staged registers exactly into bf16 planes and write them to the LDS stage
+template <bool WPLANES>
+__device__ __forceinline__ void store_stage(char* stage, int tid, const Staged& t) {
+    const int c4 = tid & 7, r0 = tid >> 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint2 pk[3];
+        split_quad(t.a[i], pk);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            *reinterpret_cast<uint2*>(stage + pl * PLANE_B + (r0 + 32 * i) * ROWB + c4 * 8) = pk[pl];
+    }
+    if constexpr (WPLANES) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int id = tid + 256 * i;
+            const int plane = id >> 9, row = (id >> 2) & 127, ch = id & 3;
+            *reinterpret_cast<uint4*>(stage + (3 + plane) * PLANE_B + row * ROWB + ch * 16) = t.wp[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint2 pk[3];
+            split_quad(t.w[i], pk);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                *reinterpret_cast<uint2*>(stage + (3 + pl) * PLANE_B + (r0 + 32 * i) * ROWB + c4 * 8) = pk[pl];
+        }
+    }
+}
+
+// one K-tile of 32: two k16 steps of 12 fragment reads + 24 MFMAs
+__device__ __forceinline__ void compute_stage(const char* stage, int wm, int wn, int r, int h, f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const char* As = stage + (wm * 64 + r) * ROWB + (2 * ks + h) * 16;
+        const char* Ws = stage + 3 * PLANE_B + (wn * 64 + r) * ROWB + (2 * ks + h) * 16;
+        bf16x8 a[2][3], w[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PLANE_B + i * 32 * ROWB);
+                w[i][pl] = *reinterpret_cast<const bf16x8*>(Ws + pl * PLANE_B + i * 32 * ROWB);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                f32x16 c = acc[i][jn];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], w[jn][0], c, 0, 0, 0);     // a3 b1
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], w[jn][2], c, 0, 0, 0);     // a1 b3
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], w[jn][1], c, 0, 0, 0);     // a2 b2
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], w[jn][0], c, 0, 0, 0);     // a2 b1
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], w[jn][1], c, 0, 0, 0);     // a1 b2
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], w[jn][0], c, 0, 0, 0);     // a1 b1
+                acc[i][jn] = c;
+            }
+    }
+}
+
+template <int EPI, bool WPLANES>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    const int tid = threadIdx.x;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const long tiles_m = (p.M + BM - 1) / BM;
+    const long b = blockIdx.x;
+    const long j = b >> 3;
+    const long mt = (j / tiles_n) * 8 + (b & 7);
+    const int nt = (int)(j % tiles_n);
+    if (mt >= tiles_m) return;
+    const long m0 = mt * BM;
+    const int n0 = nt * BN;
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+
+    // Single LDS stage (two workgroups per CU interleave their phases); global -> register prefetch runs two K-tiles
+    // ahead: register sets R0 / R1 alternate, the tile computed in iteration t was loaded during iteration t-2.
+    Cursor<WPLANES> cur;
+    cur.open(p, 0, m0, n0, tid);
+    Staged R0, R1;
+    cur.fetch(p, m0, n0, tid, R0);                       // tile 0
+    store_stage<WPLANES>(smem_c, tid, R0);
+    bool have_next = cur.valid();                        // tile t+1 exists (held in R0 for even t, R1 for odd t)
+    if (have_next) cur.fetch(p, m0, n0, tid, R0);        // tile 1
+    __syncthreads();
+    while (true) {
+        // ---- even step: R0 holds tile t+1, R1 receives tile t+2
+        const bool have_next2 = cur.valid();
+        if (have_next2) cur.fetch(p, m0, n0, tid, R1);
+        compute_stage(smem_c, wm, wn, r, h, acc);
+        if (!have_next) break;
+        __syncthreads();                                 // everybody has read the stage
+        store_stage<WPLANES>(smem_c, tid, R0);
+        __syncthreads();
+        // ---- odd step: R1 holds tile t+1, R0 receives tile t+2
+        have_next = cur.valid();
+        if (have_next) cur.fetch(p, m0, n0, tid, R0);
+        compute_stage(smem_c, wm, wn, r, h, acc);
+        if (!have_next2) break;
+        __syncthreads();
+        store_stage<WPLANES>(smem_c, tid, R1);
+        __syncthreads();
+    }
+    __syncthreads();
+    gemm_epilogue<EPI>(p, acc, m0, n0, mt, nt, tid, reinterpret_cast<float*>(smem_c));
+}
+
+__global__ void split_bf16x3_kernel(const float* __restrict__ w, long n, uint16_t* __restrict__ planes) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = w[i];
+    const unsigned a = __float_as_uint(x) & 0xffff0000u;
+    const float r = x - __uint_as_float(a);
+    const unsigned b = __float_as_uint(r) & 0xffff0000u;
+    const float t = r - __uint_as_float(b);
+    planes[i] = (uint16_t)(a >> 16);
+    planes[n + i] = (uint16_t)(b >> 16);
+    planes[2 * n + i] = (uint16_t)(__float_as_uint(t) >> 16);
+}
+
+template <int EPI, bool WPLANES>
+int launch(const GemmParams& p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_kernel<EPI, WPLANES>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BYTES);
+        if (e != hipSuccess) {
+            dvq_set_error("gemm_bf16x3: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return DVQ_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    const long tiles_m = (p.M + BM - 1) / BM;
+    const long tiles_n = (p.N + BN - 1) / BN;
+    const long grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
+    static const char* const names[] = {"gemm_bias", "gemm_resid", "gemm_gate", "gemm_colmax", "gemm_argmin"};
+    double ksum = 0;
+    for (int s = 0; s < p.nsrc; ++s) ksum += p.src[s].K;
+    {
+        DVQ_PROF(names[EPI], 2.0 * (double)p.M * p.N * ksum, ((double)p.M + p.N) * ksum * 4, stream);
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI, WPLANES>), dim3((unsigned)grid), dim3(256), SMEM_BYTES, stream, p);
+    }
+    DVQ_CHECK_LAUNCH("gemm_bf16x3");
+    return DVQ_OK;
+}
+
+}  // namespace
+
+// Called by dvq_launch_gemm (gemm_f32.hip) after argument validation.  K of every source must be a multiple of 16.
+int dvq_launch_gemm_bf16x3(const GemmParams& p, GemmEpilogue epi, hipStream_t stream) {
+    if (const char* e = getenv("DVQ_GEMM_ABL")) const_cast<GemmParams&>(p).dbg_abl = atoi(e);
+    bool planes = true;                                              // pre-split weights: all-or-nothing per launch
+    for (int s = 0; s < p.nsrc; ++s) planes = planes && p.src[s].Wp != nullptr;
+    switch (epi) {
+        case EPI_BIAS: return planes ? launch<EPI_BIAS, true>(p, stream) : launch<EPI_BIAS, false>(p, stream);
+        case EPI_RESID: return planes ? launch<EPI_RESID, true>(p, stream) : launch<EPI_RESID, false>(p, stream);
+        case EPI_GATE: return planes ? launch<EPI_GATE, true>(p, stream) : launch<EPI_GATE, false>(p, stream);
+        case EPI_COLMAX: return planes ? launch<EPI_COLMAX, true>(p, stream) : launch<EPI_COLMAX, false>(p, stream);
+        default: break;
+    }
+    dvq_set_error("gemm_bf16x3: epilogue %d is not available on the split-bf16 path", (int)epi);
+    return DVQ_EINVAL;
+}
+
+extern "C" int dvq_split_bf16x3(const float* w, int64_t n, uint16_t* planes, dvq_stream_t stream) {
+    DVQ_REQUIRE(n >= 0 && (n == 0 || (w && planes)), "split_bf16x3: null pointer");
+    if (n == 0) return DVQ_OK;
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (long)n, planes);
+    DVQ_CHECK_LAUNCH("split_bf16x3");
+    return DVQ_OK;
+}

@@ -1,0 +1,130 @@
+// Epilogues shared by the fp32-MFMA and the split-bf16 GEMM kernels.  Both use 32x32 MFMA tiles whose C/D layout is
+// dtype-independent on gfx950: acc[i][jn][e] holds row m = m0 + wm*64 + i*32 + (e&3) + 8*(e>>2) + 4*h and
+// column n = n0 + wn*64 + jn*32 + r  (wave = 2*wm + wn, r = lane & 31, h = lane >> 5).
+#pragma once
+#include "dvq_internal.h"
+
+constexpr int GEMM_BM = 128, GEMM_BN = 128;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[2][2], long m0, int n0, long mt, int nt,
+                                              int tid, float* smem) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    // ------------------------------------------------------------------ epilogues
+    // acc[i][jn][e]: row m = m0 + wm*64 + i*32 + (e&3) + 8*(e>>2) + 4*h ; col n = n0 + wn*64 + jn*32 + r
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_RESID) {
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            const int n = n0 + wn * 64 + jn * 32 + r;
+            if (n >= p.N) continue;
+            const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const long m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (m >= p.M) continue;
+                    float v = acc[i][jn][e] + bv;
+                    if constexpr (EPI == EPI_RESID) v += p.resid[m * p.ldr + n];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    p.out[m * p.ldo + n] = v;
+                }
+        }
+    } else if constexpr (EPI == EPI_GATE) {
+        // gate-packed channels: jn = 0 holds the tanh half, jn = 1 its sigmoid partner
+        const int na = n0 + wn * 64 + r;        // packed index of the tanh channel
+        const int nb = na + 32;                 // packed index of the sigmoid partner
+        const int c = nt * 64 + wn * 32 + r;    // natural output channel
+        const float ba = p.bias ? p.bias[na] : 0.f;
+        const float bb = p.bias ? p.bias[nb] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (m >= p.M) continue;
+                float a = acc[i][0][e] + ba;
+                float g = acc[i][1][e] + bb;
+                if (p.pre) {
+                    p.pre[m * p.ldpre + na] = a;
+                    p.pre[m * p.ldpre + nb] = g;
+                }
+                if (p.cls) {
+                    const float* crow = p.cls + (long)p.label[m] * p.N;
+                    a += crow[na];
+                    g += crow[nb];
+                }
+                p.out[m * p.ldo + c] = tanhf(a) * sigmoidf_(g);
+            }
+    } else if constexpr (EPI == EPI_COLMAX) {
+        __syncthreads();                         // everyone is done with the staging buffers
+        float* red = smem;                       // [2][128]
+        const int row_base = (int)(m0 % p.rows_per_group);   // a 128-row tile never straddles two groups
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            const int n = n0 + wn * 64 + jn * 32 + r;
+            const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const long m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const bool valid = (m < p.M) && (row_base + (int)(m - m0) < p.valid_rows);
+                    float v = acc[i][jn][e] + bv;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    mx = valid ? fmaxf(mx, v) : mx;
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            if (h == 0) red[wm * 128 + wn * 64 + jn * 32 + r] = mx;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int n = n0 + tid;
+            if (n < p.N) p.partial[mt * p.N + n] = fmaxf(red[tid], red[128 + tid]);
+        }
+    } else if constexpr (EPI == EPI_ARGMIN) {
+        __syncthreads();
+        float* red_v = smem;                                  // [2][128]
+        int* red_i = reinterpret_cast<int*>(smem + 256);      // [2][128]
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            const int n = n0 + wn * 64 + jn * 32 + r;
+            const float zz = (n < p.N) ? p.col_norm[n] : 0.f;
+            float bv = INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const long k = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (k >= p.M) continue;
+                    const float t = zz + p.row_norm[k];
+                    const float d = t - 2.0f * acc[i][jn][e];
+                    if (dvq_argmin_better(d, (int)k, bv, bi)) { bv = d; bi = (int)k; }
+                }
+            const float ov = __shfl_xor(bv, 32);
+            const int oi = __shfl_xor(bi, 32);
+            if (dvq_argmin_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+            if (h == 0) {
+                red_v[wm * 128 + wn * 64 + jn * 32 + r] = bv;
+                red_i[wm * 128 + wn * 64 + jn * 32 + r] = bi;
+            }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int n = n0 + tid;
+            if (n < p.N) {
+                float bv = red_v[tid];
+                int bi = red_i[tid];
+                if (dvq_argmin_better(red_v[128 + tid], red_i[128 + tid], bv, bi)) { bv = red_v[128 + tid]; bi = red_i[128 + tid]; }
+                p.part_val[mt * p.N + n] = bv;
+                p.part_idx[mt * p.N + n] = bi;
+            }
+        }
+    }
+}

@@ -12,6 +12,7 @@
 // Block -> tile map is XCD-aware: the column tiles of one 128-row panel run on one XCD (blocks b and
 // b+8 share an XCD), so the A panel is fetched into one L2 only.
 #include "dvq_internal.h"
+#include "gemm_common.h"
 
 namespace {
 
@@ -51,8 +52,6 @@ __device__ __forceinline__ void store_tile(float* stage, int tid, const TileRegs
         *reinterpret_cast<f32x4*>(stage + (BM + row) * LDT + c4 * 4) = t.w[i];
     }
 }
-
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmParams p) {
@@ -125,119 +124,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmParams p) {
         k0 = k_next;
     }
 
-    // ------------------------------------------------------------------ epilogues
-    // acc[i][jn][e]: row m = m0 + wm*64 + i*32 + (e&3) + 8*(e>>2) + 4*h ; col n = n0 + wn*64 + jn*32 + r
-    if constexpr (EPI == EPI_BIAS || EPI == EPI_RESID) {
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn) {
-            const int n = n0 + wn * 64 + jn * 32 + r;
-            if (n >= p.N) continue;
-            const float bv = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const long m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (m >= p.M) continue;
-                    float v = acc[i][jn][e] + bv;
-                    if constexpr (EPI == EPI_RESID) v += p.resid[m * p.ldr + n];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    p.out[m * p.ldo + n] = v;
-                }
-        }
-    } else if constexpr (EPI == EPI_GATE) {
-        // gate-packed channels: jn = 0 holds the tanh half, jn = 1 its sigmoid partner
-        const int na = n0 + wn * 64 + r;        // packed index of the tanh channel
-        const int nb = na + 32;                 // packed index of the sigmoid partner
-        const int c = nt * 64 + wn * 32 + r;    // natural output channel
-        const float ba = p.bias ? p.bias[na] : 0.f;
-        const float bb = p.bias ? p.bias[nb] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const long m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m >= p.M) continue;
-                float a = acc[i][0][e] + ba;
-                float g = acc[i][1][e] + bb;
-                if (p.pre) {
-                    p.pre[m * p.ldpre + na] = a;
-                    p.pre[m * p.ldpre + nb] = g;
-                }
-                if (p.cls) {
-                    const float* crow = p.cls + (long)p.label[m] * p.N;
-                    a += crow[na];
-                    g += crow[nb];
-                }
-                p.out[m * p.ldo + c] = tanhf(a) * sigmoidf_(g);
-            }
-    } else if constexpr (EPI == EPI_COLMAX) {
-        __syncthreads();                         // everyone is done with the staging buffers
-        float* red = smem;                       // [2][128]
-        const int row_base = (int)(m0 % p.rows_per_group);   // a 128-row tile never straddles two groups
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn) {
-            const int n = n0 + wn * 64 + jn * 32 + r;
-            const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
-            float mx = -INFINITY;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const long m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    const bool valid = (m < p.M) && (row_base + (int)(m - m0) < p.valid_rows);
-                    float v = acc[i][jn][e] + bv;
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    mx = valid ? fmaxf(mx, v) : mx;
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            if (h == 0) red[wm * 128 + wn * 64 + jn * 32 + r] = mx;
-        }
-        __syncthreads();
-        if (tid < 128) {
-            const int n = n0 + tid;
-            if (n < p.N) p.partial[mt * p.N + n] = fmaxf(red[tid], red[128 + tid]);
-        }
-    } else if constexpr (EPI == EPI_ARGMIN) {
-        __syncthreads();
-        float* red_v = smem;                                  // [2][128]
-        int* red_i = reinterpret_cast<int*>(smem + 256);      // [2][128]
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn) {
-            const int n = n0 + wn * 64 + jn * 32 + r;
-            const float zz = (n < p.N) ? p.col_norm[n] : 0.f;
-            float bv = INFINITY;
-            int bi = 0x7fffffff;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const long k = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    if (k >= p.M) continue;
-                    const float t = zz + p.row_norm[k];
-                    const float d = t - 2.0f * acc[i][jn][e];
-                    if (dvq_argmin_better(d, (int)k, bv, bi)) { bv = d; bi = (int)k; }
-                }
-            const float ov = __shfl_xor(bv, 32);
-            const int oi = __shfl_xor(bi, 32);
-            if (dvq_argmin_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
-            if (h == 0) {
-                red_v[wm * 128 + wn * 64 + jn * 32 + r] = bv;
-                red_i[wm * 128 + wn * 64 + jn * 32 + r] = bi;
-            }
-        }
-        __syncthreads();
-        if (tid < 128) {
-            const int n = n0 + tid;
-            if (n < p.N) {
-                float bv = red_v[tid];
-                int bi = red_i[tid];
-                if (dvq_argmin_better(red_v[128 + tid], red_i[128 + tid], bv, bi)) { bv = red_v[128 + tid]; bi = red_i[128 + tid]; }
-                p.part_val[mt * p.N + n] = bv;
-                p.part_idx[mt * p.N + n] = bi;
-            }
-        }
-    }
+    gemm_epilogue<EPI>(p, acc, m0, n0, mt, nt, tid, smem);
 }
 
 template <int EPI>
@@ -268,6 +155,15 @@ int launch(const GemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
+int dvq_gemm_mode() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("DVQ_GEMM");
+        mode = (e && (e[0] == 'f' || e[0] == 'F')) ? 0 : 1;
+    }
+    return mode;
+}
+
 int dvq_launch_gemm(const GemmParams& p, GemmEpilogue epi, hipStream_t stream) {
     DVQ_REQUIRE(p.nsrc >= 1 && p.nsrc <= DVQ_MAX_SRC, "gemm: nsrc=%d out of range", p.nsrc);
     DVQ_REQUIRE(p.M > 0 && p.N > 0, "gemm: empty problem M=%ld N=%d", p.M, p.N);
@@ -279,23 +175,28 @@ int dvq_launch_gemm(const GemmParams& p, GemmEpilogue epi, hipStream_t stream) {
         DVQ_REQUIRE(dvq_aligned16(g.A) && dvq_aligned16(g.W) && g.lda % 4 == 0 && g.ldw % 4 == 0,
                     "gemm: source %d rows are not 16-byte aligned", s);
     }
+    const bool split = dvq_gemm_mode() == 1 && epi != EPI_ARGMIN;     // the exact VQ argmin stays on the fp32 chain
     switch (epi) {
         case EPI_BIAS:
             DVQ_REQUIRE(p.out, "gemm: null output");
+            if (split) return dvq_launch_gemm_bf16x3(p, epi, stream);
             return launch<EPI_BIAS>(p, stream);
         case EPI_RESID:
             DVQ_REQUIRE(p.out && p.resid, "gemm: null output/residual");
+            if (split) return dvq_launch_gemm_bf16x3(p, epi, stream);
             return launch<EPI_RESID>(p, stream);
         case EPI_GATE:
             DVQ_REQUIRE(p.out, "gemm: null output");
             DVQ_REQUIRE(p.N % BN == 0, "gemm: gated epilogue needs N %% 128 == 0 (N=%d)", p.N);
             DVQ_REQUIRE(!p.cls || p.label, "gemm: class bias without labels");
+            if (split) return dvq_launch_gemm_bf16x3(p, epi, stream);
             return launch<EPI_GATE>(p, stream);
         case EPI_ARGMIN:
             break;
         case EPI_COLMAX:
             DVQ_REQUIRE(p.partial && p.rows_per_group > 0 && p.rows_per_group % BM == 0 && p.valid_rows > 0,
                         "gemm: bad column-max grouping");
+            if (split) return dvq_launch_gemm_bf16x3(p, epi, stream);
             return launch<EPI_COLMAX>(p, stream);
     }
     if (epi == EPI_ARGMIN) {
@@ -312,7 +213,8 @@ extern "C" int dvq_linear(const dvq_gemm_src* src, int nsrc, int64_t M, int N, c
     DVQ_REQUIRE(act == DVQ_ACT_NONE || act == DVQ_ACT_RELU, "dvq_linear: unknown activation %d", act);
     if (M == 0) return DVQ_OK;
     GemmParams p = {};
-    for (int s = 0; s < nsrc; ++s) p.src[s] = GemmSrc{src[s].x, src[s].w, (long)src[s].ldx, (long)src[s].ldw, src[s].K, 0};
+    for (int s = 0; s < nsrc; ++s)
+        p.src[s] = GemmSrc{src[s].x, src[s].w, (long)src[s].ldx, (long)src[s].ldw, src[s].K, 0, src[s].wp, (long)src[s].wp_plane};
     p.nsrc = nsrc;
     p.M = M;
     p.N = N;

@@ -180,8 +180,11 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
                         for (int kc = 0; kc < k; ++kc) {
                             const int ic = c - pad + kc;
                             if (ic < 0 || ic >= GRID) continue;
-                            g.src[ns++] = GemmSrc{pl.XV(l, ir * GRID + ic), ly.wv + (size_t)(kr * k + kc) * 2 * dim * dim,
-                                                  (long)dim, (long)dim, dim, 0};
+                            {
+                                const size_t tap = (size_t)(kr * k + kc), wsz = (size_t)2 * dim * dim;
+                                g.src[ns++] = GemmSrc{pl.XV(l, ir * GRID + ic), ly.wv + tap * wsz, (long)dim, (long)dim, dim, 0,
+                                                      ly.wv_p ? ly.wv_p + tap * wsz : nullptr, (long)(KR * k) * (long)wsz};
+                            }
                         }
                     }
                     float* out = pl.XV(l + 1, r * GRID + c);
@@ -214,13 +217,16 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
                     const int k = (l == 0) ? 5 : 3, pad = k / 2, KC = k / 2 + 1;
                     GemmParams g = {};
                     int ns = 0;
-                    g.src[ns++] = GemmSrc{pl.HV(l, c), ly.wv2h, (long)2 * dim, (long)2 * dim, 2 * dim, 0};
+                    g.src[ns++] = GemmSrc{pl.HV(l, c), ly.wv2h, (long)2 * dim, (long)2 * dim, 2 * dim, 0, ly.wv2h_p, (long)4 * dim * dim};
                     for (int kc = 0; kc < KC; ++kc) {
                         if (l == 0 && kc == KC - 1) continue;            // mask 'A': last kernel column
                         const int ic = c - pad + kc;
                         if (ic < 0) continue;
-                        g.src[ns++] = GemmSrc{pl.XH(l, r * GRID + ic), ly.wh + (size_t)kc * 2 * dim * dim, (long)dim, (long)dim,
-                                              dim, 0};
+                        {
+                            const size_t wsz = (size_t)2 * dim * dim;
+                            g.src[ns++] = GemmSrc{pl.XH(l, r * GRID + ic), ly.wh + kc * wsz, (long)dim, (long)dim, dim, 0,
+                                                  ly.wh_p ? ly.wh_p + kc * wsz : nullptr, (long)KC * (long)wsz};
+                        }
                     }
                     g.nsrc = ns;
                     g.M = Bc;
@@ -232,7 +238,7 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
                     g.ldo = dim;
                     DVQ_PROPAGATE(dvq_launch_gemm(g, EPI_GATE, st));
                     GemmParams q = {};
-                    q.src[0] = GemmSrc{pl.g, ly.wr, (long)dim, (long)dim, dim, 0};
+                    q.src[0] = GemmSrc{pl.g, ly.wr, (long)dim, (long)dim, dim, 0, ly.wr_p, (long)dim * dim};
                     q.nsrc = 1;
                     q.M = Bc;
                     q.N = dim;
@@ -248,11 +254,11 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
                     }
                 }
                 GemmParams h0 = {};
-                h0.src[0] = GemmSrc{pl.XH(L, pos), w->w0, (long)dim, (long)dim, dim, 0};
+                h0.src[0] = GemmSrc{pl.XH(L, pos), w->w0, (long)dim, (long)dim, dim, 0, w->w0_p, (long)w->n_hidden * dim};
                 h0.nsrc = 1; h0.M = Bc; h0.N = w->n_hidden; h0.bias = w->b0; h0.out = pl.hid; h0.ldo = w->n_hidden; h0.relu = 1;
                 DVQ_PROPAGATE(dvq_launch_gemm(h0, EPI_BIAS, st));
                 GemmParams h2 = {};
-                h2.src[0] = GemmSrc{pl.hid, w->w2, (long)w->n_hidden, (long)w->n_hidden, w->n_hidden, 0};
+                h2.src[0] = GemmSrc{pl.hid, w->w2, (long)w->n_hidden, (long)w->n_hidden, w->n_hidden, 0, w->w2_p, (long)w->n_in * w->n_hidden};
                 h2.nsrc = 1; h2.M = Bc; h2.N = w->n_in; h2.bias = w->b2; h2.out = pl.lg; h2.ldo = w->n_in;
                 DVQ_PROPAGATE(dvq_launch_gemm(h2, EPI_BIAS, st));
                 {

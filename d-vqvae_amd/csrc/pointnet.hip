@@ -71,10 +71,10 @@ PnScratch plan(int64_t B, int N, void* ws) {
     return s;
 }
 
-int dense(const float* x, long ldx, int K, const float* w, const float* b, long M, int N, int relu, float* y, long ldy,
-          hipStream_t st) {
+int dense(const float* x, long ldx, int K, const float* w, const uint16_t* wp, const float* b, long M, int N, int relu,
+          float* y, long ldy, hipStream_t st) {
     GemmParams p = {};
-    p.src[0] = GemmSrc{x, w, ldx, (long)K, K, 0};
+    p.src[0] = GemmSrc{x, w, ldx, (long)K, K, 0, wp, (long)N * K};
     p.nsrc = 1;
     p.M = M;
     p.N = N;
@@ -86,7 +86,7 @@ int dense(const float* x, long ldx, int K, const float* w, const float* b, long 
 }
 
 int trunk(const float* pc, int C, int N, long Bc, const float* trans, const float* w1, const float* b1, const float* w2,
-          const float* b2, const float* w3, const float* b3, int relu3, const PnScratch& s, float* feat, long ld_feat,
+          const uint16_t* w2p, const float* b2, const float* w3, const uint16_t* w3p, const float* b3, int relu3, const PnScratch& s, float* feat, long ld_feat,
           hipStream_t st) {
     const long rows = Bc * s.Npad;
     const long threads = rows * 16;
@@ -96,9 +96,9 @@ int trunk(const float* pc, int C, int N, long Bc, const float* trans, const floa
                            trans, w1, b1, s.h1);
     }
     DVQ_CHECK_LAUNCH("pn_layer1");
-    DVQ_PROPAGATE(dense(s.h1, 64, 64, w2, b2, rows, 128, 1, s.h2, 128, st));
+    DVQ_PROPAGATE(dense(s.h1, 64, 64, w2, w2p, b2, rows, 128, 1, s.h2, 128, st));
     GemmParams p = {};
-    p.src[0] = GemmSrc{s.h2, w3, 128, 128, 128, 0};
+    p.src[0] = GemmSrc{s.h2, w3, 128, 128, 128, 0, w3p, 1024L * 128};
     p.nsrc = 1;
     p.M = rows;
     p.N = 1024;
@@ -137,15 +137,15 @@ extern "C" int dvq_pointnet_encode(const dvq_pointnet_weights* w, const float* p
         const long Bc = (long)((B - b0 < s.chunk) ? (B - b0) : s.chunk);
         const float* pcb = pc + b0 * (long)w->C * N;
         // STN3d: trunk with ReLU on the last layer, then fc1/fc2 (BN folded, ReLU) and fc3 (+identity)
-        DVQ_PROPAGATE(trunk(pcb, w->C, N, Bc, nullptr, w->s_w1, w->s_b1, w->s_w2, w->s_b2, w->s_w3, w->s_b3, 1, s, s.f0,
-                            1024, st));
-        DVQ_PROPAGATE(dense(s.f0, 1024, 1024, w->s_f1, w->s_c1, Bc, 512, 1, s.f1, 512, st));
-        DVQ_PROPAGATE(dense(s.f1, 512, 512, w->s_f2, w->s_c2, Bc, 256, 1, s.f2, 256, st));
+        DVQ_PROPAGATE(trunk(pcb, w->C, N, Bc, nullptr, w->s_w1, w->s_b1, w->s_w2, w->s_w2p, w->s_b2, w->s_w3, w->s_w3p, w->s_b3,
+                            1, s, s.f0, 1024, st));
+        DVQ_PROPAGATE(dense(s.f0, 1024, 1024, w->s_f1, w->s_f1p, w->s_c1, Bc, 512, 1, s.f1, 512, st));
+        DVQ_PROPAGATE(dense(s.f1, 512, 512, w->s_f2, w->s_f2p, w->s_c2, Bc, 256, 1, s.f2, 256, st));
         float* tr = trans_out ? trans_out + b0 * 9 : s.tr;
-        DVQ_PROPAGATE(dense(s.f2, 256, 256, w->s_f3, w->s_c3, Bc, 9, 0, tr, 9, st));
+        DVQ_PROPAGATE(dense(s.f2, 256, 256, w->s_f3, w->s_f3p, w->s_c3, Bc, 9, 0, tr, 9, st));
         // main trunk on the transformed cloud; no ReLU after the last BN (pointnet_encoder.py:162)
-        DVQ_PROPAGATE(trunk(pcb, w->C, N, Bc, tr, w->w1, w->b1, w->w2, w->b2, w->w3, w->b3, 0, s, feat + b0 * ld_feat,
-                            ld_feat, st));
+        DVQ_PROPAGATE(trunk(pcb, w->C, N, Bc, tr, w->w1, w->b1, w->w2, w->w2p, w->b2, w->w3, w->w3p, w->b3, 0, s,
+                            feat + b0 * ld_feat, ld_feat, st));
     }
     return DVQ_OK;
 }

@@ -10,7 +10,7 @@ import os
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import ops, packing
 from .pointnet_encoder import PointNetEncoder
 from .VQVAE import VQVAE
 
@@ -26,15 +26,26 @@ def _codebooks(mod, n_embeddings=128):
 
 
 class _MLP(nn.Module):
+    def _planes(self, lin):
+        """split-bf16 image of a Linear's weight, rebuilt when the parameter is replaced, moved or edited in place"""
+        w = lin.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        cache = self.__dict__.setdefault("_plane_cache", {})
+        hit = cache.get(id(lin))
+        if hit is None or hit[0] != key:
+            hit = (key, packing.split_bf16x3(w.detach()))
+            cache[id(lin)] = hit
+        return hit[1]
+
     def _run(self, x, final=None):
         layers = [m for m in self.MLP if isinstance(m, nn.Linear)]
         n = len(layers)
         for i, lin in enumerate(layers):
             last = final is None and i + 1 == n
             x = ops.linear(x if x.is_contiguous() else x.contiguous(), lin.weight.detach(), lin.bias.detach(),
-                           relu=not last)
+                           relu=not last, planes=self._planes(lin))
         if final is not None:
-            x = ops.linear(x, final.weight.detach(), final.bias.detach())
+            x = ops.linear(x, final.weight.detach(), final.bias.detach(), planes=self._planes(final))
         return x
 
 

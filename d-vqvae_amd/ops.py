@@ -79,13 +79,14 @@ def new_err_flag(dev: torch.device) -> Tensor:
 
 # ------------------------------------------------------------------------------------------ dense
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, relu: bool = False,
-           out: Optional[Tensor] = None) -> Tensor:
-    """y = act(x @ weight^T + bias) on the fp32 MFMA GEMM (dvq_linear)."""
-    return linear_multi([(x, weight)], bias, relu, out)
+           out: Optional[Tensor] = None, planes: Optional[Tensor] = None) -> Tensor:
+    """y = act(x @ weight^T + bias) (dvq_linear).  ``planes`` = packing.split_bf16x3(weight) skips the on-the-fly
+    split of the weight operand on the split-bf16 path."""
+    return linear_multi([(x, weight)], bias, relu, out, planes=[planes] if planes is not None else None)
 
 
 def linear_multi(pairs: Sequence[Tuple[Tensor, Tensor]], bias: Optional[Tensor] = None, relu: bool = False,
-                 out: Optional[Tensor] = None) -> Tensor:
+                 out: Optional[Tensor] = None, planes: Optional[Sequence[Tensor]] = None) -> Tensor:
     lib = _lib.load()
     dev = _require_gpu(*[t for p in pairs for t in p], bias, out)
     M = pairs[0][0].shape[0]
@@ -97,7 +98,13 @@ def linear_multi(pairs: Sequence[Tuple[Tensor, Tensor]], bias: Optional[Tensor] 
             raise RuntimeError(f"linear: shape mismatch x{tuple(x.shape)} w{tuple(w.shape)}")
         px, ldx = _rows(x, "x")
         pw, ldw = _rows(w, "weight")
-        srcs[i] = _lib.GemmSrc(px, pw, ldx, ldw, x.shape[1], 0)
+        wp, wps = None, 0
+        if planes is not None:
+            pl = planes[i]
+            if pl.dtype != torch.int16 or tuple(pl.shape) != (3,) + tuple(w.shape) or not pl.is_contiguous() or not w.is_contiguous():
+                raise RuntimeError("linear: planes must be the contiguous int16 [3,N,K] split of a contiguous weight")
+            wp, wps = pl.data_ptr(), w.numel()
+        srcs[i] = _lib.GemmSrc(px, pw, ldx, ldw, x.shape[1], 0, wp, wps)
     if bias is not None:
         _f32(bias, "bias")
         if bias.numel() != N or not bias.is_contiguous():

@@ -36,6 +36,17 @@ def fold_bn(w: Tensor, b: Tensor, sd: Mapping[str, Tensor], bn: str):
     return (w64 * s[:, None]).float(), ((b64 - mu) * s + beta).float()
 
 
+def split_bf16x3(w: Tensor) -> Tensor:
+    """[3, *w.shape] int16 bf16 bit patterns with planes[0] + planes[1] + planes[2] == w exactly (dvq_split_bf16x3)."""
+    lib = _lib.load()
+    w = w.contiguous()
+    out = torch.empty((3,) + tuple(w.shape), dtype=torch.int16, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(lib.dvq_split_bf16x3(w.data_ptr(), w.numel(), out.data_ptr(),
+                                        torch.cuda.current_stream(w.device).cuda_stream), "dvq_split_bf16x3")
+    return out
+
+
 class _Packed:
     """Holds device tensors + the ctypes struct that points at them; re-homed lazily with .to(device)."""
 
@@ -50,10 +61,20 @@ class _Packed:
             device = torch.device("cuda", torch.cuda.current_device())
         if self.device == device:
             return self
-        self.tensors = {k: _dev(v, device) for k, v in self.tensors.items()}
+        self.tensors = {k: (v.to(device) if v.dtype == torch.int16 else _dev(v, device)) for k, v in self.tensors.items()
+                        if not k.endswith("__planes")}
         self.device = device
+        for name in self.PLANES:                        # split-bf16 images of the GEMM weights, built on the device
+            for key in [k for k in self.tensors if k == name or (k.startswith(name) and k[len(name):].isdigit())]:
+                self.tensors[key + "__planes"] = split_bf16x3(self.tensors[key])
         self._bind()
         return self
+
+    PLANES = ()
+
+    def planes_ptr(self, key):
+        t = self.tensors.get(key + "__planes")
+        return t.data_ptr() if t is not None else None
 
     def _bind(self):
         raise NotImplementedError
@@ -85,8 +106,13 @@ class PackedPointNet(_Packed):
         s = _lib.PointnetWeights()
         s.C = self.C
         for name, _ in _lib.PointnetWeights._fields_[2:]:
-            setattr(s, name, self.tensors[name].data_ptr())
+            if name.endswith("p"):
+                setattr(s, name, self.planes_ptr(name[:-1]))
+            else:
+                setattr(s, name, self.tensors[name].data_ptr())
         self.cstruct = s
+
+    PLANES = ("s_w2", "s_w3", "s_f1", "s_f2", "s_f3", "w2", "w3")
 
 
 def gate_perm(dim: int) -> Tensor:
@@ -136,13 +162,19 @@ class PackedPixelCNN(_Packed):
         self._layers = (_lib.PixelcnnLayer * self.n_layers)()
         for i in range(self.n_layers):
             for name, _ in _lib.PixelcnnLayer._fields_:
-                setattr(self._layers[i], name, t[f"{name}{i}"].data_ptr())
+                if name.endswith("_p"):
+                    setattr(self._layers[i], name, self.planes_ptr(f"{name[:-2]}{i}"))
+                else:
+                    setattr(self._layers[i], name, t[f"{name}{i}"].data_ptr())
         s = _lib.PixelcnnWeights()
         s.n_layers, s.dim, s.n_in, s.n_classes, s.n_hidden = self.n_layers, self.dim, self.n_in, self.n_classes, self.n_hidden
         s.tok_emb = t["tok_emb"].data_ptr()
         s.layers_host = C.cast(self._layers, C.POINTER(_lib.PixelcnnLayer))
         s.w0, s.b0, s.w2, s.b2 = (t[k].data_ptr() for k in ("w0", "b0", "w2", "b2"))
+        s.w0_p, s.w2_p = self.planes_ptr("w0"), self.planes_ptr("w2")
         self.cstruct = s
+
+    PLANES = ("wv", "wh", "wv2h", "wr", "w0", "w2")
 
 
 class PackedMano(_Packed):

@@ -45,13 +45,19 @@ int dvq_device_count(void);
 /* ------------------------------------------------------------------ generic dense layer (MFMA fp32)
  * y[M,N] = act( sum_s x_s[M,K_s] @ w_s[N,K_s]^T + bias[N] ) -- nn.Linear / 1x1 conv / conv taps.
  * Replaces: Decoder.forward (network/DVQVAE.py:183-185), STN3d fc1..fc3 (pointnet_encoder.py:35-37),
- * Encoder.forward (DVQVAE.py:161-166).  K_s % 32 == 0, 16-byte aligned rows. */
+ * Encoder.forward (DVQVAE.py:161-166).  K_s % 32 == 0, 16-byte aligned rows.
+ * Arithmetic ("split-bf16", default): every fp32 operand is split exactly into three bf16 pieces and the six
+ * partial products of weight >= 2^-24 are accumulated in fp32 on the bf16 matrix cores -- fp32-GEMM accuracy at
+ * 2.67x fewer MFMA cycles.  DVQ_GEMM=fp32 in the environment selects v_mfma_f32_32x32x2_f32 instead.  Weights may be
+ * handed over pre-split (`wp`, built by dvq_split_bf16x3) to skip their on-the-fly split. */
 typedef struct {
     const float* x; /* [M, K] row stride ldx */
     const float* w; /* [N, K] row stride ldw */
     int64_t ldx, ldw;
     int32_t K;
     int32_t _pad;
+    const uint16_t* wp; /* optional: w pre-split into three bf16 planes [3][N][ldw] (see "split-bf16" below) */
+    int64_t wp_plane;   /* elements between planes */
 } dvq_gemm_src;
 
 #define DVQ_MAX_SRC 8
@@ -60,6 +66,8 @@ typedef struct {
 
 int dvq_linear(const dvq_gemm_src* src_host, int nsrc, int64_t M, int N, const float* bias,
                int act, float* y, int64_t ldy, dvq_stream_t stream);
+/* planes[p][i] (p = 0,1,2; bf16 bit patterns) with w[i] == planes[0][i] + planes[1][i] + planes[2][i] exactly */
+int dvq_split_bf16x3(const float* w, int64_t n, uint16_t* planes, dvq_stream_t stream);
 
 /* ------------------------------------------------------------------ VQ codebook nearest neighbour
  * VectorQuantizer.forward(z, istrain=False), network/vqvae/quantizer.py:46-49:
@@ -108,6 +116,8 @@ typedef struct {
     const float *w1, *b1;     /* [64,4] */
     const float *w2, *b2;     /* [128,64] */
     const float *w3, *b3;     /* [1024,128] */
+    /* optional split-bf16 planes ([3][out][in], dvq_split_bf16x3) of the GEMM weights; all-or-nothing */
+    const uint16_t *s_w2p, *s_w3p, *s_f1p, *s_f2p, *s_f3p, *w2p, *w3p;
 } dvq_pointnet_weights;
 
 size_t dvq_pointnet_workspace_bytes(int64_t B, int N);
@@ -131,6 +141,8 @@ typedef struct {
     const float* cls;  /* class_cond_embedding [n_classes][2*dim] gate-packed              */
     const float* wr;   /* horiz_resid [dim][dim]                                           */
     const float* br;   /* [dim]                                                            */
+    /* optional split-bf16 planes (dvq_split_bf16x3 of the whole tensor): [3][n_taps][2*dim][dim] for wv / wh */
+    const uint16_t *wv_p, *wh_p, *wv2h_p, *wr_p;
 } dvq_pixelcnn_layer;
 
 typedef struct {
@@ -140,6 +152,7 @@ typedef struct {
     const dvq_pixelcnn_layer* layers_host; /* host array [n_layers]; layer 0: mask A applied, k=5 */
     const float *w0, *b0;       /* output_conv.0 [n_hidden][dim] */
     const float *w2, *b2;       /* output_conv.2 [n_in][n_hidden] */
+    const uint16_t *w0_p, *w2_p; /* optional split-bf16 planes */
 } dvq_pixelcnn_weights;
 
 size_t dvq_pixelcnn_workspace_bytes(const dvq_pixelcnn_weights* w_host, int64_t B);
