@@ -95,6 +95,7 @@ struct GemmParams {
     float* part_val;         // [tiles_m][N]
     int* part_idx;           // [tiles_m][N]
     int dbg_abl;             // diagnostics only (env DVQ_GEMM_ABL): 2 = no MFMAs
+    unsigned long long* dbg_clk;   // diagnostics only (env DVQ_GEMM_CLK=1): block 0 stores {memtime, memrealtime} x {begin, end}
 };
 
 // torch.argmin ordering: a NaN beats everything, among equals the lower index wins

@@ -240,6 +240,221 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const GemmParams p)
     gemm_epilogue<EPI>(p, acc, m0, n0, mt, nt, tid, reinterpret_cast<float*>(smem_c));
 }
 
+// ================================================================================================================
+// LDS-DMA variant (pre-split weights): nothing goes through registers on the way in.  Per K-tile of 32 every wave issues
+// 4 + 6 global_load_lds (1 KiB each): the fp32 activation tile [128][32] and the three bf16 weight planes [128][32],
+// both as lane-linear images whose 16-byte chunks are XOR-swizzled on the SOURCE address (fp32 rows: chunk ^ ((row>>1)&7),
+// bf16 rows: chunk ^ ((row>>2)&3)) so that the fragment ds_read_b128 are bank-conflict free.  The activation fragment is
+// split exactly into its three bf16 pieces in registers at read time -- vector work that hides under the wave's own MFMAs --
+// so there are no LDS stores and one barrier per K-tile (two stages, the next tile's DMA flies during the MFMAs).
+constexpr int D_A_BYTES = 128 * 128;                       // fp32 [128 rows][32 k]
+constexpr int D_WPL_BYTES = 128 * 64;                      // one bf16 plane [128 rows][32 k]
+constexpr int D_STAGE = D_A_BYTES + 3 * D_WPL_BYTES;       // 40 960 B
+constexpr size_t D_SMEM = 2 * D_STAGE;                     // 81 920 B: two workgroups per CU
+
+struct DmaCursor {
+    int s, k_left;
+    const float* a_ptr[4];
+    const uint16_t* w_ptr[3][2];
+
+    __device__ __forceinline__ void open(const GemmParams& p, int src_i, long m0, int n0, int wave, int lane) {
+        s = src_i;
+        if (s >= p.nsrc) { k_left = 0; return; }
+        const GemmSrc& src = p.src[s];
+        k_left = src.K;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                      // 8 rows x 128 B per DMA
+            const int row = 32 * wave + 8 * g + (lane >> 3);
+            long m = m0 + row;
+            if (m >= p.M) m = p.M - 1;                     // clamped rows only feed outputs the epilogue masks
+            a_ptr[g] = src.A + m * src.lda + 4 * ((lane & 7) ^ ((row >> 1) & 7));
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {                      // 16 rows x 64 B per DMA
+            const int row = 32 * wave + 16 * g + (lane >> 2);
+            int n = n0 + row;
+            if (n >= p.N) n = p.N - 1;
+            const uint16_t* base = src.Wp + (long)n * src.ldw + 8 * ((lane & 3) ^ ((row >> 2) & 3));
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) w_ptr[pl][g] = base + pl * src.wp_plane;
+        }
+    }
+    __device__ __forceinline__ bool valid() const { return k_left > 0; }
+    __device__ __forceinline__ void issue(const GemmParams& p, long m0, int n0, int wave, int lane, char* stage) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)a_ptr[g],
+                                             (__attribute__((address_space(3))) void*)(stage + (32 * wave + 8 * g) * 128), 16, 0, 0);
+            a_ptr[g] += BK;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[pl][g],
+                                                 (__attribute__((address_space(3))) void*)(stage + D_A_BYTES + pl * D_WPL_BYTES +
+                                                                                          (32 * wave + 16 * g) * 64), 16, 0, 0);
+                w_ptr[pl][g] += BK;
+            }
+        k_left -= BK;
+        if (k_left <= 0) open(p, s + 1, m0, n0, wave, lane);
+    }
+};
+
+__device__ __forceinline__ void split_frag(const f32x4& lo, const f32x4& hi, bf16x8 (&out)[3]) {
+    unsigned p[3][4];
+    split3_pair(lo[0], lo[1], p[0][0], p[1][0], p[2][0]);
+    split3_pair(lo[2], lo[3], p[0][1], p[1][1], p[2][1]);
+    split3_pair(hi[0], hi[1], p[0][2], p[1][2], p[2][2]);
+    split3_pair(hi[2], hi[3], p[0][3], p[1][3], p[2][3]);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) out[pl] = __builtin_bit_cast(bf16x8, uint4{p[pl][0], p[pl][1], p[pl][2], p[pl][3]});
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    const int tid = threadIdx.x;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const long tiles_m = (p.M + BM - 1) / BM;
+    const long b = blockIdx.x;
+    const long j = b >> 3;
+    const long mt = (j / tiles_n) * 8 + (b & 7);
+    const int nt = (int)(j % tiles_n);
+    if (mt >= tiles_m) return;
+    const long m0 = mt * BM;
+    const int n0 = nt * BN;
+
+    constexpr bool SWAP = EPI != EPI_COLMAX;   // store epilogues use the transposed accumulator layout (gemm_common.h)
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+
+    if (p.dbg_clk && blockIdx.x == 0 && tid == 0) {
+        p.dbg_clk[0] = __builtin_amdgcn_s_memtime();
+        p.dbg_clk[1] = __builtin_amdgcn_s_memrealtime();
+    }
+    DmaCursor cur;
+    cur.open(p, 0, m0, n0, wave, lane);
+    cur.issue(p, m0, n0, wave, lane, smem_c);
+    int stage = 0;
+    // fragment addressing (constant over the loop)
+    int a_off[2], a_sw[2], w_off[2], w_sw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int arow = wm * 64 + i * 32 + r, wrow = wn * 64 + i * 32 + r;
+        a_off[i] = arow * 128;
+        a_sw[i] = (arow >> 1) & 7;
+        w_off[i] = D_A_BYTES + wrow * 64;
+        w_sw[i] = (wrow >> 2) & 3;
+    }
+    while (true) {
+        __syncthreads();                                   // the DMA of this tile has landed for every wave (vmcnt(0) + barrier);
+                                                           // everybody is done reading the other stage
+        const bool more = cur.valid();
+        if (more) cur.issue(p, m0, n0, wave, lane, smem_c + (stage ^ 1) * D_STAGE);
+        const char* st = smem_c + stage * D_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 w[2][3];
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    w[jn][pl] = *reinterpret_cast<const bf16x8*>(st + w_off[jn] + pl * D_WPL_BYTES + 16 * ((2 * ks + h) ^ w_sw[jn]));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c0 = 4 * ks + 2 * h;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(st + a_off[i] + 16 * (c0 ^ a_sw[i]));
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(st + a_off[i] + 16 * ((c0 + 1) ^ a_sw[i]));
+                bf16x8 a[3];
+                split_frag(lo, hi, a);
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) {
+                    f32x16 c = acc[i][jn];
+                    if constexpr (SWAP) {       // weights as operand A: lanes <-> rows, registers <-> columns (16-byte stores)
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[jn][0], a[2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[jn][2], a[0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[jn][1], a[1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[jn][0], a[1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[jn][1], a[0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[jn][0], a[0], c, 0, 0, 0);
+                    } else {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], w[jn][0], c, 0, 0, 0);     // a3 b1
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], w[jn][2], c, 0, 0, 0);     // a1 b3
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], w[jn][1], c, 0, 0, 0);     // a2 b2
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], w[jn][0], c, 0, 0, 0);     // a2 b1
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], w[jn][1], c, 0, 0, 0);     // a1 b2
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], w[jn][0], c, 0, 0, 0);     // a1 b1
+                    }
+                    acc[i][jn] = c;
+                }
+            }
+        }
+        if (!more) break;
+        stage ^= 1;
+    }
+    if (p.dbg_clk && blockIdx.x == 0 && tid == 0) {
+        p.dbg_clk[2] = __builtin_amdgcn_s_memtime();
+        p.dbg_clk[3] = __builtin_amdgcn_s_memrealtime();
+    }
+    if constexpr (SWAP) {
+        gemm_epilogue_t<EPI>(p, acc, m0, n0, nt, tid);
+    } else {
+        __syncthreads();
+        gemm_epilogue<EPI>(p, acc, m0, n0, mt, nt, tid, reinterpret_cast<float*>(smem_c));
+    }
+}
+
+template <int EPI>
+int launch_dma(const GemmParams& p, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_dma_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_SMEM);
+        if (e != hipSuccess) {
+            dvq_set_error("gemm_bf16x3: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return DVQ_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    const long tiles_m = (p.M + BM - 1) / BM;
+    const long tiles_n = (p.N + BN - 1) / BN;
+    const long grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
+    static const char* const names[] = {"gemm_bias", "gemm_resid", "gemm_gate", "gemm_colmax", "gemm_argmin"};
+    double ksum = 0;
+    for (int s = 0; s < p.nsrc; ++s) ksum += p.src[s].K;
+    static unsigned long long* clk_buf = nullptr;
+    GemmParams q = p;
+    if (getenv("DVQ_GEMM_CLK")) {
+        if (!clk_buf) (void)hipMalloc(&clk_buf, 64);
+        q.dbg_clk = clk_buf;
+    }
+    {
+        DVQ_PROF(names[EPI], 2.0 * (double)p.M * p.N * ksum, ((double)p.M + p.N) * ksum * 4, stream);
+        hipLaunchKernelGGL((gemm_bf16x3_dma_kernel<EPI>), dim3((unsigned)grid), dim3(256), D_SMEM, stream, q);
+    }
+    if (q.dbg_clk) {
+        unsigned long long hbuf[4];
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(hbuf, clk_buf, 32, hipMemcpyDeviceToHost);
+        const double cyc = (double)(hbuf[2] - hbuf[0]), ref = (double)(hbuf[3] - hbuf[1]);
+        fprintf(stderr, "[dvq clk] block 0 main loop: %.0f memtime ticks, %.0f x 10 ns -> memtime ticks at %.1f MHz, span %.1f us\n", cyc, ref,
+                ref > 0 ? cyc / ref * 100.0 : 0.0, ref * 0.01);
+    }
+    DVQ_CHECK_LAUNCH("gemm_bf16x3_dma");
+    return DVQ_OK;
+}
+
 __global__ void split_bf16x3_kernel(const float* __restrict__ w, long n, uint16_t* __restrict__ planes) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -286,6 +501,22 @@ int dvq_launch_gemm_bf16x3(const GemmParams& p, GemmEpilogue epi, hipStream_t st
     if (const char* e = getenv("DVQ_GEMM_ABL")) const_cast<GemmParams&>(p).dbg_abl = atoi(e);
     bool planes = true;                                              // pre-split weights: all-or-nothing per launch
     for (int s = 0; s < p.nsrc; ++s) planes = planes && p.src[s].Wp != nullptr;
+    static const bool use_dma = !(getenv("DVQ_GEMM_NODMA") && getenv("DVQ_GEMM_NODMA")[0] == '1');
+    if (planes && use_dma) {
+        bool aligned = true;                       // the DMA moves 16-byte chunks: every pointer and row stride must allow it
+        for (int s = 0; s < p.nsrc; ++s)
+            aligned = aligned && ((reinterpret_cast<uintptr_t>(p.src[s].Wp) & 15) == 0) && (p.src[s].wp_plane % 8 == 0) &&
+                      (p.src[s].ldw % 8 == 0);
+        if (aligned) {
+            switch (epi) {
+                case EPI_BIAS: return launch_dma<EPI_BIAS>(p, stream);
+                case EPI_RESID: return launch_dma<EPI_RESID>(p, stream);
+                case EPI_GATE: return launch_dma<EPI_GATE>(p, stream);
+                case EPI_COLMAX: return launch_dma<EPI_COLMAX>(p, stream);
+                default: break;
+            }
+        }
+    }
     switch (epi) {
         case EPI_BIAS: return planes ? launch<EPI_BIAS, true>(p, stream) : launch<EPI_BIAS, false>(p, stream);
         case EPI_RESID: return planes ? launch<EPI_RESID, true>(p, stream) : launch<EPI_RESID, false>(p, stream);

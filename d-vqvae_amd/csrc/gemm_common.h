@@ -128,3 +128,74 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Transposed accumulator layout (MFMA called with the weight fragment as operand A): lanes <-> rows m, registers <-> columns n.
+// acc[i][jn][e] holds row m = m0 + wm*64 + i*32 + r and column n = n0 + wn*64 + jn*32 + (e&3) + 8*(e>>2) + 4*h, so registers
+// 4g..4g+3 are FOUR CONSECUTIVE columns of one row: every store is a 16-byte store (the default layout needs 4x as many
+// 4-byte store instructions, and the store tail is issue-bound).  Store epilogues only (bias / residual / gate).
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_t(const GemmParams& p, f32x16 (&acc)[2][2], long m0, int n0, int nt, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const bool vec_ok = (p.N % 4 == 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long m = m0 + wm * 64 + i * 32 + r;
+        if (m >= p.M) continue;
+        if constexpr (EPI == EPI_BIAS || EPI == EPI_RESID) {
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wn * 64 + jn * 32 + 8 * g + 4 * h;
+                    if (n >= p.N) continue;
+                    f32x4 v = {acc[i][jn][4 * g], acc[i][jn][4 * g + 1], acc[i][jn][4 * g + 2], acc[i][jn][4 * g + 3]};
+                    const bool full = vec_ok && n + 3 < p.N && (p.ldo % 4 == 0);
+                    if (full) {
+                        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                        if constexpr (EPI == EPI_RESID) v += *reinterpret_cast<const f32x4*>(p.resid + m * p.ldr + n);
+                        if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                        *reinterpret_cast<f32x4*>(p.out + m * p.ldo + n) = v;
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            if (n + c >= p.N) continue;
+                            float x = v[c] + (p.bias ? p.bias[n + c] : 0.f);
+                            if constexpr (EPI == EPI_RESID) x += p.resid[m * p.ldr + n + c];
+                            if (p.relu) x = fmaxf(x, 0.f);
+                            p.out[m * p.ldo + n + c] = x;
+                        }
+                    }
+                }
+        } else if constexpr (EPI == EPI_GATE) {
+            const float* crow = p.cls ? p.cls + (long)p.label[m] * p.N : nullptr;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = 8 * g + 4 * h;
+                const int na = n0 + wn * 64 + nl;        // gate-packed index of the tanh channels
+                const int nb = na + 32;                  // ... of their sigmoid partners
+                const int c = nt * 64 + wn * 32 + nl;    // natural output channels
+                f32x4 a = {acc[i][0][4 * g], acc[i][0][4 * g + 1], acc[i][0][4 * g + 2], acc[i][0][4 * g + 3]};
+                f32x4 gg = {acc[i][1][4 * g], acc[i][1][4 * g + 1], acc[i][1][4 * g + 2], acc[i][1][4 * g + 3]};
+                if (p.bias) {
+                    a += *reinterpret_cast<const f32x4*>(p.bias + na);
+                    gg += *reinterpret_cast<const f32x4*>(p.bias + nb);
+                }
+                if (p.pre) {
+                    *reinterpret_cast<f32x4*>(p.pre + m * p.ldpre + na) = a;
+                    *reinterpret_cast<f32x4*>(p.pre + m * p.ldpre + nb) = gg;
+                }
+                if (crow) {
+                    a += *reinterpret_cast<const f32x4*>(crow + na);
+                    gg += *reinterpret_cast<const f32x4*>(crow + nb);
+                }
+                f32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = tanhf(a[q]) * sigmoidf_(gg[q]);
+                *reinterpret_cast<f32x4*>(p.out + m * p.ldo + c) = o;
+            }
+        }
+    }
+}
