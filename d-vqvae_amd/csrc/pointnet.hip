@@ -4,6 +4,10 @@
 // the [N,1024] activation is never written.  BatchNorm (eval) is folded into the weights by the packer.
 #include "dvq_internal.h"
 
+int dvq_launch_pn_trunk(const float* pc, int C, int N, long B, const float* trans, const float* W1, const float* b1,
+                        const uint16_t* W2p, const float* b2, const uint16_t* W3p, const float* b3, float* partial,
+                        hipStream_t st);
+
 namespace {
 
 // 16 threads per point, 4 output channels each; rows >= N of a sample's padded block are zero-filled.
@@ -88,6 +92,11 @@ int dense(const float* x, long ldx, int K, const float* w, const uint16_t* wp, c
 int trunk(const float* pc, int C, int N, long Bc, const float* trans, const float* w1, const float* b1, const float* w2,
           const uint16_t* w2p, const float* b2, const float* w3, const uint16_t* w3p, const float* b3, int relu3, const PnScratch& s, float* feat, long ld_feat,
           hipStream_t st) {
+    if (w2p && w3p && dvq_gemm_mode() == 1) {       // fused trunk; w3p is the k-permuted plane image (see pn_trunk_kernel)
+        DVQ_PROPAGATE(dvq_launch_pn_trunk(pc, C, N, Bc, trans, w1, b1, w2p, b2, w3p, b3, s.part, st));
+        return dvq_launch_colmax_reduce(s.part, Bc, s.Npad / 128, 1024, relu3, feat, ld_feat, st);
+    }
+    w3p = nullptr;                                  // the unfused GEMM path takes natural-order planes only: split on the fly
     const long rows = Bc * s.Npad;
     const long threads = rows * 16;
     {
@@ -147,5 +156,228 @@ extern "C" int dvq_pointnet_encode(const dvq_pointnet_weights* w, const float* p
         DVQ_PROPAGATE(trunk(pcb, w->C, N, Bc, tr, w->w1, w->b1, w->w2, w->w2p, w->b2, w->w3, w->w3p, w->b3, 0, s,
                             feat + b0 * ld_feat, ld_feat, st));
     }
+    return DVQ_OK;
+}
+
+// =====================================================================================================================
+// Fused PointNet trunk: conv1 (C->64, VALU) -> conv2 (64->128) -> conv3 (128->1024) -> max over points, ONE kernel,
+// split-bf16 MFMA arithmetic (gemm_bf16x3.hip), nothing but the 16-byte points is read per point and nothing but the
+// per-128-point column maxima is written: the [N,64], [N,128] and [N,1024] activations never leave the CU.
+//   * a wave owns 32 points (lanes): conv1 builds the h1 fragments in registers; conv2 runs with the WEIGHT fragment as
+//     MFMA operand A, so its accumulator (h2 channel on registers, point on lanes) IS the A-operand fragment of conv3 after
+//     ReLU + exact 3-way split -- the k order inside each 16-channel block comes out permuted
+//     (pos 8h+j <-> channel 8(j>>2)+4h+(j&3)), so the packer stores W3 with the same permutation;
+//   * W3 (768 KB of bf16 planes) streams L2 -> LDS by global_load_lds in 24 KB half-chunks (64 output channels x 64 k),
+//     double buffered, one barrier per half-chunk; conv3's A operand stays in 96 VGPRs for the whole kernel;
+//   * column maxima over the wave's 32 points are lane-local (+ one half swap), waves meet once through LDS at the end.
+// Padding points of the last tile duplicate point N-1 (a max ignores duplicates).
+namespace {
+
+typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int T_STAGE = 3 * 64 * 128;                    // one half-chunk: 3 planes x 64 rows x 128 B
+constexpr int T_OFF_RED = 2 * T_STAGE;                   // [4 waves][1024] fp32
+constexpr int T_OFF_W1 = T_OFF_RED + 4 * 1024 * 4;       // [64][4] fp32
+constexpr int T_OFF_B1 = T_OFF_W1 + 64 * 4 * 4;          // [64]
+constexpr int T_OFF_B2 = T_OFF_B1 + 64 * 4;              // [128]
+constexpr int T_LDS = T_OFF_B2 + 128 * 4;                // 67 328 B -> 2 workgroups per CU
+
+__device__ __forceinline__ void t_split_pair(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+    const unsigned a0 = __float_as_uint(x0) & 0xffff0000u, a1 = __float_as_uint(x1) & 0xffff0000u;
+    const float r0 = x0 - __uint_as_float(a0), r1 = x1 - __uint_as_float(a1);
+    const unsigned b0 = __float_as_uint(r0) & 0xffff0000u, b1 = __float_as_uint(r1) & 0xffff0000u;
+    const float s0 = r0 - __uint_as_float(b0), s1 = r1 - __uint_as_float(b1);
+    p1 = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+    p2 = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+    p3 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+
+// eight fp32 values -> three bf16x8 fragments (exact split)
+__device__ __forceinline__ void t_split8(const float (&v)[8], pbf16x8 (&out)[3]) {
+    unsigned p[3][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t_split_pair(v[2 * q], v[2 * q + 1], p[0][q], p[1][q], p[2][q]);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) out[pl] = __builtin_bit_cast(pbf16x8, uint4{p[pl][0], p[pl][1], p[pl][2], p[pl][3]});
+}
+
+// DMA one half-chunk (3 planes x 64 rows x 128 B) of a [rows][ld] bf16 plane set into an LDS stage; 24 x 1 KiB pieces,
+// six per wave; rows of 128 B = 8 chunks, chunk c of row r lands at chunk c ^ ((r >> 1) & 7)
+__device__ __forceinline__ void t_issue(const uint16_t* __restrict__ planes, long plane_stride, long ld, int row0, int k0,
+                                        char* stage, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int id = wave * 6 + i;
+        const int pl = id >> 3, rb = id & 7;
+        const int row = rb * 8 + (lane >> 3);
+        const uint16_t* src = planes + pl * plane_stride + (long)(row0 + row) * ld + k0 + 8 * ((lane & 7) ^ ((row >> 1) & 7));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(stage + (pl * 64 + rb * 8) * 128), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ pbf16x8 t_frag(const char* stage, int pl, int row, int chunk) {
+    return *reinterpret_cast<const pbf16x8*>(stage + (pl * 64 + row) * 128 + 16 * (chunk ^ ((row >> 1) & 7)));
+}
+
+#define T_MFMA6(ACC, X, Y)                                                            \
+    do {                                                                              \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[2], Y[0], ACC, 0, 0, 0);      \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[0], Y[2], ACC, 0, 0, 0);      \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[1], Y[1], ACC, 0, 0, 0);      \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[1], Y[0], ACC, 0, 0, 0);      \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[0], Y[1], ACC, 0, 0, 0);      \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[0], Y[0], ACC, 0, 0, 0);      \
+    } while (0)
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void pn_trunk_kernel(const float* __restrict__ pc, const float* __restrict__ trans, int N,
+                                                          int tiles, const float* __restrict__ W1, const float* __restrict__ b1,
+                                                          const uint16_t* __restrict__ W2p, const float* __restrict__ b2,
+                                                          const uint16_t* __restrict__ W3p, const float* __restrict__ b3,
+                                                          float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char tl[];
+    float* red = reinterpret_cast<float*>(tl + T_OFF_RED);
+    float* w1s = reinterpret_cast<float*>(tl + T_OFF_W1);
+    float* b1s = reinterpret_cast<float*>(tl + T_OFF_B1);
+    float* b2s = reinterpret_cast<float*>(tl + T_OFF_B2);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const long b = blockIdx.x / tiles;
+    const int tile = blockIdx.x % tiles;
+
+    // W2 planes [3][128][64]: rows of 128 B; rows 0..63 -> stage 0, rows 64..127 -> stage 1
+    t_issue(W2p, 128L * 64, 64, 0, 0, tl, wave, lane);
+    t_issue(W2p, 128L * 64, 64, 64, 0, tl + T_STAGE, wave, lane);
+    w1s[tid] = W1[tid];                                    // 64 x 4
+    if (tid < 64) b1s[tid] = b1[tid];
+    if (tid < 128) b2s[tid] = b2[tid];
+
+    // ---- conv1 on this lane's point (both lane halves hold the same point, different k)
+    int pidx = tile * 128 + wave * 32 + r;
+    if (pidx >= N) pidx = N - 1;
+    const float* src = pc + b * (long)C * N + pidx;
+    float x0 = src[0], x1 = src[N], x2 = src[2L * N];
+    const float x3 = (C > 3) ? src[3L * N] : 0.f;
+    if (trans) {                                           // xyz @ trans[b]  (pointnet_encoder.py:146)
+        const float* t = trans + b * 9;
+        const float n0 = fmaf(x2, t[6], fmaf(x1, t[3], x0 * t[0]));
+        const float n1 = fmaf(x2, t[7], fmaf(x1, t[4], x0 * t[1]));
+        const float n2 = fmaf(x2, t[8], fmaf(x1, t[5], x0 * t[2]));
+        x0 = n0; x1 = n1; x2 = n2;
+    }
+    __syncthreads();                                       // W1/b1/b2 visible, W2 planes landed
+    pbf16x8 h1f[4][3];                                     // B-operand fragments of conv2: k = 16 s + 8 h + j
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * s + 8 * h + j;
+            const f32x4 w = *reinterpret_cast<const f32x4*>(w1s + 4 * k);
+            float a = x0 * w[0];
+            a = fmaf(x1, w[1], a);
+            a = fmaf(x2, w[2], a);
+            a = fmaf(x3, w[3], a);
+            v[j] = fmaxf(a + b1s[k], 0.f);
+        }
+        t_split8(v, h1f[s]);
+    }
+    // ---- conv2: weight fragment as operand A -> accumulator = (h2 channel on registers, point on lanes)
+    pbf16x8 a3[8][3];                                      // conv3 A operand: step = 2 * tile32 + q
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {                       // 32 h2 channels per tile
+        const char* st = tl + (t4 >> 1) * T_STAGE;
+        const int row = 32 * (t4 & 1) + r;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            pbf16x8 wf[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wf[pl] = t_frag(st, pl, row, 2 * s + h);
+            T_MFMA6(acc, wf, h1f[s]);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = 8 * q + j;
+                const int ch = 32 * t4 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                v[j] = fmaxf(acc[e] + b2s[ch], 0.f);
+            }
+            t_split8(v, a3[2 * t4 + q]);
+        }
+    }
+    __syncthreads();                                       // everybody is done with W2 in the stages
+    // ---- conv3: 16 chunks of 64 output channels, each in two K halves of 64
+    t_issue(W3p, 1024L * 128, 128, 0, 0, tl, wave, lane);
+    int stage = 0;
+    for (int c = 0; c < 16; ++c) {
+        f32x16 acc2[2];
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc2[jn][e] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            __syncthreads();                               // this half-chunk landed everywhere; the other stage is free
+            const int nxt = 2 * c + kh + 1;
+            if (nxt < 32) t_issue(W3p, 1024L * 128, 128, 64 * (nxt >> 1), 64 * (nxt & 1), tl + (stage ^ 1) * T_STAGE, wave, lane);
+            const char* st = tl + stage * T_STAGE;
+#pragma unroll
+            for (int sq = 0; sq < 4; ++sq) {
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) {
+                    pbf16x8 wf[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) wf[pl] = t_frag(st, pl, 32 * jn + r, 2 * sq + h);
+                    T_MFMA6(acc2[jn], a3[4 * kh + sq], wf);
+                }
+            }
+            stage ^= 1;
+        }
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {                   // max over this wave's 32 points (rows = registers + lane half)
+            const int n = 64 * c + 32 * jn + r;
+            const float bias = b3[n];
+            float m = acc2[jn][0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) m = fmaxf(m, acc2[jn][e]);
+            m = fmaxf(m, __shfl_xor(m, 32)) + bias;         // max(x + b) == max(x) + b
+            if (h == 0) red[wave * 1024 + n] = m;
+        }
+    }
+    __syncthreads();
+    for (int col = tid; col < 1024; col += 256)
+        partial[(long)blockIdx.x * 1024 + col] = fmaxf(fmaxf(red[col], red[1024 + col]), fmaxf(red[2048 + col], red[3072 + col]));
+}
+
+}  // namespace
+
+int dvq_launch_pn_trunk(const float* pc, int C, int N, long B, const float* trans, const float* W1, const float* b1,
+                        const uint16_t* W2p, const float* b2, const uint16_t* W3p, const float* b3, float* partial,
+                        hipStream_t st) {
+    const int tiles = (N + 127) / 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_trunk_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_trunk_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+        attr_set = true;
+    }
+    const long grid = B * tiles;
+    DVQ_REQUIRE(grid < (1L << 31), "pointnet: grid too large");
+    const double pts = (double)B * tiles * 128;
+    {
+        DVQ_PROF("pn_trunk", 2.0 * pts * (4.0 * 64 + 64.0 * 128 + 128.0 * 1024), pts * 16 + (double)grid * 4096, st);
+        if (C == 3)
+            hipLaunchKernelGGL(pn_trunk_kernel<3>, dim3((unsigned)grid), dim3(256), T_LDS, st, pc, trans, N, tiles, W1, b1, W2p, b2, W3p, b3, partial);
+        else
+            hipLaunchKernelGGL(pn_trunk_kernel<4>, dim3((unsigned)grid), dim3(256), T_LDS, st, pc, trans, N, tiles, W1, b1, W2p, b2, W3p, b3, partial);
+    }
+    DVQ_CHECK_LAUNCH("pn_trunk");
     return DVQ_OK;
 }

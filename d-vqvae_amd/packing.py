@@ -66,11 +66,14 @@ class _Packed:
         self.device = device
         for name in self.PLANES:                        # split-bf16 images of the GEMM weights, built on the device
             for key in [k for k in self.tensors if k == name or (k.startswith(name) and k[len(name):].isdigit())]:
-                self.tensors[key + "__planes"] = split_bf16x3(self.tensors[key])
+                self.tensors[key + "__planes"] = split_bf16x3(self._plane_source(key, self.tensors[key]))
         self._bind()
         return self
 
     PLANES = ()
+
+    def _plane_source(self, key, t):
+        return t
 
     def planes_ptr(self, key):
         t = self.tensors.get(key + "__planes")
@@ -113,6 +116,15 @@ class PackedPointNet(_Packed):
         self.cstruct = s
 
     PLANES = ("s_w2", "s_w3", "s_f1", "s_f2", "s_f3", "w2", "w3")
+    # the fused trunk kernel consumes conv3's weights with the k order inside every 16-channel block permuted to the order in
+    # which conv2's accumulator delivers its channels (pos 8h+j <-> channel 8(j>>2)+4h+(j&3)); see csrc/pointnet.hip
+    K_PERM16 = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
+
+    def _plane_source(self, key, t):
+        if key in ("w3", "s_w3"):
+            idx = torch.tensor([16 * b + p for b in range(t.shape[1] // 16) for p in self.K_PERM16], device=t.device)
+            return t.index_select(1, idx).contiguous()
+        return t
 
 
 def gate_perm(dim: int) -> Tensor:
