@@ -249,19 +249,20 @@ def main():
                                       f"15-layer gated PixelCNN prior (cached sampler), synthetic weights",
                           "global_batch": B * world, "points": N, "codebook": K, "parallelism": f"batch-shard x{world}"}}
         if kernels:
-            gemm = {k: v for k, v in kernels.items() if k.startswith("gemm_") and k != "gemm_argmin"}
-            dom = max(kernels.items(), key=lambda kv: kv[1]["ms"])[0]
-            g_ms = sum(v["ms"] for v in gemm.values())
-            g_fl = sum(v["flops"] for v in gemm.values())
-            g_n = sum(v["count"] for v in gemm.values())
-            achieved = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
-            out["roofline"] = {"bound": "mfma", "kernel": f"gemm_{GEMM_MODE}_kernel (all epilogues)", "achieved": achieved,
-                               "peak": GEMM_PEAK_TF, "unit": "TFLOP/s", "frac": achieved / GEMM_PEAK_TF,
+            # MFMA kernels: the fused PointNet trunk and the GEMMs (exact VQ argmin excluded: it runs the fp32 chain)
+            mf = {k: v for k, v in kernels.items() if (k.startswith("gemm_") and k != "gemm_argmin") or k == "pn_trunk"}
+            dom = max(mf.items(), key=lambda kv: kv[1]["ms"])[0]
+            d = mf[dom]
+            achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            all_ms = sum(v["ms"] for v in mf.values())
+            all_fl = sum(v["flops"] for v in mf.values())
+            out["roofline"] = {"bound": "mfma", "kernel": {"pn_trunk": "pn_trunk_kernel (fused PointNet trunk)"}.get(dom, f"gemm_{GEMM_MODE} {dom}"),
+                               "achieved": achieved, "peak": GEMM_PEAK_TF, "unit": "TFLOP/s", "frac": achieved / GEMM_PEAK_TF,
                                "peak_note": ("dense bf16 MFMA 2500 TF / 6 partial products per fp32 product"
                                              if GEMM_MODE == "bf16x3" else "fp32 MFMA (= fp32 vector) peak"),
-                               "traffic": None, "launches": g_n, "avg_launch_ms": g_ms / max(g_n, 1),
-                               "flops_per_launch": g_fl / max(g_n, 1), "dominant_kind": dom,
-                               "gemm_share_of_step": g_ms / (elapsed * 1e3)}
+                               "traffic": None, "launches": d["count"], "avg_launch_ms": d["ms"] / d["count"],
+                               "flops_per_launch": d["flops"] / d["count"], "share_of_step": d["ms"] / (elapsed * 1e3),
+                               "all_mfma_kernels": {"achieved": all_fl / (all_ms * 1e-3) / 1e12, "share_of_step": all_ms / (elapsed * 1e3)}}
             out["kernels"] = {k: {"count": v["count"], "ms": round(v["ms"], 3),
                                   "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0}
                               for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}
