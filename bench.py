@@ -77,6 +77,24 @@ def usable_cores():
     return max(1, n)
 
 
+def pmc_traffic(kind, batch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950
+    correction + WRITE_SIZE, profiles/*_pmc_hbm_traffic.json; collected at the default batch only) or None."""
+    if batch != 65536:
+        return None
+    names = {"pn_trunk": "pn_trunk_kernel<4>", "gemm_gate": "gemm_bf16x3_dma_kernel<2>", "gemm_bias": "gemm_bf16x3_dma_kernel<0>",
+             "gemm_resid": "gemm_bf16x3_dma_kernel<1>"}
+    try:
+        import glob
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))[-1]
+        for row in json.load(open(path))["per_launch_bytes"]:
+            if names.get(kind, "?") in row["kernel"]:
+                return row["hbm_bytes_corrected"]
+    except Exception:
+        pass
+    return None
+
+
 def prof_read(lib, _lib):
     buf = (_lib.ProfEntry * 64)()
     n = lib.dvq_prof_read(buf, 64)
@@ -263,6 +281,7 @@ def main():
                                "traffic": None, "launches": d["count"], "avg_launch_ms": d["ms"] / d["count"],
                                "flops_per_launch": d["flops"] / d["count"], "share_of_step": d["ms"] / (elapsed * 1e3),
                                "all_mfma_kernels": {"achieved": all_fl / (all_ms * 1e-3) / 1e12, "share_of_step": all_ms / (elapsed * 1e3)}}
+            out["roofline"]["traffic"] = pmc_traffic(dom, B)
             out["kernels"] = {k: {"count": v["count"], "ms": round(v["ms"], 3),
                                   "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0}
                               for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}
