@@ -28,6 +28,9 @@
 // Algorithmic HBM bytes per row: D*4 (z) + 8 (int64 index); the codebook (K*D*4) is read once.
 #include "dvq_internal.h"
 
+#ifndef DVQ_ABL
+#define DVQ_ABL 0
+#endif
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -36,13 +39,23 @@ constexpr int K = 512, D = 256;
 constexpr int WG_ROWS = 128;                       // 4 waves x 32 rows
 constexpr int KS = D / 16;                         // 16 MFMA k-steps
 constexpr int NCHUNK = K / 64;                     // 8 chunks of 64 entries
-constexpr int MAXC = 8;                            // candidate slots per row in the hand-off record (<= 6 used)
 constexpr int EXP_LIMIT = 40;                      // |log2(max magnitude)| beyond this -> exact fallback
 
 constexpr int CHUNK_B = 64 * D * 2;                // 32 768 B: 64 entries x 256 fp16
 constexpr int OFF_EE = 2 * CHUNK_B;                // [K] fp32
 constexpr int OFF_CNT = OFF_EE + K * 4;            // [4] ints (per-wave ambiguous counts)
 constexpr int LDS_BYTES = OFF_CNT + 64;            // 67 648 B -> two workgroups per CU
+// refine tail: regions inside the (then free) codebook stages
+constexpr int RF_ROW = 0;                          // [768] u16 local row of a pair
+constexpr int RF_K = 2048;                         // [768] u16 entry of a pair
+constexpr int RF_D = 4096;                         // [768] f32 canonical distance of a pair
+constexpr int RF_OVER = 8192;                      // [128] u16 rows that need all K entries
+constexpr int RF_RED = 9216;                       // [256] f32 + [256] int block reduction
+constexpr int RF_AP = 11264;                       // [512] f32 second-level (plain fp32) distances of one row
+constexpr int RF_OBASE = 13312;                    // [128] u16 first pair of a second-level row
+constexpr int RF_OCNT = 13568;                     // [128] u16 its pair count
+constexpr int RF_OEPS = 13824;                     // [128] f32 its eps2
+constexpr int RF_PAIRS = 768;                      // pair list capacity (128 rows x 6)
 
 struct PackHeader {
     float emax;        // upper bound of max_k |e_k|_2 (inf if the codebook is not finite)
@@ -102,188 +115,93 @@ __global__ void vq_pack_img_kernel(const float* __restrict__ E, const PackHeader
 // ------------------------------------------------------------------------------------------------ filter
 // DMA one chunk (64 entries x 512 B) into an LDS stage: 32 pieces of 1 KiB (two rows each), eight per wave; a row has 32
 // 16-byte chunks, chunk c of row r lands at chunk c ^ (r & 15)
-__device__ __forceinline__ void issue_chunk(const _Float16* __restrict__ img, int chunk, char* stage, int wave, int lane) {
+// per-lane byte offsets of the 8 DMA pieces a wave issues per chunk (constant across chunks: the chunk moves the
+// uniform base, so an issue is one instruction, no vector address arithmetic)
+__device__ __forceinline__ void chunk_offsets(unsigned (&voff)[8], int wave, int lane) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int rp = wave * 8 + i;                              // row pair
-        const int row = 2 * rp + (lane >> 5);
-        const _Float16* src = img + (long)(64 * chunk + row) * D + 8 * ((lane & 31) ^ (row & 15));
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(stage + rp * 1024), 16, 0, 0);
+        const int row = 2 * (wave * 8 + i) + (lane >> 5);
+        voff[i] = (unsigned)(row * (D * 2) + 16 * ((lane & 31) ^ (row & 15)));
     }
+}
+
+__device__ __forceinline__ void issue_chunk(const char* __restrict__ img_chunk, const unsigned (&voff)[8], char* stage, int wave) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img_chunk + voff[i]),
+                                         (__attribute__((address_space(3))) void*)(stage + (wave * 8 + i) * 1024), 16, 0, 0);
 }
 
 __device__ __forceinline__ f16x8 efrag(const char* stage, int row, int chunk) {
     return *reinterpret_cast<const f16x8*>(stage + row * 512 + 16 * (chunk ^ (row & 15)));
 }
 
-// keep the four smallest of (m1 <= m2 <= m3 <= m4) and s
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)p;
+}
+
+// Hand-issued LDS reads of the chunk loop.  The compiler's own wait insertion turns every wait after an LDS-DMA issue
+// into lgkmcnt(0), which exposes the full LDS latency once per k-step; reads it does not see can be waited for by
+// count.  `off` is one of four values (stage x tile), folded after unrolling.
+__device__ __forceinline__ void lds_read16(f16x8& d, unsigned addr, int off) {
+    switch (off) {
+        case 0: asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr)); break;
+        case 16384: asm volatile("ds_read_b128 %0, %1 offset:16384" : "=v"(d) : "v"(addr)); break;
+        case 32768: asm volatile("ds_read_b128 %0, %1 offset:32768" : "=v"(d) : "v"(addr)); break;
+        default: asm volatile("ds_read_b128 %0, %1 offset:49152" : "=v"(d) : "v"(addr)); break;
+    }
+}
+__device__ __forceinline__ void lds_read16(f32x4& d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr));
+}
+// wait until at most n younger LDS reads are outstanding; the operands pin the consumers below the wait
+template <class A, class B>
+__device__ __forceinline__ void lds_wait(int n, A& a, B& b) {   // (never pass one object twice: the copy would be made before the wait)
+    switch (n) {
+        case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); break;
+        case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a), "+v"(b)); break;
+        case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(b)); break;
+        case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a), "+v"(b)); break;
+        default: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a), "+v"(b)); break;
+    }
+}
+template <class A, class B, class C>
+__device__ __forceinline__ void lds_wait(int n, A& a, B& b, C& c) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c)); break;
+        case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a), "+v"(b), "+v"(c)); break;
+        case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(b), "+v"(c)); break;
+        case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a), "+v"(b), "+v"(c)); break;
+        case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a), "+v"(b), "+v"(c)); break;
+        case 5: asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a), "+v"(b), "+v"(c)); break;
+        case 6: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a), "+v"(b), "+v"(c)); break;
+        default: asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(a), "+v"(b), "+v"(c)); break;
+    }
+}
+
+// keep the four smallest of (m1 <= m2 <= m3 <= m4) and s: four median-of-3 (min(a, b) = med3(a, b, -inf); plain fminf
+// costs a second instruction for sNaN canonicalisation)
 __device__ __forceinline__ void top4(float s, float& m1, float& m2, float& m3, float& m4) {
     m4 = __builtin_amdgcn_fmed3f(m3, m4, s);
     m3 = __builtin_amdgcn_fmed3f(m2, m3, s);
     m2 = __builtin_amdgcn_fmed3f(m1, m2, s);
-    m1 = fminf(m1, s);
+    m1 = __builtin_amdgcn_fmed3f(m1, s, -3.0e38f);
 }
 
-// scores of one chunk half (one 32-entry MFMA tile): s = ee + acc * inv, entry id into the low 8 mantissa bits, top-3 update
-__device__ __forceinline__ void absorb(const f32x16& acc, const float* __restrict__ ee_s, int c, int jn, int h, float inv,
-                                       float& m1, float& m2, float& m3, float& m4) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {                                 // regs 4g..4g+3 <-> entries 64c + 32jn + 8g + 4h + 0..3
-        const f32x4 ev = *reinterpret_cast<const f32x4*>(ee_s + 64 * c + 32 * jn + 8 * g + 4 * h);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = 4 * g + i;
-            const float s = fmaf(acc[e], inv, ev[i]);
-            const float p = __uint_as_float((__float_as_uint(s) & 0xffffff00u) | (unsigned)(c << 5 | jn << 4 | e));
-            top4(p, m1, m2, m3, m4);
-        }
-    }
+// one score s = acc / (sz sE) + ee, its 8-bit entry id replacing the low mantissa byte, top-4 update.  The id comes
+// out of a register holding four ids (one v_perm_b32: gfx950's three-operand encodings take no literal, so an
+// and/or with two constants would be two instructions).
+__device__ __forceinline__ void absorb1(float acc, float inv, float ee, unsigned ids4, int k,
+                                        float& m1, float& m2, float& m3, float& m4) {
+    const float sc = fmaf(acc, inv, ee);
+    const float p = __uint_as_float(__builtin_amdgcn_perm(__float_as_uint(sc), ids4, 0x07060500u + (unsigned)k));
+    top4(p, m1, m2, m3, m4);
 }
 
 __device__ __forceinline__ int decode_entry(float packed, int half) {
     const unsigned id = __float_as_uint(packed) & 0xffu;
     const int c = id >> 5, jn = (id >> 4) & 1, e = id & 15;
     return 64 * c + 32 * jn + (e & 3) + 8 * (e >> 2) + 4 * half;
-}
-
-__global__ __launch_bounds__(256, 2) void vq_filter_kernel(const float* __restrict__ z, long M, const char* __restrict__ packed,
-                                                           int64_t* __restrict__ idx, uint16_t* __restrict__ cand_out,
-                                                           uint8_t* __restrict__ cnt_out, int* __restrict__ amb_count,
-                                                           int* __restrict__ amb_list) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    float* ee_s = reinterpret_cast<float*>(lds + OFF_EE);
-    int* wcnt = reinterpret_cast<int*>(lds + OFF_CNT);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    const PackHeader* hdr = reinterpret_cast<const PackHeader*>(packed);
-    const float emax = hdr->emax;
-    const int e_sexp = hdr->sexp;
-    const bool e_valid = hdr->valid != 0;
-    const float* ee_g = reinterpret_cast<const float*>(packed + PK_OFF_EE);
-    const _Float16* img = reinterpret_cast<const _Float16*>(packed + PK_OFF_IMG);
-
-    // Two workgroups share a CU; both would stream their rows from HBM first and multiply afterwards, in lockstep.  The
-    // second half of the grid starts ~4.5 us late so that its loads run under the first half's matrix work (speed only).
-    if (blockIdx.x >= (gridDim.x + 1) / 2 && gridDim.x > 256) __builtin_amdgcn_s_sleep(127);
-    // ---- this lane's row: 128 of its 256 floats (k = 16 s + 8 h + j), straight from HBM in fragment shape
-    long grow = (long)blockIdx.x * WG_ROWS + wave * 32 + r;
-    const bool live = grow < M;
-    if (!live) grow = M - 1;
-    const float* zr = z + grow * D + 8 * h;
-    f32x4 zf[KS][2];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        zf[s][0] = *reinterpret_cast<const f32x4*>(zr + 16 * s);
-        zf[s][1] = *reinterpret_cast<const f32x4*>(zr + 16 * s + 4);
-    }
-    ee_s[tid] = ee_g[tid];
-    ee_s[tid + 256] = ee_g[tid + 256];
-    float mx = 0.f, ss = 0.f;
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                mx = fmaxf(mx, fabsf(zf[s][q][i]));
-                ss = fmaf(zf[s][q][i], zf[s][q][i], ss);
-            }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    ss += __shfl_xor(ss, 32);
-    const bool bad = !(ss <= 3.0e38f);                          // NaN / Inf anywhere in the row poisons the sum of squares
-    const int ez = (int)((__float_as_uint(mx) >> 23) & 0xff) - 127;
-    const bool ok = e_valid && !bad && (mx == 0.f || (ez >= -EXP_LIMIT && ez <= EXP_LIMIT));
-    const int zs = (mx == 0.f || !ok) ? 0 : 13 - ez;
-    const float sc = pow2f(zs);
-    const float inv = ok ? pow2f(-(zs + e_sexp)) : __int_as_float(0x7fc00000);     // NaN marks "exact path"
-    const float zn = __builtin_amdgcn_sqrtf(ss) * 1.0001f;
-    f16x8 zh[KS];                                                // MFMA B operand: B[k = 8h + j][col = row r]
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        f16x8 v;
-        v[0] = (_Float16)(zf[s][0][0] * sc); v[1] = (_Float16)(zf[s][0][1] * sc);
-        v[2] = (_Float16)(zf[s][0][2] * sc); v[3] = (_Float16)(zf[s][0][3] * sc);
-        v[4] = (_Float16)(zf[s][1][0] * sc); v[5] = (_Float16)(zf[s][1][1] * sc);
-        v[6] = (_Float16)(zf[s][1][2] * sc); v[7] = (_Float16)(zf[s][1][3] * sc);
-        zh[s] = v;
-    }
-
-    // ---- stream the codebook: chunk c in stage c & 1; scores of chunk c are absorbed while chunk c+1 multiplies
-    issue_chunk(img, 0, lds, wave, lane);
-    float m1 = INFINITY, m2 = INFINITY, m3 = INFINITY, m4 = INFINITY;
-    f32x16 accA[2], accB[2];
-#pragma unroll
-    for (int c = 0; c < NCHUNK; ++c) {
-        __syncthreads();                                          // chunk c landed everywhere; the other stage is free
-        if (c + 1 < NCHUNK) issue_chunk(img, c + 1, lds + ((c + 1) & 1) * CHUNK_B, wave, lane);
-        const char* st = lds + (c & 1) * CHUNK_B;
-        f32x16 (&cur)[2] = (c & 1) ? accB : accA;
-        f32x16 (&prev)[2] = (c & 1) ? accA : accB;
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) cur[jn][e] = 0.f;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const f16x8 e0 = efrag(st, r, 2 * s + h);
-            const f16x8 e1 = efrag(st, 32 + r, 2 * s + h);
-            cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e0, zh[s], cur[0], 0, 0, 0);
-            cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(e1, zh[s], cur[1], 0, 0, 0);
-            if (c > 0 && s == 3) absorb(prev[0], ee_s, c - 1, 0, h, inv, m1, m2, m3, m4);   // vector work in the MFMA shadow
-            if (c > 0 && s == 9) absorb(prev[1], ee_s, c - 1, 1, h, inv, m1, m2, m3, m4);
-        }
-    }
-    absorb(accB[0], ee_s, NCHUNK - 1, 0, h, inv, m1, m2, m3, m4);
-    absorb(accB[1], ee_s, NCHUNK - 1, 1, h, inv, m1, m2, m3, m4);
-
-    // ---- per row: merge the two lane halves' top-3 lists, threshold, decide or hand off
-    const float p1 = __shfl_xor(m1, 32), p2 = __shfl_xor(m2, 32), p3 = __shfl_xor(m3, 32), p4 = __shfl_xor(m4, 32);
-    const float best = fminf(m1, p1);
-    const float eps = 0.00196076f * zn * emax + 0.00018311f * (zn + emax) * (zn + emax);
-    const float thr = best + eps + (inv - inv);                  // NaN scale (exact path) poisons the threshold
-    const int own = (m1 <= thr) + (m2 <= thr) + (m3 <= thr);
-    const int oth = (p1 <= thr) + (p2 <= thr) + (p3 <= thr);
-    const int c = own + oth;
-    const bool complete = !(m4 <= thr) && !(p4 <= thr);          // no lane may be hiding a fourth score within eps
-    const bool unique = c == 1;
-    const bool amb = live && (h == 0) && !unique;
-    if (live && h == 0) {
-        if (unique) {
-            idx[grow] = (m1 <= thr) ? decode_entry(m1, 0) : decode_entry(p1, 1);
-        } else {
-            idx[grow] = -1;
-            const bool usable = complete && c >= 2;               // c == 0: NaN/Inf or out-of-range magnitudes
-            cnt_out[grow] = usable ? (uint8_t)c : (uint8_t)255;
-            unsigned long long lo = 0, hi = 0;                    // up to six 16-bit entry ids, no runtime-indexed arrays
-            int n = 0;
-            auto push = [&](bool take, int v) {
-                if (take) {
-                    if (n < 4) lo |= (unsigned long long)v << (16 * n);
-                    else hi |= (unsigned long long)v << (16 * (n - 4));
-                    ++n;
-                }
-            };
-            push(m1 <= thr, decode_entry(m1, 0));
-            push(m2 <= thr, decode_entry(m2, 0));
-            push(m3 <= thr, decode_entry(m3, 0));
-            push(p1 <= thr, decode_entry(p1, 1));
-            push(p2 <= thr, decode_entry(p2, 1));
-            push(p3 <= thr, decode_entry(p3, 1));
-            uint4 v;
-            v.x = (unsigned)lo; v.y = (unsigned)(lo >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
-            *reinterpret_cast<uint4*>(cand_out + grow * MAXC) = v;
-        }
-    }
-    // ambiguous rows of this workgroup -> its own segment of the work list (no global atomics)
-    const unsigned long long mask = __ballot(amb);
-    if (lane == 0) wcnt[wave] = __builtin_popcountll(mask);
-    __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; ++w) base += wcnt[w];
-    if (amb) amb_list[(long)blockIdx.x * WG_ROWS + base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (int)grow;
-    if (tid == 0) amb_count[blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
 }
 
 // ------------------------------------------------------------------------------------------------ refine
@@ -318,6 +236,12 @@ __device__ __forceinline__ void chain_pair_x4(const float* __restrict__ zr, cons
     dot = __shfl(b, base + 3);
 }
 
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int w = 32; w > 0; w >>= 1) v += __shfl_xor(v, w);
+    return v;
+}
+
 // full-row single-lane form (used by the all-K fallback)
 __device__ __forceinline__ void chain_pair(const float* __restrict__ zr, const float* __restrict__ er, float& zz, float& dot) {
     float a = 0.f, b = 0.f;
@@ -340,89 +264,367 @@ __device__ __forceinline__ void chain_pair(const float* __restrict__ zr, const f
     dot = b;
 }
 
-__global__ __launch_bounds__(256) void vq_refine_kernel(const float* __restrict__ z, const float* __restrict__ E,
-                                                        const float* __restrict__ ee, long M, int64_t* __restrict__ idx,
-                                                        const uint16_t* __restrict__ cand_out, const uint8_t* __restrict__ cnt_out,
-                                                        const int* __restrict__ amb_count, const int* __restrict__ amb_list_all) {
-    __shared__ float s_v[256];
-    __shared__ int s_i[256];
-    const int seg = blockIdx.x >> 1, part = blockIdx.x & 1;     // 2 blocks share one filter workgroup's segment
-    const int n_amb = amb_count[seg];
-    const int* amb_list = amb_list_all + (long)seg * WG_ROWS;
-    const int tid = threadIdx.x;
-    const int g = tid >> 5;              // 8 rows per block pass, 32 lanes each: 8 candidate slots x 4 lanes
-    const int j = (tid >> 2) & 7;        // candidate slot
-    const int q = tid & 3;               // quarter of the row
-    for (int i0 = part * 8; i0 < n_amb; i0 += 16) {
-        const int i = i0 + g;
-        float d = INFINITY;
-        int k = 0x7fffffff;
-        long grow = -1;
-        bool work = false, overflow = false;
-        if (i < n_amb) {
-            grow = amb_list[i];
-            const int c = cnt_out[grow];
-            if (c == 255) overflow = true;
-            else if (j < c) {
-                k = cand_out[grow * MAXC + j];
-                work = true;
-            }
-        }
-        // every lane runs the (shuffling) chain code; lanes without work load nothing and are ignored
-        float zz, dot;
-        chain_pair_x4(z + (work ? grow : 0) * D, E + (long)(work ? k : 0) * D, q, work, zz, dot);
-        if (work) {
-            const float t = zz + ee[k];
-            d = t - 2.0f * dot;
-        } else {
-            k = 0x7fffffff;
-        }
+__global__ __launch_bounds__(256, 2) void vq_filter_kernel(const float* __restrict__ z, const float* __restrict__ E, long M,
+                                                           const char* __restrict__ packed, int64_t* __restrict__ idx,
+                                                           unsigned long long* __restrict__ dbg) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    float* ee_s = reinterpret_cast<float*>(lds + OFF_EE);
+    if (threadIdx.x < 2) reinterpret_cast<int*>(lds + OFF_CNT)[threadIdx.x] = 0;   // refine counters (first use is barriers away)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const PackHeader* hdr = reinterpret_cast<const PackHeader*>(packed);
+    const float emax = hdr->emax;
+    const int e_sexp = hdr->sexp;
+    const bool e_valid = hdr->valid != 0;
+    const float* ee_g = reinterpret_cast<const float*>(packed + PK_OFF_EE);
+    const _Float16* img = reinterpret_cast<const _Float16*>(packed + PK_OFF_IMG);
+
+    // ---- this lane's row: 128 of its 256 floats (k = 16 s + 8 h + j).  Rows come HBM -> LDS as whole 1 KiB lines by
+    // global_load_lds (coalesced; fragment-shaped register loads would touch 32 cache lines per instruction and make the
+    // texture path the bottleneck), 64 rows at a time through the (still unused) codebook stages, then to registers.
+    long grow = (long)blockIdx.x * WG_ROWS + wave * 32 + r;
+    const bool live = grow < M;
+    if (!live) grow = M - 1;
+    f32x4 zf[KS][2];
 #pragma unroll
-        for (int o = 4; o < 32; o <<= 1) {                        // over the 8 candidate slots (lanes 4 apart)
-            const float od = __shfl_xor(d, o);
-            const int ok = __shfl_xor(k, o);
-            if (dvq_argmin_better(od, ok, d, k)) { d = od; k = ok; }
+    for (int half = 0; half < 2; ++half) {
+        // rows [64 half, 64 half + 64) of the workgroup tile: 16 DMAs per wave; LDS chunk `lane` <- source chunk lane ^ (row & 15)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int lrow = wave * 16 + i;                       // 0..63 inside this half
+            long gr = (long)blockIdx.x * WG_ROWS + 64 * half + lrow;
+            if (gr >= M) gr = M - 1;
+            const float* src = z + gr * D + 4 * (lane ^ (lrow & 15));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds + lrow * 1024), 16, 0, 0);
         }
-        if (grow >= 0 && !overflow && (tid & 31) == 0) idx[grow] = k;
-        if (!__syncthreads_or(overflow)) continue;
-        // rows without a usable candidate list (NaN/Inf, out-of-range magnitudes, possibly incomplete lists): all K entries,
-        // the whole block per row
-        for (int u = 0; u < 8; ++u) {
-            const int iu = i0 + u;
-            if (iu >= n_amb) break;
-            const long gr = amb_list[iu];
-            if (cnt_out[gr] != 255) continue;
-            const float* zr = z + gr * D;
-            float bv = INFINITY;
-            int bi = 0x7fffffff;
-            for (int kk = tid; kk < K; kk += 256) {
-                float zz2, dot2;
-                chain_pair(zr, E + (long)kk * D, zz2, dot2);
-                const float t = zz2 + ee[kk];
-                const float dd = t - 2.0f * dot2;
-                if (dvq_argmin_better(dd, kk, bv, bi)) { bv = dd; bi = kk; }
+        __syncthreads();                                          // landed for every wave
+        if ((wave >> 1) == half) {
+            const int lrow = (wave & 1) * 32 + r;
+            const float* zrow = reinterpret_cast<const float*>(lds + lrow * 1024);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int c0 = 4 * s + 2 * h;
+                zf[s][0] = *reinterpret_cast<const f32x4*>(zrow + 4 * (c0 ^ (lrow & 15)));
+                zf[s][1] = *reinterpret_cast<const f32x4*>(zrow + 4 * ((c0 + 1) ^ (lrow & 15)));
             }
-            s_v[tid] = bv;
-            s_i[tid] = bi;
-            __syncthreads();
-            for (int o = 128; o > 0; o >>= 1) {
-                if (tid < o && dvq_argmin_better(s_v[tid + o], s_i[tid + o], s_v[tid], s_i[tid])) {
-                    s_v[tid] = s_v[tid + o];
-                    s_i[tid] = s_i[tid + o];
+        }
+        __syncthreads();                                          // consumed: the area may be overwritten
+    }
+    ee_s[tid] = ee_g[tid];
+    ee_s[tid + 256] = ee_g[tid + 256];
+    float mx = 0.f, ss = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                mx = fmaxf(mx, fabsf(zf[s][q][i]));
+                ss = fmaf(zf[s][q][i], zf[s][q][i], ss);
+            }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    ss += __shfl_xor(ss, 32);
+    const bool bad = !(ss <= 3.0e38f);                          // NaN / Inf anywhere in the row poisons the sum of squares
+    const int ez = (int)((__float_as_uint(mx) >> 23) & 0xff) - 127;
+    const bool ok = e_valid && !bad && (mx == 0.f || (ez >= -EXP_LIMIT && ez <= EXP_LIMIT));
+    const int zs = (mx == 0.f || !ok) ? 0 : 13 - ez;
+    const float sc = pow2f(zs);
+    const float zn = __builtin_amdgcn_sqrtf(ss) * 1.0001f;
+    f16x8 zh[KS];                                                // MFMA B operand: B[k = 8h + j][col = row r]
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        f16x8 v;
+        v[0] = (_Float16)(zf[s][0][0] * sc); v[1] = (_Float16)(zf[s][0][1] * sc);
+        v[2] = (_Float16)(zf[s][0][2] * sc); v[3] = (_Float16)(zf[s][0][3] * sc);
+        v[4] = (_Float16)(zf[s][1][0] * sc); v[5] = (_Float16)(zf[s][1][1] * sc);
+        v[6] = (_Float16)(zf[s][1][2] * sc); v[7] = (_Float16)(zf[s][1][3] * sc);
+        zh[s] = v;
+    }
+
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    // ---- stream the codebook: chunk c in stage c & 1; scores of chunk c are absorbed while chunk c+1 multiplies
+    unsigned voff[8];
+    chunk_offsets(voff, wave, lane);
+    const char* img_b = reinterpret_cast<const char*>(img);
+    issue_chunk(img_b, voff, lds, wave);
+    float m1 = INFINITY, m2 = INFINITY, m3 = INFINITY, m4 = INFINITY;
+    const float inv = ok ? pow2f(-(zs + e_sexp)) : __int_as_float(0x7fc00000);     // NaN marks "exact path"
+    unsigned ids4[8];                                             // ids4[j] byte k = id of score 4j + k of the chunk being absorbed
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ids4[j] = 0x03020100u + 0x04040404u * j;
+        asm volatile("" : "+v"(ids4[j]));                         // keep them in registers (a folded constant would cost a move per score)
+    }
+    unsigned fa[KS];                                              // LDS byte address of this lane's fragment of k-step s (stage 0, tile 0)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) fa[s] = lds_addr(lds) + r * 512 + 16 * ((2 * s + h) ^ (r & 15));
+    const unsigned ee_a = lds_addr(lds) + OFF_EE + 16 * h;
+    f32x16 accA[2], accB[2];
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NCHUNK; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's DMA pieces of chunk c (the compiler does not see the asm readers)
+        __syncthreads();                                          // chunk c landed everywhere; the other stage is free
+        if (c + 1 < NCHUNK && DVQ_ABL != 3) issue_chunk(img_b + (c + 1) * CHUNK_B, voff, lds + ((c + 1) & 1) * CHUNK_B, wave);
+        f32x16 (&cur)[2] = (c & 1) ? accB : accA;
+        f32x16 (&prev)[2] = (c & 1) ? accA : accB;
+        // Issue order per k-step s: [|e|^2 quad of score group s/2+1 (even s)], fragments of step s+PF, wait for step s's
+        // fragments (and the quad its scores need, which is older), two MFMAs, two scores of the previous chunk.
+        f16x8 ef[KS][2];
+        f32x4 ev[KS / 2];
+        constexpr int PF = 2;
+        const int soff = (c & 1) * CHUNK_B;
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            lds_read16(ef[s][0], fa[s], soff);
+            lds_read16(ef[s][1], fa[s], soff + 16384);
+        }
+        if (c > 0) lds_read16(ev[0], ee_a + 256 * (c - 1));
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (c > 0 && (s & 1) == 0 && s / 2 + 1 < KS / 2) {
+                const int g = s / 2 + 1;
+                lds_read16(ev[g], ee_a + 256 * (c - 1) + 128 * (g >> 2) + 32 * (g & 3));
+            }
+            if (s + PF < KS) {
+                lds_read16(ef[s + PF][0], fa[s + PF], soff);
+                lds_read16(ef[s + PF][1], fa[s + PF], soff + 16384);
+            }
+            // reads younger than the last one step s needs (its own fragments; at s = 0 the quad read behind the prologue)
+            const bool quad_prev = c > 0 && s >= 1 && ((s - 1) & 1) == 0 && (s - 1) / 2 + 1 < KS / 2;
+            const bool quad_this = c > 0 && (s & 1) == 0 && s / 2 + 1 < KS / 2;
+            const int younger = s == 0 ? (c > 0 ? 3 : 4)
+                                       : (s + 1 < KS ? 2 : 0) + (s + 2 < KS ? 2 : 0) + (quad_prev ? 1 : 0) + (quad_this ? 1 : 0);
+            if (c > 0) lds_wait(DVQ_ABL == 4 ? 0 : younger, ef[s][0], ef[s][1], ev[s / 2]);
+            else lds_wait(DVQ_ABL == 4 ? 0 : younger, ef[s][0], ef[s][1]);
+            cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ef[s][0], zh[s], s == 0 ? zero16 : cur[0], 0, 0, 0);
+            cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ef[s][1], zh[s], s == 0 ? zero16 : cur[1], 0, 0, 0);
+            if (c > 0 && (DVQ_ABL != 2 || s == 0)) {              // two scores of the previous chunk per k-step: vector work in the MFMA shadow
+                const int q = 2 * s, jn = q >> 4, e = q & 15;     // acc register e of tile jn: entry 64 (c-1) + 32 jn + 8 (e>>2) + 4 h + (e&3)
+                absorb1(prev[jn][e], inv, ev[q >> 2][q & 3], ids4[q >> 2], q & 3, m1, m2, m3, m4);
+                absorb1(prev[jn][e + 1], inv, ev[q >> 2][(q + 1) & 3], ids4[q >> 2], (q + 1) & 3, m1, m2, m3, m4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c > 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                ids4[j] += 0x20202020u;
+                asm volatile("" : "+v"(ids4[j]));
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        const int jn = q >> 4, e = q & 15;
+        const float ee = ee_s[64 * (NCHUNK - 1) + 32 * jn + 8 * (e >> 2) + 4 * h + (e & 3)];
+        absorb1(accB[jn][e], inv, ee, ids4[q >> 2], q & 3, m1, m2, m3, m4);
+    }
+    const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
+    // ---- per row: merge the two lane halves' top-4 lists, threshold, decide or refine
+    const float p1 = __shfl_xor(m1, 32), p2 = __shfl_xor(m2, 32), p3 = __shfl_xor(m3, 32), p4 = __shfl_xor(m4, 32);
+    const float best = fminf(m1, p1);
+    const float eps = 0.00196076f * zn * emax + 0.00018311f * (zn + emax) * (zn + emax);
+    const float thr = best + eps + (inv - inv);                  // NaN scale (exact path) poisons the threshold
+    const int own = (m1 <= thr) + (m2 <= thr) + (m3 <= thr);
+    const int oth = (p1 <= thr) + (p2 <= thr) + (p3 <= thr);
+    const int c = own + oth;
+    const bool complete = !(m4 <= thr) && !(p4 <= thr);          // no lane may be hiding a fourth score within eps
+    const bool unique = c == 1;
+    const bool owner = live && h == 0;
+    const bool amb = owner && !unique;
+    const bool usable = complete && c >= 2;                       // c == 0: NaN/Inf or out-of-range magnitudes
+    // The refine runs inside the workgroup (no second launch, no hand-off through HBM): ambiguous rows claim slots
+    // of a (row, entry) pair list in LDS (the codebook stages are free now), the pairs are evaluated four lanes per
+    // canonical chain, and each row's owner lane picks its winner.
+    int* s_tot = reinterpret_cast<int*>(lds + OFF_CNT);          // [0] pairs, [1] rows that need all K entries
+    uint16_t* s_row = reinterpret_cast<uint16_t*>(lds + RF_ROW);
+    uint16_t* s_k = reinterpret_cast<uint16_t*>(lds + RF_K);
+    float* s_d = reinterpret_cast<float*>(lds + RF_D);
+    uint16_t* s_over = reinterpret_cast<uint16_t*>(lds + RF_OVER);
+    float* s_v = reinterpret_cast<float*>(lds + RF_RED);
+    int* s_i = reinterpret_cast<int*>(lds + RF_RED + 1024);
+    float* s_ap = reinterpret_cast<float*>(lds + RF_AP);
+    uint16_t* s_obase = reinterpret_cast<uint16_t*>(lds + RF_OBASE);
+    uint16_t* s_ocnt = reinterpret_cast<uint16_t*>(lds + RF_OCNT);
+    float* s_oeps = reinterpret_cast<float*>(lds + RF_OEPS);
+    __syncthreads();                                              // every wave is done with the stages
+    int base = 0;
+    if (owner && unique) idx[grow] = (m1 <= thr) ? decode_entry(m1, 0) : decode_entry(p1, 1);
+    if (amb) {
+        const int rl = wave * 32 + r;
+        if (usable) {
+            base = atomicAdd(&s_tot[0], c);
+            int n = base;
+            auto push = [&](bool take, int v) {
+                if (take) { s_row[n] = (uint16_t)rl; s_k[n] = (uint16_t)v; ++n; }
+            };
+            push(m1 <= thr, decode_entry(m1, 0));
+            push(m2 <= thr, decode_entry(m2, 0));
+            push(m3 <= thr, decode_entry(m3, 0));
+            push(p1 <= thr, decode_entry(p1, 1));
+            push(p2 <= thr, decode_entry(p2, 1));
+            push(p3 <= thr, decode_entry(p3, 1));
+        } else {
+            // !complete: finite row, more than four scores of one lane within eps -> second-level filter below;
+            // c == 0: NaN/Inf or out-of-range magnitudes -> all K entries canonically (bit 15)
+            const int o = atomicAdd(&s_tot[1], 1);
+            s_over[o] = (uint16_t)(rl | (complete ? 0x8000 : 0));
+            s_oeps[o] = 0.00018311f * (zn + emax) * (zn + emax);
+        }
+    }
+    __syncthreads();
+    const int n_over = s_tot[1];
+    // Second-level filter for the (rare) finite rows with a possibly incomplete list: every entry's distance by plain
+    // fp32 dot products, a wave per entry so the row loads are coalesced.  Any summation order keeps
+    // |approx_k - true_k| <= gamma_260 (|z| + |e_k|)^2, and so does the canonical chain, hence the canonical winner
+    // is within 4 gamma_260 (|z| + Emax)^2 < eps2 = (2^-13 + 2^-14) (|z| + Emax)^2 of the approximate minimum.
+    for (int o = 0; o < n_over; ++o) {
+        const int ov = s_over[o];
+        if (ov & 0x8000) continue;
+        const long gr = (long)blockIdx.x * WG_ROWS + ov;
+        const f32x4 z4 = *reinterpret_cast<const f32x4*>(z + gr * D + 4 * lane);
+        const float zz_a = wave_sum(z4[0] * z4[0] + z4[1] * z4[1] + z4[2] * z4[2] + z4[3] * z4[3]);
+        f32x4 nx[16];                                             // next batch: 16 coalesced row loads always in flight behind the math
+#pragma unroll
+        for (int u = 0; u < 16; ++u) nx[u] = *reinterpret_cast<const f32x4*>(E + (long)(4 * u + wave) * D + 4 * lane);
+        for (int i0 = 0; i0 < K / 4; i0 += 16) {
+            f32x4 e4[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) e4[u] = nx[u];
+            if (i0 + 16 < K / 4) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) nx[u] = *reinterpret_cast<const f32x4*>(E + (long)(4 * (i0 + 16 + u) + wave) * D + 4 * lane);
+            }
+            float pd[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) pd[u] = z4[0] * e4[u][0] + z4[1] * e4[u][1] + z4[2] * e4[u][2] + z4[3] * e4[u][3];
+            // 16 wave sums by a halving butterfly (17 shuffles instead of 96): after the masks 32, 16, 8, 4 the lane holds
+            // the partial of entry u = 8 b5 + 4 b4 + 2 b3 + b2 (b = lane bits) over its 16-lane class; masks 2, 1 finish it
+#pragma unroll
+            for (int lvl = 0; lvl < 4; ++lvl) {
+                const int w = 32 >> lvl, n = 8 >> lvl;
+                const bool up = (lane & w) != 0;
+#pragma unroll
+                for (int u = 0; u < n; ++u) {
+                    const float send = up ? pd[u] : pd[u + n];
+                    const float keep = up ? pd[u + n] : pd[u];
+                    pd[u] = keep + __shfl_xor(send, w);
                 }
-                __syncthreads();
             }
-            if (tid == 0) idx[gr] = s_i[0];
+            float tot = pd[0] + __shfl_xor(pd[0], 2);
+            tot += __shfl_xor(tot, 1);
+            if ((lane & 3) == 0) {
+                const int u = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+                const int kk = 4 * (i0 + u) + wave;
+                s_ap[kk] = (zz_a + ee_s[kk]) - 2.0f * tot;
+            }
+        }
+        __syncthreads();
+        float mn = fminf(s_ap[tid], s_ap[tid + 256]);
+#pragma unroll
+        for (int w = 32; w > 0; w >>= 1) mn = fminf(mn, __shfl_xor(mn, w));
+        if (lane == 0) s_v[wave] = mn;
+        const int base_o = s_tot[0];
+        __syncthreads();
+        const float thr2 = fminf(fminf(s_v[0], s_v[1]), fminf(s_v[2], s_v[3])) + s_oeps[o];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int kk = tid + 256 * u;
+            if (s_ap[kk] <= thr2) {
+                const int pos = atomicAdd(&s_tot[0], 1);
+                if (pos < RF_PAIRS) { s_row[pos] = (uint16_t)ov; s_k[pos] = (uint16_t)kk; }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int c_o = s_tot[0] - base_o;
+            if (c_o < 1 || c_o > 64 || base_o + c_o > RF_PAIRS) {   // (c_o < 1 cannot happen for finite data) -> all K entries
+                s_over[o] = (uint16_t)(ov | 0x8000);
+                s_tot[0] = base_o;
+            } else {
+                s_obase[o] = (uint16_t)base_o;
+                s_ocnt[o] = (uint16_t)c_o;
+            }
+        }
+        __syncthreads();
+    }
+    const int total = s_tot[0];
+    for (int s0 = 0; s0 < total; s0 += 64) {
+        if (s0 + wave * 16 < total) {                             // wave-uniform: this wave has at least one pair
+            const int slot = s0 + (tid >> 2), q = tid & 3;
+            const bool act = slot < total;
+            const int rl = act ? s_row[slot] : 0, k = act ? s_k[slot] : 0;
+            float zz, dot;
+            chain_pair_x4(z + ((long)blockIdx.x * WG_ROWS + rl) * D, E + (long)k * D, q, act, zz, dot);
+            if (act && q == 0) {
+                const float t = zz + ee_s[k];
+                s_d[slot] = t - 2.0f * dot;
+            }
+        }
+    }
+    __syncthreads();
+    if (amb && usable) {
+        float d = s_d[base];
+        int k = s_k[base];
+        for (int i = 1; i < c; ++i) {
+            const float od = s_d[base + i];
+            const int ok2 = s_k[base + i];
+            if (dvq_argmin_better(od, ok2, d, k)) { d = od; k = ok2; }
+        }
+        idx[grow] = k;
+    }
+    if (tid < n_over && !(s_over[tid] & 0x8000)) {               // rows that went through the second-level filter
+        const int b0 = s_obase[tid], cn = s_ocnt[tid];
+        float d = s_d[b0];
+        int k = s_k[b0];
+        for (int i = 1; i < cn; ++i) {
+            const float od = s_d[b0 + i];
+            const int ok2 = s_k[b0 + i];
+            if (dvq_argmin_better(od, ok2, d, k)) { d = od; k = ok2; }
+        }
+        idx[(long)blockIdx.x * WG_ROWS + s_over[tid]] = k;
+    }
+    // what is left (NaN/Inf, out-of-range magnitudes, > 64 second-level candidates): all K entries canonically, the whole
+    // workgroup per row, one single-lane chain per entry
+    for (int o = 0; o < n_over; ++o) {
+        if (!(s_over[o] & 0x8000)) continue;
+        const long gr = (long)blockIdx.x * WG_ROWS + (s_over[o] & 0x7fff);
+        const float* zr = z + gr * D;
+        float bv = INFINITY;
+        int bi = 0x7fffffff;
+        for (int kk = tid; kk < K; kk += 256) {
+            float zz2, dot2;
+            chain_pair(zr, E + (long)kk * D, zz2, dot2);
+            const float t = zz2 + ee_s[kk];
+            const float dd = t - 2.0f * dot2;
+            if (dvq_argmin_better(dd, kk, bv, bi)) { bv = dd; bi = kk; }
+        }
+        s_v[tid] = bv;
+        s_i[tid] = bi;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (tid < w && dvq_argmin_better(s_v[tid + w], s_i[tid + w], s_v[tid], s_i[tid])) {
+                s_v[tid] = s_v[tid + w];
+                s_i[tid] = s_i[tid + w];
+            }
             __syncthreads();
         }
+        if (tid == 0) idx[gr] = s_i[0];
+        __syncthreads();
+    }
+    if (dbg && tid == 0) {
+        const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
+        dbg[blockIdx.x * 8 + 0] = t0; dbg[blockIdx.x * 8 + 1] = t1; dbg[blockIdx.x * 8 + 2] = t2; dbg[blockIdx.x * 8 + 3] = t3;
+        dbg[blockIdx.x * 8 + 4] = (unsigned long long)total; dbg[blockIdx.x * 8 + 5] = (unsigned long long)n_over;
     }
 }
 
 struct FastScratch {
-    uint16_t* cand;
-    uint8_t* cnt;
-    int* amb_count;
-    int* amb_list;
+    char* dbg;
     long n_wg;
     size_t bytes;
 };
@@ -430,13 +632,8 @@ struct FastScratch {
 FastScratch plan(int64_t M, void* ws) {
     FastScratch s;
     s.n_wg = (M + WG_ROWS - 1) / WG_ROWS;
-    char* p = (char*)ws;
-    auto take = [&](size_t n) { char* q = p; p += dvq_round_up(n, 256); return q; };
-    s.cand = (uint16_t*)take((size_t)M * MAXC * 2);
-    s.cnt = (uint8_t*)take((size_t)M);
-    s.amb_count = (int*)take((size_t)s.n_wg * 4);
-    s.amb_list = (int*)take((size_t)s.n_wg * WG_ROWS * 4);
-    s.bytes = (size_t)(p - (char*)ws);
+    s.dbg = (char*)ws;                                           // per-workgroup phase stamps (DVQ_VQ_DBG only)
+    s.bytes = dvq_round_up((size_t)s.n_wg * 64, 256);
     return s;
 }
 
@@ -490,18 +687,9 @@ extern "C" int dvq_vq_argmin_fast(const float* z, const float* E, const void* pa
         attr_set = true;
     }
     const char* pk = (const char*)packed;
-    DVQ_PROF("vq_argmin_total", 2.0 * M * K * D, (double)M * D * 4 + (double)K * D * 4 + (double)M * 8, st);
-    {
-        DVQ_PROF("vq_filter", 2.0 * M * K * D, (double)M * D * 4 + (double)K * D * 2 + (double)M * 8, st);
-        hipLaunchKernelGGL(vq_filter_kernel, dim3((unsigned)s.n_wg), dim3(256), LDS_BYTES, st, z, (long)M, pk, idx, s.cand,
-                           s.cnt, s.amb_count, s.amb_list);
-    }
+    DVQ_PROF("vq_argmin_fast", 2.0 * M * K * D, (double)M * D * 4 + (double)K * D * 2 + (double)M * 8, st);
+    hipLaunchKernelGGL(vq_filter_kernel, dim3((unsigned)s.n_wg), dim3(256), LDS_BYTES, st, z, E, (long)M, pk, idx,
+                       getenv("DVQ_VQ_DBG") ? (unsigned long long*)s.dbg : nullptr);
     DVQ_CHECK_LAUNCH("vq_filter");
-    {
-        DVQ_PROF("vq_refine", 0, 0, st);
-        hipLaunchKernelGGL(vq_refine_kernel, dim3((unsigned)(s.n_wg * 2)), dim3(256), 0, st, z, E,
-                           (const float*)(pk + PK_OFF_EE), (long)M, idx, s.cand, s.cnt, s.amb_count, s.amb_list);
-    }
-    DVQ_CHECK_LAUNCH("vq_refine");
     return DVQ_OK;
 }
