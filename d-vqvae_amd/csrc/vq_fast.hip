@@ -28,9 +28,6 @@
 // Algorithmic HBM bytes per row: D*4 (z) + 8 (int64 index); the codebook (K*D*4) is read once.
 #include "dvq_internal.h"
 
-#ifndef DVQ_ABL
-#define DVQ_ABL 0
-#endif
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -368,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void vq_filter_kernel(const float* __restri
     for (int c = 0; c < NCHUNK; ++c) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's DMA pieces of chunk c (the compiler does not see the asm readers)
         __syncthreads();                                          // chunk c landed everywhere; the other stage is free
-        if (c + 1 < NCHUNK && DVQ_ABL != 3) issue_chunk(img_b + (c + 1) * CHUNK_B, voff, lds + ((c + 1) & 1) * CHUNK_B, wave);
+        if (c + 1 < NCHUNK) issue_chunk(img_b + (c + 1) * CHUNK_B, voff, lds + ((c + 1) & 1) * CHUNK_B, wave);
         f32x16 (&cur)[2] = (c & 1) ? accB : accA;
         f32x16 (&prev)[2] = (c & 1) ? accA : accB;
         // Issue order per k-step s: [|e|^2 quad of score group s/2+1 (even s)], fragments of step s+PF, wait for step s's
@@ -398,11 +395,11 @@ __global__ __launch_bounds__(256, 2) void vq_filter_kernel(const float* __restri
             const bool quad_this = c > 0 && (s & 1) == 0 && s / 2 + 1 < KS / 2;
             const int younger = s == 0 ? (c > 0 ? 3 : 4)
                                        : (s + 1 < KS ? 2 : 0) + (s + 2 < KS ? 2 : 0) + (quad_prev ? 1 : 0) + (quad_this ? 1 : 0);
-            if (c > 0) lds_wait(DVQ_ABL == 4 ? 0 : younger, ef[s][0], ef[s][1], ev[s / 2]);
-            else lds_wait(DVQ_ABL == 4 ? 0 : younger, ef[s][0], ef[s][1]);
+            if (c > 0) lds_wait(younger, ef[s][0], ef[s][1], ev[s / 2]);
+            else lds_wait(younger, ef[s][0], ef[s][1]);
             cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ef[s][0], zh[s], s == 0 ? zero16 : cur[0], 0, 0, 0);
             cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ef[s][1], zh[s], s == 0 ? zero16 : cur[1], 0, 0, 0);
-            if (c > 0 && (DVQ_ABL != 2 || s == 0)) {              // two scores of the previous chunk per k-step: vector work in the MFMA shadow
+            if (c > 0) {              // two scores of the previous chunk per k-step: vector work in the MFMA shadow
                 const int q = 2 * s, jn = q >> 4, e = q & 15;     // acc register e of tile jn: entry 64 (c-1) + 32 jn + 8 (e>>2) + 4 h + (e&3)
                 absorb1(prev[jn][e], inv, ev[q >> 2][q & 3], ids4[q >> 2], q & 3, m1, m2, m3, m4);
                 absorb1(prev[jn][e + 1], inv, ev[q >> 2][(q + 1) & 3], ids4[q >> 2], (q + 1) & 3, m1, m2, m3, m4);
@@ -620,6 +617,8 @@ __global__ __launch_bounds__(256, 2) void vq_filter_kernel(const float* __restri
         const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
         dbg[blockIdx.x * 8 + 0] = t0; dbg[blockIdx.x * 8 + 1] = t1; dbg[blockIdx.x * 8 + 2] = t2; dbg[blockIdx.x * 8 + 3] = t3;
         dbg[blockIdx.x * 8 + 4] = (unsigned long long)total; dbg[blockIdx.x * 8 + 5] = (unsigned long long)n_over;
+        dbg[blockIdx.x * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));   // HW_ID
+        dbg[blockIdx.x * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));  // XCC_ID
     }
 }
 

@@ -399,6 +399,30 @@ def test_vq_fast_adversarial_rows():
     assert idx[0] == 7 and idx[1] == 7 and idx[2] == 399
 
 
+def test_vq_fast_incomplete_candidate_lists():
+    """Rows with more near-minimal entries than a lane can track (four): the in-kernel second-level filter (plain fp32
+    distances, then canonical chains for <= 64 entries), its overflow to the all-entries canonical scan (> 64 entries,
+    or the workgroup's pair list full), many such rows in one workgroup."""
+    K, D = 512, 256
+    E = synth.synthetic_normal((K, D), 11, "vqinc/E")
+    noise = synth.synthetic_normal((K, D), 11, "vqinc/n")
+    for k in range(1, 100):                                    # 100 entries within 1e-6 of each other
+        E[k] = E[0] + 1e-7 * noise[k]
+    for k in range(201, 210):                                  # 10 entries, same
+        E[k] = E[200] + 1e-7 * noise[k]
+    for k in range(301, 340):                                  # 40 exact copies
+        E[k] = E[300]
+    z = synth.synthetic_normal((640, D), 11, "vqinc/z")
+    z[0:200] = E[0] + 1e-3 * z[0:200]                          # > 64 second-level candidates: whole workgroups of them
+    z[200:330] = E[200] + 1e-3 * z[200:330]                    # 10 candidates per row: > 768 pairs in one workgroup
+    z[330:400] = E[300] + 1e-3 * z[330:400]                    # 40-way exact ties -> first index
+    z[400] = E[300]
+    idx = _fast_vs_exact(gpu(z), gpu(E), "incomplete lists")
+    ci, _ = vq_canonical.argmin(z.numpy(), E.numpy())
+    assert np.array_equal(idx.cpu().numpy(), ci)
+    assert int(idx[400]) == 300 and bool((idx[330:400] == 300).all())
+
+
 def test_vq_fast_scales_and_tie_prone_codebook():
     for scale_z, scale_e in [(1.0, 1.0 / 512), (100.0, 0.01), (1e-3, 1e3), (30.0, 30.0)]:
         E = synth.synthetic_uniform((512, 256), 10, f"vqs/E/{scale_e}", -scale_e, scale_e)
@@ -416,7 +440,7 @@ def test_vq_fast_full_size():
     rows = torch.arange(0, 65536, 97)
     ci, _ = vq_canonical.argmin(z[rows].cpu().numpy(), E.cpu().numpy())
     assert np.array_equal(idx[rows].cpu().numpy(), ci)
-    # repeatability (the prefetch ring must not leak stale tiles between launches)
+    # repeatability (nothing may leak between launches)
     for _ in range(3):
         assert torch.equal(ops.vq_argmin(z, E, packed=packed), idx)
 
