@@ -6,10 +6,12 @@
 //       that put the largest magnitude in [2^13, 2^14)).  Every lane keeps the FOUR smallest scores it has seen
 //       (entry id packed into the low 8 mantissa bits); a row's candidates are the scores within a PROVEN eps_row
 //       of the row minimum, so the exact fp32 argmin is always among them.  One candidate -> decided; else
-//   refine (vq_refine_kernel): the canonical fp32 evaluation d_k = (zz + ee_k) - 2*dot_k (k-ordered fmaf
-//       chains) of the <= 6 candidates, torch.argmin ordering (first minimum, NaN first).  Rows whose
-//       candidate set is empty (NaN/Inf, magnitudes outside 2^+-40) or may be incomplete (a lane's fourth-smallest
-//       score is still within eps) are evaluated over all K entries.
+//   refine (same kernel, same workgroup): the canonical fp32 evaluation d_k = (zz + ee_k) - 2*dot_k (k-ordered fmaf
+//       chains) of the <= 6 candidates, torch.argmin ordering (first minimum, NaN first).  Rows whose candidate
+//       set may be incomplete (a lane's fourth-smallest score is still within eps) pass a second-level filter
+//       (plain fp32 distances of all K entries, threshold 4 gamma_260 (|z| + Emax)^2) and evaluate its <= 64
+//       survivors; rows with an empty set (NaN/Inf, magnitudes outside 2^+-40) or more survivors are evaluated
+//       canonically over all K entries.
 //
 // Error bound.  With u = 2^-12 (fp16 round-to-nearest; elements below the fp16 normal range add at most
 // 2^-20 |z||e| in total, flushed or not), for every k
@@ -22,9 +24,10 @@
 // Structure (the fused PointNet trunk's, pointnet.hip): a wave owns 32 rows; their fp16 fragments (64 VGPRs) are
 // the MFMA B operand for the whole kernel; the codebook image (256 KB, L2-resident) streams L2 -> LDS by
 // global_load_lds in 32 KB chunks of 64 entries (XOR-swizzled source, conflict-free ds_read_b128), double buffered,
-// one barrier per chunk; scores land with the row on the lane and the entry on the registers, so the top-3 tracking
+// one barrier per chunk; scores land with the row on the lane and the entry on the registers, so the top-4 tracking
 // is lane-local VALU work interleaved with the next chunk's MFMAs.  128 rows per 256-thread workgroup, two
-// workgroups per CU.  z is read from HBM exactly once (fragment-shaped loads straight to registers).
+// workgroups per CU.  z is read from HBM exactly once (whole 1 KiB lines by LDS-DMA, then fragments to registers);
+// ambiguous rows re-read their 1 KiB (L2/MALL) in the refine tail.
 // Algorithmic HBM bytes per row: D*4 (z) + 8 (int64 index); the codebook (K*D*4) is read once.
 #include "dvq_internal.h"
 
