@@ -82,7 +82,7 @@ def pmc_traffic(kind, batch):
     correction + WRITE_SIZE, profiles/*_pmc_hbm_traffic.json; collected at the default batch only) or None."""
     if batch != 65536:
         return None
-    names = {"pn_trunk": "pn_trunk_kernel<4>", "gemm_gate": "gemm_bf16x3_dma_kernel<2>", "gemm_bias": "gemm_bf16x3_dma_kernel<0>",
+    names = {"vq_fast": "vq_filter_kernel", "pn_trunk": "pn_trunk_kernel<4>", "gemm_gate": "gemm_bf16x3_dma_kernel<2>", "gemm_bias": "gemm_bf16x3_dma_kernel<0>",
              "gemm_resid": "gemm_bf16x3_dma_kernel<1>"}
     try:
         import glob
@@ -138,7 +138,7 @@ def vq_microbench(args, lib, _lib, ops, dev, K):
     exact = ops.vq_argmin(z, E, fast=False)
     ref_idx = torch.argmin((z ** 2).sum(1, keepdim=True) + (E ** 2).sum(1) - 2 * z @ E.t(), dim=1)
     res = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-           "traffic": None, "us_per_call": dur * 1e6, "algorithmic_bytes": alg_bytes, "rows_per_s": M / dur,
+           "traffic": pmc_traffic("vq_fast", 65536), "us_per_call": dur * 1e6, "algorithmic_bytes": alg_bytes, "rows_per_s": M / dur,
            "bit_match_vs_exact_fp32_kernel": float((idx == exact).float().mean()),
            "index_match_rate_vs_torch_gpu_expr": float((idx == ref_idx).float().mean()),
            "workload": "VectorQuantizer K=512 D=256 argmin-only, M=65536; duration = every kernel of one call "

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel-trace stats of the default bench and of the VQ microbench, plus the
+# two PMC passes (FETCH_SIZE, WRITE_SIZE - separate runs, counters only with --kernel-trace) for HBM traffic.
+# Outputs land in gpurun_out/prof_<tag>/; tools/summarize_profiles.py turns them into the files kept under profiles/.
+set -u
+TAG=${1:-r01}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+run() { # name, then the rocprofv3 args
+  local name=$1; shift
+  timeout 900 rocprofv3 "$@" -d $OUT/$name -o $name --output-format csv -- python3 bench.py ${BENCH_ARGS} > $OUT/$name.json 2> $OUT/$name.log
+  echo "$name rc=$?"
+}
+BENCH_ARGS="--steps 2 --warmup 1 --no-cpu-baseline" run bench_stats --kernel-trace --stats
+BENCH_ARGS="--vq-only" run vq_stats --kernel-trace --stats
+BENCH_ARGS="--vq-only" run vq_pmc_fetch --kernel-trace --pmc FETCH_SIZE
+BENCH_ARGS="--vq-only" run vq_pmc_write --kernel-trace --pmc WRITE_SIZE
+BENCH_ARGS="--steps 1 --warmup 1 --no-cpu-baseline" run bench_pmc_fetch --kernel-trace --pmc FETCH_SIZE
+BENCH_ARGS="--steps 1 --warmup 1 --no-cpu-baseline" run bench_pmc_write --kernel-trace --pmc WRITE_SIZE
+find $OUT -name "*.csv" | head -30

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 output of tools/collect_profiles.sh (gpurun_out/prof_<tag>/) into the summaries kept under
+profiles/: the per-kernel stats CSVs as they are, and <tag>_pmc_hbm_traffic.json = HBM bytes per launch per kernel from the
+FETCH_SIZE and WRITE_SIZE passes (both count KB; FETCH_SIZE x2 on gfx950, /opt/skills/guides/MI355X_MICROARCH.md).
+
+    python tools/summarize_profiles.py r01_v4
+"""
+import csv, glob, json, os, shutil, sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def find(d, pattern):
+    hits = sorted(glob.glob(os.path.join(d, "**", pattern), recursive=True))
+    return hits[0] if hits else None
+
+
+def counters(path, name):
+    acc = defaultdict(lambda: [0.0, 0])
+    if not path:
+        return acc
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row.get("Counter_Name") != name:
+                continue
+            a = acc[row["Kernel_Name"]]
+            a[0] += float(row["Counter_Value"]); a[1] += 1
+    return acc
+
+
+def traffic(src, stem):
+    fe = counters(find(os.path.join(src, f"{stem}_pmc_fetch"), "*counter_collection.csv"), "FETCH_SIZE")
+    wr = counters(find(os.path.join(src, f"{stem}_pmc_write"), "*counter_collection.csv"), "WRITE_SIZE")
+    rows = []
+    for k in sorted(fe, key=lambda k: -fe[k][0]):
+        n = fe[k][1]
+        fb = fe[k][0] / n * 1024.0
+        wb = (wr[k][0] / wr[k][1] * 1024.0) if k in wr and wr[k][1] else 0.0
+        rows.append({"kernel": k[:60], "launches": n, "fetch_size_bytes_raw": fb, "write_size_bytes": wb,
+                     "hbm_bytes_corrected": 2.0 * fb + wb})
+    return rows
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    dst = os.path.join(ROOT, "profiles")
+    for stem in ("bench_stats", "vq_stats"):
+        p = find(os.path.join(src, stem), "*kernel_stats.csv")
+        if p:
+            shutil.copy(p, os.path.join(dst, f"{tag}_{stem}_rocprofv3_kernel_stats.csv"))
+        j = os.path.join(src, f"{stem}.json")
+        if os.path.exists(j) and os.path.getsize(j):
+            shutil.copy(j, os.path.join(dst, f"{tag}_{stem}_bench_under_rocprofv3.json"))
+    rows = traffic(src, "bench") + [dict(r, scope="vq microbench") for r in traffic(src, "vq")]
+    if rows:
+        json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only), KB counters "
+                           "converted to bytes, mean per launch; per MI355X_MICROARCH.md FETCH_SIZE under-reports wide "
+                           "coalesced reads by 2x on gfx950 (x2 applied in hbm_bytes_corrected)",
+                   "per_launch_bytes": rows}, open(os.path.join(dst, f"{tag}_pmc_hbm_traffic.json"), "w"), indent=1)
+    print("wrote", sorted(os.listdir(dst)))
+
+
+if __name__ == "__main__":
+    main()
