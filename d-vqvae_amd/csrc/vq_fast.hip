@@ -13,13 +13,17 @@
 //       survivors; rows with an empty set (NaN/Inf, magnitudes outside 2^+-40) or more survivors are evaluated
 //       canonically over all K entries.
 //
-// Error bound.  With u = 2^-12 (fp16 round-to-nearest; elements below the fp16 normal range add at most
-// 2^-20 |z||e| in total, flushed or not), for every k
-//   |s_k - (true_k - |z|^2)| <= 2 (2u + u^2 + 2^-20) |z||e_k| + gamma_258 (|e_k|^2 + 2|z||e_k|)   (filter)
-//   |d_k - true_k|           <= gamma_260 (|z| + |e_k|)^2                                          (exact side)
-//   |packed(s_k) - s_k|      <= 2^-15 |s_k| <= 2^-15 (|z| + |e_k|)^2                               (id in the mantissa)
-// hence for the exact winner k*:  packed(s_k*) <= min_k packed(s_k) + eps_row,
-//   eps_row = 2^-9 (1 + 2^-8) |z| Emax + (2^-13 + 2^-14) (|z| + Emax)^2     (gamma_n = n 2^-24, with slack).
+// Error bound.  The fp16 rounding errors are MEASURED, not bounded a priori: with dz_j = z_j - h(sz z_j)/sz and
+// de_kj = e_kj - h(-2 sE e_kj)/(-2 sE) (both exact in fp32; underflow and flushes included), the products
+// h.h are exact in the MFMA's fp32, so for every k
+//   |s_k - (true_k - |z|^2)| <= 2 (|dz||e_k| + |z||de_k| + |dz||de_k|) + gamma_258' (|e_k|^2 + 2|z||e_k|)   (filter)
+//   |d_k - true_k|           <= gamma_260 (|z| + |e_k|)^2                                                  (exact side)
+//   |packed(s_k) - s_k|      <= 2^-15 |s_k| <= 2^-15 (|z| + |e_k|)^2                                  (id in the mantissa)
+// (gamma_n = n 2^-24; gamma' allows a truncating accumulator, n 2^-23), hence for the exact winner k*:
+//   packed(s_k*) <= min_k packed(s_k) + eps_row,
+//   eps_row = 4 (|dz| Emax + |z| dEmax + |dz| dEmax) + (2^-13 + 2^-14) (|z| + Emax)^2,
+// |dz| per row from the kernel's own conversion, dEmax = max_k |de_k| from dvq_vq_pack, norms rounded up.  (The a-priori
+// bound would be |dz| <= 2^-11 |z|: eps = 2^-8 |z| Emax + ...; the measured norms are ~0.4 of that.)
 //
 // Structure (the fused PointNet trunk's, pointnet.hip): a wave owns 32 rows; their fp16 fragments (64 VGPRs) are
 // the MFMA B operand for the whole kernel; the codebook image (256 KB, L2-resident) streams L2 -> LDS by
@@ -62,6 +66,7 @@ struct PackHeader {
     int sexp;          // codebook scale sE = 2^sexp
     int valid;         // 0: codebook magnitudes outside the filter's range -> every row takes the exact path
     int K, D;
+    float demax;       // upper bound of max_k |e_k - image_k / (-2 sE)|_2: the image's MEASURED fp16 rounding error
 };
 constexpr size_t PK_OFF_EE = 256;
 constexpr size_t PK_OFF_IMG = PK_OFF_EE + (size_t)K * 4;
@@ -110,6 +115,26 @@ __global__ void vq_pack_img_kernel(const float* __restrict__ E, const PackHeader
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= K * D) return;
     img[gid] = (_Float16)(-2.0f * pow2f(hdr->sexp) * E[gid]);
+}
+
+// measured rounding error of the image, per entry, as a 2-norm in codebook units; its maximum goes into the header
+__global__ void vq_pack_err_kernel(const float* __restrict__ E, const _Float16* __restrict__ img, PackHeader* hdr) {
+    __shared__ float red[K];
+    const int k = threadIdx.x;                                   // blockDim = K
+    const float m2s = -2.0f * pow2f(hdr->sexp);
+    float acc = 0.f;
+    for (int j = 0; j < D; ++j) {
+        const float sv = m2s * E[k * D + j];                     // exact (power-of-two scale, range checked by `valid`)
+        const float d = sv - (float)img[k * D + j];              // exact: both are fp32 values 11 significant bits apart
+        acc = fmaf(d, d, acc);
+    }
+    red[k] = acc;
+    __syncthreads();
+    for (int o = K / 2; o > 0; o >>= 1) {
+        if (k < o) red[k] = fmaxf(red[k], red[k + o]);
+        __syncthreads();
+    }
+    if (k == 0) hdr->demax = hdr->valid ? sqrtf(red[0]) / fabsf(m2s) * 1.0001f : INFINITY;
 }
 
 // ------------------------------------------------------------------------------------------------ filter
@@ -275,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void vq_filter_kernel(const float* __restri
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const PackHeader* hdr = reinterpret_cast<const PackHeader*>(packed);
-    const float emax = hdr->emax;
+    const float emax = hdr->emax, demax = hdr->demax;
     const int e_sexp = hdr->sexp;
     const bool e_valid = hdr->valid != 0;
     const float* ee_g = reinterpret_cast<const float*>(packed + PK_OFF_EE);
@@ -334,15 +359,24 @@ __global__ __launch_bounds__(256, 2) void vq_filter_kernel(const float* __restri
     const float sc = pow2f(zs);
     const float zn = __builtin_amdgcn_sqrtf(ss) * 1.0001f;
     f16x8 zh[KS];                                                // MFMA B operand: B[k = 8h + j][col = row r]
+    float dsq = 0.f;                                             // measured rounding error of the row: sum (sz z_j - h(sz z_j))^2
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         f16x8 v;
-        v[0] = (_Float16)(zf[s][0][0] * sc); v[1] = (_Float16)(zf[s][0][1] * sc);
-        v[2] = (_Float16)(zf[s][0][2] * sc); v[3] = (_Float16)(zf[s][0][3] * sc);
-        v[4] = (_Float16)(zf[s][1][0] * sc); v[5] = (_Float16)(zf[s][1][1] * sc);
-        v[6] = (_Float16)(zf[s][1][2] * sc); v[7] = (_Float16)(zf[s][1][3] * sc);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float sv = zf[s][q][i] * sc;               // exact
+                const _Float16 hv = (_Float16)sv;
+                const float d = sv - (float)hv;                  // exact
+                dsq = fmaf(d, d, dsq);
+                v[4 * q + i] = hv;
+            }
         zh[s] = v;
     }
+    dsq += __shfl_xor(dsq, 32);
+    const float dzn = __builtin_amdgcn_sqrtf(dsq) * pow2f(-zs) * 1.0001f;    // |z - h(sz z)/sz|_2, rounded up
 
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
     // ---- stream the codebook: chunk c in stage c & 1; scores of chunk c are absorbed while chunk c+1 multiplies
@@ -427,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void vq_filter_kernel(const float* __restri
     // ---- per row: merge the two lane halves' top-4 lists, threshold, decide or refine
     const float p1 = __shfl_xor(m1, 32), p2 = __shfl_xor(m2, 32), p3 = __shfl_xor(m3, 32), p4 = __shfl_xor(m4, 32);
     const float best = fminf(m1, p1);
-    const float eps = 0.00196076f * zn * emax + 0.00018311f * (zn + emax) * (zn + emax);
+    const float eps = 4.004f * (dzn * emax + zn * demax + dzn * demax) + 0.00018311f * (zn + emax) * (zn + emax);
     const float thr = best + eps + (inv - inv);                  // NaN scale (exact path) poisons the threshold
     const int own = (m1 <= thr) + (m2 <= thr) + (m3 <= thr);
     const int oth = (p1 <= thr) + (p2 <= thr) + (p3 <= thr);
@@ -656,6 +690,8 @@ extern "C" int dvq_vq_pack(const float* E, int Kq, int Dq, void* packed, size_t 
     hipLaunchKernelGGL(vq_pack_img_kernel, dim3((K * D + 255) / 256), dim3(256), 0, st, E, (const PackHeader*)pk,
                        (_Float16*)(pk + PK_OFF_IMG));
     DVQ_CHECK_LAUNCH("vq_pack_img");
+    hipLaunchKernelGGL(vq_pack_err_kernel, dim3(1), dim3(K), 0, st, E, (const _Float16*)(pk + PK_OFF_IMG), (PackHeader*)pk);
+    DVQ_CHECK_LAUNCH("vq_pack_err");
     return DVQ_OK;
 }
 
