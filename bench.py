@@ -153,6 +153,30 @@ def vq_microbench(args, lib, _lib, ops, dev, K):
     lib.dvq_prof_enable(0)
     pk = prof_read(lib, _lib); lib.dvq_prof_reset()
     res["exact_fp32_kernel_us"] = pk["vq_argmin_total"]["ms"] / pk["vq_argmin_total"]["count"] * 1e3
+    # SURVEY 8(d) second run: the reference's initial codebook U(+-1/K) against the same O(1) rows -- ill-conditioned
+    # (fp32 itself cancels |z|^2 against a 1e-2 spread).  Forced fast kernel vs exact kernel; the VectorQuantizer module
+    # watches the kernel's slow-row counter and uses the exact kernel there (tests/test_gpu_parity.py).
+    Et = (torch.rand(K, D, device=dev) * 2 - 1) / K
+    pt = ops.vq_pack(Et)
+    slow = torch.zeros(1, dtype=torch.int64, device=dev)
+    it = ops.vq_argmin(z, Et, packed=pt, slow_rows=slow)
+    et = ops.vq_argmin(z, Et, fast=False)
+    torch.cuda.synchronize(dev)
+
+    def timed(fn, n=3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) * 1e3 / n
+    res["tie_prone_regime"] = {"codebook": "U(-1/512, 1/512) (reference init, quantizer.py:27)", "rows": "N(0,1)",
+                               "fast_kernel_forced_us": timed(lambda: ops.vq_argmin(z, Et, packed=pt)),
+                               "exact_kernel_us": timed(lambda: ops.vq_argmin(z, Et, fast=False)),
+                               "slow_row_fraction": float(slow.item()) / M,
+                               "bit_match_fast_vs_exact": float((it == et).float().mean()),
+                               "module_choice": "exact kernel (VectorQuantizer switches when > 1/16 of the rows are slow)"}
     return res
 
 

@@ -73,7 +73,7 @@ SIGNATURES = {
     "dvq_vq_pack": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, c_stream]),
     "dvq_vq_fast_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "dvq_vq_argmin_fast": (C.c_int, [c_f32p, c_f32p, C.c_void_p, C.c_int64, C.c_int, C.c_int, c_i64p, C.c_void_p,
-                                     C.c_size_t, c_stream]),
+                                     C.c_void_p, C.c_size_t, c_stream]),
     "dvq_vq_lookup": (C.c_int, [c_f32p, c_i64p, C.c_int64, C.c_int64, C.c_int, C.c_int, c_f32p, C.c_int64, c_i32p, c_stream]),
     "dvq_pointnet_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "dvq_pointnet_encode": (C.c_int, [C.POINTER(PointnetWeights), c_f32p, C.c_int64, C.c_int, c_f32p, C.c_int64, c_f32p,

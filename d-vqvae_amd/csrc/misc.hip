@@ -12,7 +12,7 @@ void dvq_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* dvq_last_error(void) { return g_err; }
-extern "C" int dvq_abi_version(void) { return 1; }
+extern "C" int dvq_abi_version(void) { return 2; }
 extern "C" int dvq_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return -1;

@@ -291,6 +291,7 @@ __device__ __forceinline__ void chain_pair(const float* __restrict__ zr, const f
 
 __global__ __launch_bounds__(256, 2) void vq_filter_kernel(const float* __restrict__ z, const float* __restrict__ E, long M,
                                                            const char* __restrict__ packed, int64_t* __restrict__ idx,
+                                                           unsigned long long* __restrict__ slow_rows,
                                                            unsigned long long* __restrict__ dbg) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -512,6 +513,7 @@ __global__ __launch_bounds__(256, 2) void vq_filter_kernel(const float* __restri
     }
     __syncthreads();
     const int n_over = s_tot[1];
+    if (slow_rows && n_over > 0 && tid == 0) atomicAdd(slow_rows, (unsigned long long)n_over);
     // Second-level filter for the (rare) finite rows with a possibly incomplete list: every entry's distance by plain
     // fp32 dot products, a wave per entry so the row loads are coalesced.  Any summation order keeps
     // |approx_k - true_k| <= gamma_260 (|z| + |e_k|)^2, and so does the canonical chain, hence the canonical winner
@@ -701,7 +703,8 @@ extern "C" size_t dvq_vq_fast_workspace_bytes(int64_t M, int Kq, int Dq) {
 }
 
 extern "C" int dvq_vq_argmin_fast(const float* z, const float* E, const void* packed, int64_t M, int Kq, int Dq,
-                                  int64_t* idx, void* workspace, size_t workspace_bytes, dvq_stream_t stream) {
+                                  int64_t* idx, unsigned long long* slow_rows, void* workspace, size_t workspace_bytes,
+                                  dvq_stream_t stream) {
     DVQ_REQUIRE(dvq_vq_fast_supported(Kq, Dq), "vq_argmin_fast: supports K=%d, D=%d only (got %d, %d)", K, D, Kq, Dq);
     DVQ_REQUIRE(M >= 0 && M < (1L << 31), "vq_argmin_fast: bad M");
     if (M == 0) return DVQ_OK;
@@ -727,7 +730,7 @@ extern "C" int dvq_vq_argmin_fast(const float* z, const float* E, const void* pa
     const char* pk = (const char*)packed;
     DVQ_PROF("vq_argmin_fast", 2.0 * M * K * D, (double)M * D * 4 + (double)K * D * 2 + (double)M * 8, st);
     hipLaunchKernelGGL(vq_filter_kernel, dim3((unsigned)s.n_wg), dim3(256), LDS_BYTES, st, z, E, (long)M, pk, idx,
-                       getenv("DVQ_VQ_DBG") ? (unsigned long long*)s.dbg : nullptr);
+                       slow_rows, getenv("DVQ_VQ_DBG") ? (unsigned long long*)s.dbg : nullptr);
     DVQ_CHECK_LAUNCH("vq_filter");
     return DVQ_OK;
 }

@@ -13,7 +13,9 @@ class VectorQuantizer(nn.Module):
         self.embedding.weight.data.uniform_(-1.0 / n_e, 1.0 / n_e)
 
     def _packed_codebook(self, E):
-        """Fast-path image of the codebook, rebuilt whenever the parameter is replaced, moved or edited in place."""
+        """Fast-path image of the codebook, rebuilt whenever the parameter is replaced, moved or edited in place
+        (load_state_dict, optimizer steps, no_grad in-place ops: anything that bumps the tensor version; writes
+        through ``weight.data`` bypass the version counter -- call ``invalidate_pack()`` after those)."""
         if not ops.vq_fast_supported(self.n_e, self.e_dim):
             return None
         w = self.embedding.weight
@@ -24,10 +26,58 @@ class VectorQuantizer(nn.Module):
             object.__setattr__(self, "_pack_cache", cached)
         return cached[1]
 
+    # The fast kernel decides ~all rows of a well-conditioned problem from short candidate lists; on an ill-conditioned
+    # one (|z| far above the codebook's spread, e.g. the reference's U(+-1/n_e) initial codebook against O(1)
+    # features) most rows need its slow all-entries scan and the exact kernel is faster.  The kernel counts those rows
+    # on the device; the count is fetched without a sync every few calls and the module switches to the exact kernel
+    # (same indices) once more than 1/16 of a window's rows were slow.  State lives with the packed codebook.
+    SLOW_FRACTION = 1.0 / 16.0
+    PROBE_EVERY = 8
+
+    def _regime(self, packed):
+        st = getattr(self, "_regime_state", None)
+        if st is None or st["packed"] is not packed:
+            dev = packed.device
+            st = dict(packed=packed, counter=torch.zeros(1, dtype=torch.int64, device=dev),
+                      host=torch.zeros(1, dtype=torch.int64).pin_memory(), event=None, calls=0, rows=0,
+                      rows_at_copy=0, rows_seen=0, slow_seen=0, prefer_exact=False)
+            object.__setattr__(self, "_regime_state", st)
+        return st
+
+    def _regime_update(self, st, M):
+        st["rows"] += M
+        ev = st["event"]
+        if ev is not None and ev.query():
+            slow = int(st["host"][0])
+            d_slow, d_rows = slow - st["slow_seen"], st["rows_at_copy"] - st["rows_seen"]
+            if d_rows > 0 and d_slow > self.SLOW_FRACTION * d_rows:
+                st["prefer_exact"] = True
+            st["slow_seen"], st["rows_seen"], st["event"] = slow, st["rows_at_copy"], None
+        if st["event"] is None and st["calls"] % self.PROBE_EVERY == 0:
+            st["host"].copy_(st["counter"], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            st["event"], st["rows_at_copy"] = ev, st["rows"]
+        st["calls"] += 1
+
+    def invalidate_pack(self):
+        object.__setattr__(self, "_pack_cache", None)
+        object.__setattr__(self, "_regime_state", None)
+
     def _quantize(self, z):
         E = self.embedding.weight.detach()
         zf = z.detach().reshape(-1, self.e_dim)
-        idx = ops.vq_argmin(zf if zf.is_contiguous() else zf.contiguous(), E, packed=self._packed_codebook(E))
+        zf = zf if zf.is_contiguous() else zf.contiguous()
+        packed = self._packed_codebook(E)
+        if packed is None or zf.shape[0] == 0:
+            idx = ops.vq_argmin(zf, E)
+        else:
+            st = self._regime(packed)
+            if st["prefer_exact"]:
+                idx = ops.vq_argmin(zf, E, fast=False)
+            else:
+                idx = ops.vq_argmin(zf, E, packed=packed, slow_rows=st["counter"])
+                self._regime_update(st, zf.shape[0])
         z_q = ops.vq_lookup(E, idx).view(z.shape)
         return idx.unsqueeze(1), z_q
 

@@ -144,11 +144,12 @@ def vq_pack(E: Tensor) -> Tensor:
 
 
 def vq_argmin(z: Tensor, E: Tensor, return_dist: bool = False, fast: Optional[bool] = None,
-              packed: Optional[Tensor] = None):
+              packed: Optional[Tensor] = None, slow_rows: Optional[Tensor] = None):
     """idx[m] = argmin_k (|z_m|^2 + |E_k|^2) - 2 z_m.E_k in the canonical fp32 order -> int64 [M].
     K=512/D=256 on dense rows takes the filter+refine kernels (same indices, bit for bit); everything else
     (and ``return_dist``) the exact fp32-MFMA kernel.  ``fast`` forces the choice; ``packed`` = vq_pack(E) skips the
-    per-call codebook packing (two tiny kernels)."""
+    per-call codebook packing (three tiny kernels); ``slow_rows`` (int64 [1] on the device, accumulated, never reset)
+    counts the rows the fast kernel could not decide from their candidate lists (see dvq.h)."""
     lib = _lib.load()
     dev = _require_gpu(z, E)
     _f32(z, "z"), _f32(E, "E")
@@ -171,8 +172,9 @@ def vq_argmin(z: Tensor, E: Tensor, return_dist: bool = False, fast: Optional[bo
         nws = lib.dvq_vq_fast_workspace_bytes(M, K, D)
         ws = workspace(nws, dev)
         with torch.cuda.device(dev):
-            check(lib.dvq_vq_argmin_fast(pz, E.data_ptr(), packed.data_ptr(), M, K, D, idx.data_ptr(), ws.data_ptr(),
-                                         ws.numel(), _stream(dev)), "dvq_vq_argmin_fast")
+            check(lib.dvq_vq_argmin_fast(pz, E.data_ptr(), packed.data_ptr(), M, K, D, idx.data_ptr(),
+                                         _i64(slow_rows, "slow_rows").data_ptr() if slow_rows is not None else None,
+                                         ws.data_ptr(), ws.numel(), _stream(dev)), "dvq_vq_argmin_fast")
         return idx
     dmin = torch.empty(M, dtype=torch.float32, device=dev) if return_dist else None
     nws = lib.dvq_vq_argmin_workspace_bytes(M, K)

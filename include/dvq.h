@@ -82,16 +82,20 @@ int dvq_vq_argmin(const float* z, int64_t ldz, const float* E, int64_t M, int K,
                   dvq_stream_t stream);
 
 /* Fast path for the headline shape (K = 512, D = 256, dense z): returns the SAME indices as dvq_vq_argmin,
- * bit for bit.  A bf16-MFMA filter with a proven error bound keeps every row's candidate entries (the exact
- * fp32 argmin is always among them); rows with one candidate are decided, the rest are re-evaluated in the
- * canonical fp32 order (DESIGN.md "vq_argmin").  `packed` is the codebook image built once per codebook by
- * dvq_vq_pack (bf16 MFMA fragments of -2E, canonical |e_k|^2, max |e_k|). */
+ * bit for bit.  One kernel: an fp16-MFMA filter with a proven error bound keeps every row's candidate entries (the
+ * exact fp32 argmin is always among them); rows with one candidate are decided, the rest are re-evaluated in the
+ * canonical fp32 order inside the same workgroup (DESIGN.md "vq_argmin").  `packed` is the codebook image built once
+ * per codebook by dvq_vq_pack (fp16 image of -2 sE E, canonical |e_k|^2, max |e_k|, measured rounding error).
+ * `slow_rows` (device, may be NULL, never reset by the library): the kernel adds the number of rows that could not
+ * be decided from their candidate list (second-level filter or all-entries scan, 10-20 us each).  A caller that sees
+ * a large fraction there (ill-conditioned input: |z| >> codebook spread) should use dvq_vq_argmin instead. */
 int dvq_vq_fast_supported(int K, int D);
 size_t dvq_vq_pack_bytes(int K, int D);
 int dvq_vq_pack(const float* E, int K, int D, void* packed, size_t packed_bytes, dvq_stream_t stream);
 size_t dvq_vq_fast_workspace_bytes(int64_t M, int K, int D);
 int dvq_vq_argmin_fast(const float* z, const float* E, const void* packed, int64_t M, int K, int D,
-                       int64_t* idx, void* workspace, size_t workspace_bytes, dvq_stream_t stream);
+                       int64_t* idx, unsigned long long* slow_rows, void* workspace, size_t workspace_bytes,
+                       dvq_stream_t stream);
 
 /* VectorQuantizer.get_emb / one-hot @ E (quantizer.py:50-53,68-75): out[m, :] = E[idx[m], :].
  * *err_flag (device int32, caller zeroes it) is set to 1 if any idx is outside [0,K). */

@@ -423,6 +423,31 @@ def test_vq_fast_incomplete_candidate_lists():
     assert int(idx[400]) == 300 and bool((idx[330:400] == 300).all())
 
 
+def test_quantizer_switches_to_exact_kernel_when_ill_conditioned():
+    """Reference-initialised codebook U(+-1/n_e) against O(1) features: nearly every row needs the fast kernel's slow
+    all-entries scan; the module must notice (device counter, no sync) and use the exact kernel.  Indices are the same
+    either way.  A well-separated codebook stays on the fast kernel."""
+    from dvqvae_amd.network.vqvae.quantizer import VectorQuantizer
+    torch.manual_seed(0)
+    vq = VectorQuantizer(512, 256, 0.25, 1.0).to(DEV).eval()                  # reference init
+    z = gpu(synth.synthetic_normal((4096, 256), 12, "vqreg/z"))
+    want = ops.vq_argmin(z, vq.embedding.weight.detach(), fast=False)
+    for _ in range(4):
+        idx, _ = vq(z, False)
+        torch.cuda.synchronize()
+        assert torch.equal(idx.squeeze(1), want)
+    assert vq._regime_state["prefer_exact"]
+    assert int(vq._regime_state["counter"][0]) > 4096 // 16
+    with torch.no_grad():
+        vq.embedding.weight.normal_()                                            # new codebook -> new pack, new state
+    want = ops.vq_argmin(z, vq.embedding.weight.detach(), fast=False)
+    for _ in range(4):
+        idx, _ = vq(z, False)
+        torch.cuda.synchronize()
+        assert torch.equal(idx.squeeze(1), want)
+    assert not vq._regime_state["prefer_exact"]
+
+
 def test_vq_fast_scales_and_tie_prone_codebook():
     for scale_z, scale_e in [(1.0, 1.0 / 512), (100.0, 0.01), (1e-3, 1e3), (30.0, 30.0)]:
         E = synth.synthetic_uniform((512, 256), 10, f"vqs/E/{scale_e}", -scale_e, scale_e)
