@@ -91,6 +91,11 @@ SIGNATURES = {
     "dvq_prof_reset": (C.c_int, []),
     "dvq_prof_read": (C.c_int, [C.POINTER(ProfEntry), C.c_int]),
     "dvq_transform_cloud": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int, c_f32p, c_stream]),
+    "dvq_nn_points": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int64, c_f32p, C.c_int64, C.c_int64, C.c_int64,
+                                C.c_int64, C.c_int, C.c_int, c_f32p, c_i64p, c_stream]),
+    "dvq_vertex_normals": (C.c_int, [c_f32p, C.c_int64, C.c_int, c_i32p, c_i32p, c_i32p, c_f32p, c_stream]),
+    "dvq_interior": (C.c_int, [c_f32p, c_f32p, C.c_int, c_f32p, C.c_int64, C.c_int64, C.c_int64, c_i64p, C.c_int64,
+                               C.c_int, C.c_void_p, c_stream]),
 }
 
 

@@ -103,8 +103,10 @@ def load_model(args, device) -> GenNet:
 
 @torch.no_grad()
 def generate_for_object(net: GenNet, obj4n: torch.Tensor, num_grasp: int, rotate: bool, rng: np.random.Generator,
-                        noise: Optional[torch.Tensor] = None) -> Dict[str, object]:
-    """num_grasp grasps for one object in ONE batched call.  Returns the reference's JSON fields plus tensors."""
+                        noise: Optional[torch.Tensor] = None, proxies: bool = False) -> Dict[str, object]:
+    """num_grasp grasps for one object in ONE batched call.  Returns the reference's JSON fields plus tensors.
+    ``proxies``: also the per-grasp penetration / contact proxies (contact.grasp_proxies) of the posed hands against
+    the (rotated) object clouds -- the cheap on-device stand-in for the scripts' trimesh / pybullet metrics."""
     dev = next(net.parameters()).device
     G = num_grasp
     if rotate:
@@ -122,7 +124,18 @@ def generate_for_object(net: GenNet, obj4n: torch.Tensor, num_grasp: int, rotate
     final = net.rh_mano(betas=params[:, :10], global_orient=params[:, 10:13], hand_pose=params[:, 13:58],
                         transl=params[:, 58:61])                                   # obman.py:252-253
     Rt = np.concatenate([R, np.broadcast_to(t.reshape(1, 3, 1), (G, 3, 1))], axis=2)
-    return {"params": params, "vertices": final.vertices,
+    extra = {}
+    if proxies:
+        from . import contact
+        faces = np.asarray(net.rh_mano.faces)
+        if faces.size == 0 or int(faces.max()) == 0:
+            raise RuntimeError("proxies: the MANO layer has no face list (synthetic model); load MANO_RIGHT.pkl")
+        topo = getattr(net, "_hand_topology", None)
+        if topo is None or topo.faces.device != dev:
+            topo = contact.HandTopology(faces, final.vertices.shape[1], dev)
+            object.__setattr__(net, "_hand_topology", topo)
+        extra["proxies"] = contact.grasp_proxies(topo, final.vertices, batch[:, :3].transpose(1, 2))
+    return {**extra, "params": params, "vertices": final.vertices,
             "json": {"recon_params": [[p] for p in params.cpu().numpy().tolist()],   # [[61 floats]] per grasp, as the reference
                      "R_list": Rt.tolist(), "trans_list": [t.reshape(3, 1).tolist()] * G, "r_list": angles.tolist()}}
 

@@ -357,3 +357,69 @@ def transform_cloud(pc: Tensor, R: Tensor, t: Optional[Tensor] = None) -> Tensor
         check(lib.dvq_transform_cloud(pc.data_ptr(), bstride, R.data_ptr(), t.data_ptr() if t is not None else None, B, Cc,
                                       N, out.data_ptr(), _stream(dev)), "dvq_transform_cloud")
     return out
+
+
+# ---------------------------------------------------------------------------------------- contact / penetration proxies
+def _points(x: Tensor, name: str):
+    """[B,N,3]-shaped view (any strides: a permuted [B,C,N] cloud is read in place) -> (ptr, batch, point, coord strides)."""
+    if x.dim() != 3 or x.shape[2] != 3:
+        raise RuntimeError(f"{name}: expected [B,N,3] (got {tuple(x.shape)})")
+    _f32(x, name)
+    return x.data_ptr(), x.stride(0), x.stride(1), x.stride(2)
+
+
+def nn_points(src: Tensor, trg: Tensor):
+    """Nearest target point per source point (utils_loss.get_NN): src [B,N1,3], trg [B,N2,3] -> (dist2 [B,N1] f32,
+    idx [B,N1] int64).  d = fma(dz,dz, fma(dy,dy, dx*dx)); first minimum; NaN first."""
+    lib = _lib.load()
+    dev = _require_gpu(src, trg)
+    ps, sb, sp, sc = _points(src, "src")
+    pt, tb, tp, tc = _points(trg, "trg")
+    B, N1, N2 = src.shape[0], src.shape[1], trg.shape[1]
+    if trg.shape[0] != B:
+        raise RuntimeError("nn_points: batch mismatch")
+    dist = torch.empty(B, N1, dtype=torch.float32, device=dev)
+    idx = torch.empty(B, N1, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.dvq_nn_points(ps, sb, sp, sc, pt, tb, tp, tc, B, N1, N2, dist.data_ptr(), idx.data_ptr(), _stream(dev)),
+              "dvq_nn_points")
+    return dist, idx
+
+
+def vertex_normals(verts: Tensor, faces: Tensor, vf_off: Tensor, vf_face: Tensor) -> Tensor:
+    """Area-weighted unit vertex normals of B meshes with shared topology: verts [B,V,3]; faces [F,3], vf_off [V+1],
+    vf_face [3F] int32 on the device (``contact.face_csr``)."""
+    lib = _lib.load()
+    dev = _require_gpu(verts, faces, vf_off, vf_face)
+    _f32(verts, "verts")
+    for t, n in ((faces, "faces"), (vf_off, "vf_off"), (vf_face, "vf_face")):
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise RuntimeError(f"vertex_normals: {n} must be contiguous int32")
+    if verts.dim() != 3 or verts.shape[2] != 3 or not verts.is_contiguous():
+        raise RuntimeError("vertex_normals: verts must be contiguous [B,V,3]")
+    B, V = verts.shape[0], verts.shape[1]
+    if vf_off.numel() != V + 1 or vf_face.numel() != faces.numel():
+        raise RuntimeError("vertex_normals: CSR does not match the mesh")
+    out = torch.empty_like(verts)
+    with torch.cuda.device(dev):
+        check(lib.dvq_vertex_normals(verts.data_ptr(), B, V, faces.data_ptr(), vf_off.data_ptr(), vf_face.data_ptr(),
+                                     out.data_ptr(), _stream(dev)), "dvq_vertex_normals")
+    return out
+
+
+def interior(normals: Tensor, hand: Tensor, obj: Tensor, nn_idx: Tensor) -> Tensor:
+    """utils_loss.get_interior: bool [B,N], True where the object point lies behind its nearest hand vertex's surface."""
+    lib = _lib.load()
+    dev = _require_gpu(normals, hand, obj, nn_idx)
+    _f32(normals, "normals"), _f32(hand, "hand"), _i64(nn_idx, "nn_idx")
+    po, ob, op, oc = _points(obj, "obj")
+    B, N, V = obj.shape[0], obj.shape[1], hand.shape[1]
+    if not (normals.is_contiguous() and hand.is_contiguous() and nn_idx.is_contiguous()):
+        raise RuntimeError("interior: normals, hand, nn_idx must be contiguous")
+    if tuple(normals.shape) != tuple(hand.shape) or tuple(nn_idx.shape) != (B, N) or hand.shape[0] != B:
+        raise RuntimeError("interior: shape mismatch")
+    out = torch.empty(B, N, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.dvq_interior(normals.data_ptr(), hand.data_ptr(), V, po, ob, op, oc, nn_idx.data_ptr(), B, N,
+                               out.data_ptr(), _stream(dev)), "dvq_interior")
+    return out.bool()

@@ -207,6 +207,22 @@ int dvq_transform_cloud(const float* pc /* [C,N] or [B,C,N] */, int64_t pc_batch
                         const float* t /* [3] */, int64_t B, int C, int N, float* out /* [B,C,N] */,
                         dvq_stream_t stream);
 
+/* ------------------------------------------------------------------ contact / penetration proxies (after the path)
+ * utils/utils_loss.py:7-24 get_NN (pytorch3d knn_points, K=1): nearest target point of every source point of the same
+ * batch element: squared distance d = fma(dz,dz, fma(dy,dy, dx*dx)) and index (first minimum; NaN first).
+ * Strides are in floats, so [B,N,3] tensors and [B,C,N] channel-first clouds are both read in place.  N2 <= 4096. */
+int dvq_nn_points(const float* src, int64_t src_batch_stride, int64_t src_point_stride, int64_t src_coord_stride,
+                  const float* trg, int64_t trg_batch_stride, int64_t trg_point_stride, int64_t trg_coord_stride,
+                  int64_t B, int N1, int N2, float* dist /* [B,N1] */, int64_t* idx /* [B,N1] */, dvq_stream_t stream);
+/* Area-weighted vertex normals (utils/loss.py:156-157: Meshes(...).verts_normals_packed()) of B meshes sharing one
+ * topology: faces [F,3] int32; vf_off [V+1], vf_face [3F]: the faces incident to each vertex, ascending (CSR). */
+int dvq_vertex_normals(const float* verts /* [B,V,3] */, int64_t B, int V, const int32_t* faces, const int32_t* vf_off,
+                       const int32_t* vf_face, float* normals /* [B,V,3] */, dvq_stream_t stream);
+/* utils/utils_loss.py:27-45 get_interior: interior[b,p] = (hand[b,nn[b,p]] - obj[b,p]) . normals[b,nn[b,p]] > 0 */
+int dvq_interior(const float* normals /* [B,V,3] */, const float* hand /* [B,V,3] */, int V, const float* obj,
+                 int64_t obj_batch_stride, int64_t obj_point_stride, int64_t obj_coord_stride,
+                 const int64_t* nn_idx /* [B,N] */, int64_t B, int N, uint8_t* interior /* [B,N] */, dvq_stream_t stream);
+
 /* ------------------------------------------------------------------ optional per-launch timing
  * When enabled, every kernel launch of the library is bracketed by two HIP events on its stream.
  * dvq_prof_read waits for the recorded events and returns per-kernel-kind totals (bench.py's roofline leg). */
