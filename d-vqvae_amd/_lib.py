@@ -116,6 +116,10 @@ def load() -> C.CDLL:
     with _lock:
         if _lib is not None:
             return _lib
+        # PyTorch owns the device memory and streams this library works on, and its wheel bundles its own HIP runtime
+        # (libamdhip64 with the same SONAME as /opt/rocm's).  Whichever copy is loaded first serves the whole process:
+        # load torch's first, or torch would run on the system runtime and see no devices.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP extension has not been built "

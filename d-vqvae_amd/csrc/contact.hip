@@ -113,7 +113,7 @@ extern "C" int dvq_nn_points(const float* src, int64_t src_batch_stride, int64_t
     for (int64_t b0 = 0; b0 < B; b0 += 65535) {                  // gridDim.y limit
         const int64_t nb = B - b0 < 65535 ? B - b0 : 65535;
         DVQ_PROF("nn_points", 8.0 * nb * N1 * N2, (double)nb * (N1 + N2) * 12 + (double)nb * N1 * 12, st);
-        hipLaunchKernelGGL(nn_points_kernel, dim3((N1 + 255) / 256, (unsigned)nb), dim3(256), (size_t)N2 * 12, st,
+        DVQ_LAUNCH(nn_points_kernel, dim3((N1 + 255) / 256, (unsigned)nb), dim3(256), (size_t)N2 * 12, st,
                            src + b0 * src_batch_stride, (long)src_batch_stride, (long)src_point_stride, (long)src_coord_stride,
                            trg + b0 * trg_batch_stride, (long)trg_batch_stride, (long)trg_point_stride, (long)trg_coord_stride,
                            N1, N2, dist + b0 * N1, idx + b0 * N1);
@@ -130,7 +130,7 @@ extern "C" int dvq_vertex_normals(const float* verts, int64_t B, int V, const in
     hipStream_t st = (hipStream_t)stream;
     for (int64_t b0 = 0; b0 < B; b0 += 65535) {
         const int64_t nb = B - b0 < 65535 ? B - b0 : 65535;
-        hipLaunchKernelGGL(vertex_normals_kernel, dim3((V + 127) / 128, (unsigned)nb), dim3(128), 0, st,
+        DVQ_LAUNCH(vertex_normals_kernel, dim3((V + 127) / 128, (unsigned)nb), dim3(128), 0, st,
                            verts + b0 * V * 3, faces, vf_off, vf_face, V, normals + b0 * V * 3);
     }
     DVQ_CHECK_LAUNCH("vertex_normals");
@@ -146,7 +146,7 @@ extern "C" int dvq_interior(const float* normals, const float* hand, int V, cons
     hipStream_t st = (hipStream_t)stream;
     for (int64_t b0 = 0; b0 < B; b0 += 65535) {
         const int64_t nb = B - b0 < 65535 ? B - b0 : 65535;
-        hipLaunchKernelGGL(interior_kernel, dim3((N + 255) / 256, (unsigned)nb), dim3(256), 0, st, normals + b0 * V * 3,
+        DVQ_LAUNCH(interior_kernel, dim3((N + 255) / 256, (unsigned)nb), dim3(256), 0, st, normals + b0 * V * 3,
                            hand + b0 * V * 3, V, obj + b0 * obj_batch_stride, (long)obj_batch_stride, (long)obj_point_stride,
                            (long)obj_coord_stride, nn_idx + b0 * N, N, interior + b0 * N);
     }

@@ -19,6 +19,13 @@ void dvq_set_error(const char* fmt, ...);
         }                                           \
     } while (0)
 
+// Launch with the thread's sticky HIP error cleared first: hipGetLastError() after the launch must report THIS launch,
+// not an unrelated earlier failure of another library in the same thread (e.g. a device probe before the runtime was up).
+#define DVQ_LAUNCH(...)                  \
+    do {                                 \
+        (void)hipGetLastError();         \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
 #define DVQ_CHECK_LAUNCH(what)                                                        \
     do {                                                                              \
         hipError_t e__ = hipGetLastError();                                           \

@@ -361,7 +361,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(const GemmParam
         __syncthreads();                                   // the DMA of this tile has landed for every wave (vmcnt(0) + barrier);
                                                            // everybody is done reading the other stage
         const bool more = cur.valid();
-        if (more) cur.issue(p, m0, n0, wave, lane, smem_c + (stage ^ 1) * D_STAGE);
+        if (more) {
+            if (p.dbg_abl == 5) { cur.k_left -= BK; if (cur.k_left <= 0) cur.open(p, cur.s + 1, m0, n0, wave, lane); }   // diag: no DMA
+            else cur.issue(p, m0, n0, wave, lane, smem_c + (stage ^ 1) * D_STAGE);
+        }
         const char* st = smem_c + stage * D_STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -370,14 +373,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(const GemmParam
             for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    w[jn][pl] = *reinterpret_cast<const bf16x8*>(st + w_off[jn] + pl * D_WPL_BYTES + 16 * ((2 * ks + h) ^ w_sw[jn]));
+                    w[jn][pl] = *reinterpret_cast<const bf16x8*>(st + w_off[jn] + (p.dbg_abl == 3 ? 0 : pl * D_WPL_BYTES + 16 * ((2 * ks + h) ^ w_sw[jn])));
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int c0 = 4 * ks + 2 * h;
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(st + a_off[i] + 16 * (c0 ^ a_sw[i]));
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(st + a_off[i] + 16 * ((c0 + 1) ^ a_sw[i]));
                 bf16x8 a[3];
-                split_frag(lo, hi, a);
+                if (p.dbg_abl == 4) {                       // diag: no split arithmetic
+                    a[0] = __builtin_bit_cast(bf16x8, lo); a[1] = __builtin_bit_cast(bf16x8, hi); a[2] = a[0];
+                } else split_frag(lo, hi, a);
 #pragma unroll
                 for (int jn = 0; jn < 2; ++jn) {
                     f32x16 c = acc[i][jn];
@@ -441,7 +446,7 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
     }
     {
         DVQ_PROF(names[EPI], 2.0 * (double)p.M * p.N * ksum, ((double)p.M + p.N) * ksum * 4, stream);
-        hipLaunchKernelGGL((gemm_bf16x3_dma_kernel<EPI>), dim3((unsigned)grid), dim3(256), D_SMEM, stream, q);
+        DVQ_LAUNCH((gemm_bf16x3_dma_kernel<EPI>), dim3((unsigned)grid), dim3(256), D_SMEM, stream, q);
     }
     if (q.dbg_clk) {
         unsigned long long hbuf[4];
@@ -488,7 +493,7 @@ int launch(const GemmParams& p, hipStream_t stream) {
     for (int s = 0; s < p.nsrc; ++s) ksum += p.src[s].K;
     {
         DVQ_PROF(names[EPI], 2.0 * (double)p.M * p.N * ksum, ((double)p.M + p.N) * ksum * 4, stream);
-        hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI, WPLANES>), dim3((unsigned)grid), dim3(256), SMEM_BYTES, stream, p);
+        DVQ_LAUNCH((gemm_bf16x3_kernel<EPI, WPLANES>), dim3((unsigned)grid), dim3(256), SMEM_BYTES, stream, p);
     }
     DVQ_CHECK_LAUNCH("gemm_bf16x3");
     return DVQ_OK;
@@ -531,7 +536,7 @@ int dvq_launch_gemm_bf16x3(const GemmParams& p, GemmEpilogue epi, hipStream_t st
 extern "C" int dvq_split_bf16x3(const float* w, int64_t n, uint16_t* planes, dvq_stream_t stream) {
     DVQ_REQUIRE(n >= 0 && (n == 0 || (w && planes)), "split_bf16x3: null pointer");
     if (n == 0) return DVQ_OK;
-    hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (long)n, planes);
+    DVQ_LAUNCH(split_bf16x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (long)n, planes);
     DVQ_CHECK_LAUNCH("split_bf16x3");
     return DVQ_OK;
 }

@@ -147,7 +147,7 @@ int launch(const GemmParams& p, hipStream_t stream) {
     for (int s = 0; s < p.nsrc; ++s) ksum += p.src[s].K;
     {
         DVQ_PROF(names[EPI], 2.0 * (double)p.M * p.N * ksum, ((double)p.M + p.N) * ksum * 4, stream);
-        hipLaunchKernelGGL(gemm_f32_kernel<EPI>, dim3((unsigned)grid), dim3(256), SMEM_BYTES, stream, p);
+        DVQ_LAUNCH(gemm_f32_kernel<EPI>, dim3((unsigned)grid), dim3(256), SMEM_BYTES, stream, p);
     }
     DVQ_CHECK_LAUNCH("gemm_f32");
     return DVQ_OK;

@@ -127,7 +127,7 @@ extern "C" int dvq_mano_forward(const dvq_mano_model* m, const float* betas, int
     if (B == 0) return DVQ_OK;
     {
         DVQ_PROF("mano_lbs", (double)B * 1.17e6, (double)B * (55 + 2334) * 4, (hipStream_t)stream);
-        hipLaunchKernelGGL(mano_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, *m, betas, (long)ldb, pose, (long)ldp,
+        DVQ_LAUNCH(mano_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, *m, betas, (long)ldb, pose, (long)ldp,
                            global_orient, (long)ldg, transl, (long)ldt, (long)B, verts, layout, joints);
     }
     DVQ_CHECK_LAUNCH("mano_forward");

@@ -167,7 +167,7 @@ int dvq_launch_gather_rows(const float* table, const int64_t* idx, long idx_stri
     const long total = M * (D / 4);
     {
         DVQ_PROF("gather_rows", 0, 2.0 * M * D * 4, stream);
-        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, table, idx,
+        DVQ_LAUNCH(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, table, idx,
                            idx_stride, M, K, D, out, ldo, err_flag);
     }
     DVQ_CHECK_LAUNCH("gather_rows");
@@ -179,7 +179,7 @@ int dvq_launch_colmax_reduce(const float* partial, long groups, int tiles_per_gr
     const long total = groups * N;
     {
         DVQ_PROF("colmax_reduce", 0, (double)groups * (tiles_per_group + 1) * N * 4, stream);
-        hipLaunchKernelGGL(colmax_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, partial, groups,
+        DVQ_LAUNCH(colmax_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, partial, groups,
                            tiles_per_group, N, relu, out, ldo);
     }
     DVQ_CHECK_LAUNCH("colmax_reduce");
@@ -198,7 +198,7 @@ extern "C" int dvq_copy_cols(const float* src, int64_t lds, int64_t M, int W, fl
                 "copy_cols: rows not 16-byte aligned");
     if (M == 0) return DVQ_OK;
     const long total = M * (W / 4);
-    hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+    DVQ_LAUNCH(copy_cols_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
                        (long)lds, (long)M, W, out, (long)ldo);
     DVQ_CHECK_LAUNCH("copy_cols");
     return DVQ_OK;
@@ -208,7 +208,7 @@ extern "C" int dvq_assemble61(const float* recon, const float* recon_pos, int64_
     DVQ_REQUIRE(recon && recon_pos && out, "assemble61: null pointer");
     if (B == 0) return DVQ_OK;
     const long total = B * 61;
-    hipLaunchKernelGGL(assemble61_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, recon,
+    DVQ_LAUNCH(assemble61_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, recon,
                        recon_pos, (long)B, out);
     DVQ_CHECK_LAUNCH("assemble61");
     return DVQ_OK;
@@ -220,7 +220,7 @@ extern "C" int dvq_transform_cloud(const float* pc, int64_t pc_batch_stride, con
     DVQ_REQUIRE(C >= 3 && N > 0, "transform_cloud: bad shape C=%d N=%d", C, N);
     if (B == 0) return DVQ_OK;
     const long total = B * N;
-    hipLaunchKernelGGL(transform_cloud_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+    DVQ_LAUNCH(transform_cloud_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        pc, (long)pc_batch_stride, R, t, (long)B, C, N, out);
     DVQ_CHECK_LAUNCH("transform_cloud");
     return DVQ_OK;

@@ -158,7 +158,7 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
     const int dim = w->dim, L = w->n_layers;
     for (int64_t b0 = 0; b0 < B; b0 += pl.chunk) {
         const long Bc = (long)((B - b0 < pl.chunk) ? (B - b0) : pl.chunk);
-        hipLaunchKernelGGL(sanitize_labels_kernel, dim3((unsigned)((Bc + 255) / 256)), dim3(256), 0, st, label + b0, Bc,
+        DVQ_LAUNCH(sanitize_labels_kernel, dim3((unsigned)((Bc + 255) / 256)), dim3(256), 0, st, label + b0, Bc,
                            w->n_classes, pl.lab, err_flag);
         DVQ_CHECK_LAUNCH("sanitize_labels");
         if (forced)   // teacher forcing: level-0 activations of all nine positions are known up front
@@ -191,7 +191,7 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
                     float* pre = pl.HV(l, c);
                     if (ns == 0) {
                         const long tot = Bc * dim;
-                        hipLaunchKernelGGL(bias_gate_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, ly.bv,
+                        DVQ_LAUNCH(bias_gate_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, ly.bv,
                                            ly.cls, pl.lab, Bc, dim, out, pre);
                         DVQ_CHECK_LAUNCH("bias_gate");
                         continue;
@@ -263,7 +263,7 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
                 DVQ_PROPAGATE(dvq_launch_gemm(h2, EPI_BIAS, st));
                 {
                 DVQ_PROF("pixelcnn_draw", 0, (double)Bc * (2.0 * w->n_in + dim) * 4, st);
-                hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((Bc + 3) / 4)), dim3(256), 0, st, pl.lg,
+                DVQ_LAUNCH(sample_kernel, dim3((unsigned)((Bc + 3) / 4)), dim3(256), 0, st, pl.lg,
                                    noise ? noise + b0 * NPOS * w->n_in : nullptr, pos, w->n_in, Bc,
                                    forced ? forced + b0 * NPOS : nullptr, codes ? codes + b0 * NPOS : nullptr, w->tok_emb, dim,
                                    pl.XV(0, pos), logits_out ? logits_out + b0 * NPOS * w->n_in : nullptr, err_flag);

@@ -101,7 +101,7 @@ int trunk(const float* pc, int C, int N, long Bc, const float* trans, const floa
     const long threads = rows * 16;
     {
         DVQ_PROF("pn_layer1", 2.0 * rows * 64 * 4, (double)rows * (16 + 256), st);
-        hipLaunchKernelGGL(pn_layer1_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, pc, C, N, s.Npad, Bc,
+        DVQ_LAUNCH(pn_layer1_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, pc, C, N, s.Npad, Bc,
                            trans, w1, b1, s.h1);
     }
     DVQ_CHECK_LAUNCH("pn_layer1");
@@ -374,9 +374,9 @@ int dvq_launch_pn_trunk(const float* pc, int C, int N, long B, const float* tran
     {
         DVQ_PROF("pn_trunk", 2.0 * pts * (4.0 * 64 + 64.0 * 128 + 128.0 * 1024), pts * 16 + (double)grid * 4096, st);
         if (C == 3)
-            hipLaunchKernelGGL(pn_trunk_kernel<3>, dim3((unsigned)grid), dim3(256), T_LDS, st, pc, trans, N, tiles, W1, b1, W2p, b2, W3p, b3, partial);
+            DVQ_LAUNCH(pn_trunk_kernel<3>, dim3((unsigned)grid), dim3(256), T_LDS, st, pc, trans, N, tiles, W1, b1, W2p, b2, W3p, b3, partial);
         else
-            hipLaunchKernelGGL(pn_trunk_kernel<4>, dim3((unsigned)grid), dim3(256), T_LDS, st, pc, trans, N, tiles, W1, b1, W2p, b2, W3p, b3, partial);
+            DVQ_LAUNCH(pn_trunk_kernel<4>, dim3((unsigned)grid), dim3(256), T_LDS, st, pc, trans, N, tiles, W1, b1, W2p, b2, W3p, b3, partial);
     }
     DVQ_CHECK_LAUNCH("pn_trunk");
     return DVQ_OK;

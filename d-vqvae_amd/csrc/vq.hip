@@ -80,9 +80,9 @@ extern "C" int dvq_vq_argmin(const float* z, int64_t ldz, const float* E, int64_
     }
     hipStream_t st = (hipStream_t)stream;
     DVQ_PROF("vq_argmin_total", 2.0 * M * K * D, (double)M * D * 4 + (double)K * D * 4 + (double)M * 8, st);
-    hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, z, (long)ldz, (long)M, D, s.zz);
+    DVQ_LAUNCH(rownorm_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, z, (long)ldz, (long)M, D, s.zz);
     DVQ_CHECK_LAUNCH("rownorm(z)");
-    hipLaunchKernelGGL(rownorm_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, E, (long)D, (long)K, D, s.ee);
+    DVQ_LAUNCH(rownorm_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, E, (long)D, (long)K, D, s.ee);
     DVQ_CHECK_LAUNCH("rownorm(E)");
     GemmParams p = {};
     p.src[0] = GemmSrc{E, z, (long)D, (long)ldz, D, 0};
@@ -95,7 +95,7 @@ extern "C" int dvq_vq_argmin(const float* z, int64_t ldz, const float* E, int64_
     p.part_val = s.pv;
     p.part_idx = s.pi;
     DVQ_PROPAGATE(dvq_launch_gemm(p, EPI_ARGMIN, st));
-    hipLaunchKernelGGL(argmin_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, s.pv, s.pi, s.tiles, (long)M,
+    DVQ_LAUNCH(argmin_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, s.pv, s.pi, s.tiles, (long)M,
                        idx, dmin);
     DVQ_CHECK_LAUNCH("argmin_finish");
     return DVQ_OK;

@@ -687,12 +687,12 @@ extern "C" int dvq_vq_pack(const float* E, int Kq, int Dq, void* packed, size_t 
     DVQ_REQUIRE(packed_bytes >= PK_BYTES, "vq_pack: buffer %zu < %zu bytes", packed_bytes, PK_BYTES);
     hipStream_t st = (hipStream_t)stream;
     char* pk = (char*)packed;
-    hipLaunchKernelGGL(vq_pack_norm_kernel, dim3(1), dim3(K), 0, st, E, (float*)(pk + PK_OFF_EE), (PackHeader*)pk);
+    DVQ_LAUNCH(vq_pack_norm_kernel, dim3(1), dim3(K), 0, st, E, (float*)(pk + PK_OFF_EE), (PackHeader*)pk);
     DVQ_CHECK_LAUNCH("vq_pack_norm");
-    hipLaunchKernelGGL(vq_pack_img_kernel, dim3((K * D + 255) / 256), dim3(256), 0, st, E, (const PackHeader*)pk,
+    DVQ_LAUNCH(vq_pack_img_kernel, dim3((K * D + 255) / 256), dim3(256), 0, st, E, (const PackHeader*)pk,
                        (_Float16*)(pk + PK_OFF_IMG));
     DVQ_CHECK_LAUNCH("vq_pack_img");
-    hipLaunchKernelGGL(vq_pack_err_kernel, dim3(1), dim3(K), 0, st, E, (const _Float16*)(pk + PK_OFF_IMG), (PackHeader*)pk);
+    DVQ_LAUNCH(vq_pack_err_kernel, dim3(1), dim3(K), 0, st, E, (const _Float16*)(pk + PK_OFF_IMG), (PackHeader*)pk);
     DVQ_CHECK_LAUNCH("vq_pack_err");
     return DVQ_OK;
 }
@@ -729,7 +729,7 @@ extern "C" int dvq_vq_argmin_fast(const float* z, const float* E, const void* pa
     }
     const char* pk = (const char*)packed;
     DVQ_PROF("vq_argmin_fast", 2.0 * M * K * D, (double)M * D * 4 + (double)K * D * 2 + (double)M * 8, st);
-    hipLaunchKernelGGL(vq_filter_kernel, dim3((unsigned)s.n_wg), dim3(256), LDS_BYTES, st, z, E, (long)M, pk, idx,
+    DVQ_LAUNCH(vq_filter_kernel, dim3((unsigned)s.n_wg), dim3(256), LDS_BYTES, st, z, E, (long)M, pk, idx,
                        slow_rows, getenv("DVQ_VQ_DBG") ? (unsigned long long*)s.dbg : nullptr);
     DVQ_CHECK_LAUNCH("vq_filter");
     return DVQ_OK;
