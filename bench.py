@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--vq-iters", type=int, default=20)
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernel launches with HIP events")
     ap.add_argument("--vq-only", action="store_true", help="only the VQ argmin microbench (BASELINE config 2)")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL on GPUs)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="every rank on cuda:0 with gloo: exercises the N > 1 path on a one-GPU box (numbers meaningless)")
     return ap.parse_args()
 
 
@@ -221,7 +224,7 @@ def main():
     from dvqvae_amd import _lib, dist, mano as dmano, ops, synth
     from dvqvae_amd.network.gen_net import GenNet
 
-    rank, local_rank, world = dist.init()
+    rank, local_rank, world = dist.init(args.backend, args.share_gpu)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)

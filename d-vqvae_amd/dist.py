@@ -16,13 +16,17 @@ def env_world() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
+def init(backend: Optional[str] = None, share_gpu: bool = False) -> Tuple[int, int, int]:
+    """``share_gpu``: every rank drives cuda:0 (plumbing tests of the N > 1 path on a one-GPU box; needs "gloo",
+    RCCL refuses two ranks on one device).  Returns (rank, local_rank or 0, world)."""
     rank, local_rank, world = env_world()
+    if share_gpu:
+        local_rank = 0
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = "nccl" if torch.cuda.is_available() and not share_gpu else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -42,6 +46,8 @@ def all_gather_rows(local: torch.Tensor, total_rows: Optional[int] = None) -> to
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     local = local.contiguous()
+    if local.is_cuda and dist.get_backend() == "gloo":       # gloo gathers host tensors only (one-GPU plumbing tests)
+        return all_gather_rows(local.cpu(), total_rows).to(local.device)
     if total_rows is None or total_rows % world == 0:
         out = torch.empty((local.shape[0] * world,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local)
