@@ -308,6 +308,31 @@ def test_gen_batched_equals_loop():
         assert torch.equal(rb, r[b:b + 1]) and torch.equal(pb, p[b:b + 1])
 
 
+def test_gen_full_size_properties():
+    """BASELINE's bench size (65 536 grasps, N = 1024) through size-independent properties: the batch is a 2 048-grasp
+    block tiled 32 times, so every tile must reproduce the block's result bit for bit (rows are independent and the
+    accumulation order does not depend on the M tiling), the block computed alone must give the same bits, a loop of
+    B = 1 reference-style calls too, and the whole call is repeatable."""
+    net, _ = _gennet()
+    blk, reps, N = 2048, 32, 1024
+    obj = gpu(synth.synthetic_clouds(blk, N, seed=91))
+    q = gpu(synth.exp1_noise(blk, 9, 512, seed=92))
+    big_obj, big_q = obj.repeat(reps, 1, 1), q.repeat(reps, 1, 1)
+    r, p, aux = net.gen(big_obj, noise=big_q, return_aux=True)
+    assert tuple(r.shape) == (blk * reps, 55) and tuple(p.shape) == (blk * reps, 6)
+    assert bool(torch.isfinite(r).all()) and bool(torch.isfinite(p).all())
+    r0, p0, aux0 = net.gen(obj, noise=q, return_aux=True)
+    rt, pt = r.view(reps, blk, 55), p.view(reps, blk, 6)
+    assert torch.equal(rt, r0.expand(reps, blk, 55)) and torch.equal(pt, p0.expand(reps, blk, 6))
+    assert torch.equal(aux["codes"].view(reps, blk, -1), aux0["codes"].view(1, blk, -1).expand(reps, blk, -1))
+    for b in (0, 1, 777, 2047):
+        rb, pb = net.gen(obj[b:b + 1], noise=q[b:b + 1])
+        assert torch.equal(rb, r0[b:b + 1]) and torch.equal(pb, p0[b:b + 1])
+    r2, p2 = net.gen(big_obj, noise=big_q)
+    assert torch.equal(r2, r) and torch.equal(p2, p)
+    assert int(aux["codes"].min()) >= 0 and int(aux["codes"].max()) < 128
+
+
 def test_gen_raises_when_prior_exceeds_codebook():
     from dvqvae_amd.network.gen_net import GenNet
     net = GenNet()
