@@ -15,6 +15,7 @@
 // The accumulation order is still independent of the M tiling (batched == loop, bitwise).
 #include "dvq_internal.h"
 #include "gemm_common.h"
+#include <vector>
 
 namespace {
 
@@ -291,6 +292,7 @@ struct DmaCursor {
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
+                if (p.dbg_abl == 6) { w_ptr[pl][g] += BK; continue; }          // diag: no weight pieces
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[pl][g],
                                                  (__attribute__((address_space(3))) void*)(stage + D_A_BYTES + pl * D_WPL_BYTES +
                                                                                           (32 * wave + 16 * g) * 64), 16, 0, 0);
@@ -343,6 +345,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(const GemmParam
         p.dbg_clk[0] = __builtin_amdgcn_s_memtime();
         p.dbg_clk[1] = __builtin_amdgcn_s_memrealtime();
     }
+    if (p.dbg_clk && tid == 0) p.dbg_clk[8 + 4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     DmaCursor cur;
     cur.open(p, 0, m0, n0, wave, lane);
     cur.issue(p, m0, n0, wave, lane, smem_c);
@@ -412,11 +415,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(const GemmParam
         p.dbg_clk[2] = __builtin_amdgcn_s_memtime();
         p.dbg_clk[3] = __builtin_amdgcn_s_memrealtime();
     }
+    if (p.dbg_clk && tid == 0) p.dbg_clk[8 + 4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
     if constexpr (SWAP) {
         gemm_epilogue_t<EPI>(p, acc, m0, n0, nt, tid);
     } else {
         __syncthreads();
         gemm_epilogue<EPI>(p, acc, m0, n0, mt, nt, tid, reinterpret_cast<float*>(smem_c));
+    }
+    if (p.dbg_clk) {
+        __syncthreads();
+        if (tid == 0) p.dbg_clk[8 + 4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -441,7 +449,7 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
     static unsigned long long* clk_buf = nullptr;
     GemmParams q = p;
     if (getenv("DVQ_GEMM_CLK")) {
-        if (!clk_buf) (void)hipMalloc(&clk_buf, 64);
+        if (!clk_buf) (void)hipMalloc(&clk_buf, 64 + 32 * 65536);
         q.dbg_clk = clk_buf;
     }
     {
@@ -455,6 +463,19 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
         const double cyc = (double)(hbuf[2] - hbuf[0]), ref = (double)(hbuf[3] - hbuf[1]);
         fprintf(stderr, "[dvq clk] block 0 main loop: %.0f memtime ticks, %.0f x 10 ns -> memtime ticks at %.1f MHz, span %.1f us\n", cyc, ref,
                 ref > 0 ? cyc / ref * 100.0 : 0.0, ref * 0.01);
+        if (grid <= 65536) {                                 // per-block phases (10 ns ticks relative to the first start)
+            std::vector<unsigned long long> hb((size_t)grid * 4);
+            (void)hipMemcpy(hb.data(), clk_buf + 8, (size_t)grid * 32, hipMemcpyDeviceToHost);
+            unsigned long long t0 = ~0ull, tend = 0;
+            for (long b = 0; b < grid; ++b) { if (hb[4 * b] < t0) t0 = hb[4 * b]; if (hb[4 * b + 2] > tend) tend = hb[4 * b + 2]; }
+            double lo = 0, ep = 0, st_second = 0; long n2 = 0;
+            for (long b = 0; b < grid; ++b) {
+                lo += (double)(hb[4 * b + 1] - hb[4 * b]); ep += (double)(hb[4 * b + 2] - hb[4 * b + 1]);
+                if (b >= 512) { st_second += (double)(hb[4 * b] - t0); ++n2; }
+            }
+            fprintf(stderr, "[dvq clk] %ld blocks: mean loop %.1f us, mean epilogue %.1f us, first start..last end %.1f us, mean start of blocks >= 512: %.1f us\n",
+                    grid, lo / grid * 0.01, ep / grid * 0.01, (double)(tend - t0) * 0.01, n2 ? st_second / n2 * 0.01 : 0.0);
+        }
     }
     DVQ_CHECK_LAUNCH("gemm_bf16x3_dma");
     return DVQ_OK;

@@ -40,7 +40,11 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int K = 512, D = 256;
-constexpr int WG_ROWS = 128;                       // 4 waves x 32 rows
+constexpr int NW = 4;                              // waves per workgroup; two workgroups per CU (NW = 8, one workgroup per CU with
+                                                   // half the DMA issues per wave, measured slower: 19.6 vs 14.3 us chunk loop --
+                                                   // eight waves stall together at every chunk barrier, two workgroups of four do not)
+constexpr int NT = 64 * NW;                        // threads
+constexpr int WG_ROWS = 32 * NW;                   // a wave owns 32 rows
 constexpr int KS = D / 16;                         // 16 MFMA k-steps
 constexpr int NCHUNK = K / 64;                     // 8 chunks of 64 entries
 constexpr int EXP_LIMIT = 40;                      // |log2(max magnitude)| beyond this -> exact fallback
@@ -48,18 +52,20 @@ constexpr int EXP_LIMIT = 40;                      // |log2(max magnitude)| beyo
 constexpr int CHUNK_B = 64 * D * 2;                // 32 768 B: 64 entries x 256 fp16
 constexpr int OFF_EE = 2 * CHUNK_B;                // [K] fp32
 constexpr int OFF_CNT = OFF_EE + K * 4;            // [4] ints (per-wave ambiguous counts)
-constexpr int LDS_BYTES = OFF_CNT + 64;            // 67 648 B -> two workgroups per CU
+constexpr int Z_STAGE_B = NW * 16 * 1024;          // row staging of the prologue: 16 rows per wave per round
+constexpr int LDS_BYTES = (OFF_CNT + 64 > Z_STAGE_B) ? OFF_CNT + 64 : Z_STAGE_B;
 // refine tail: regions inside the (then free) codebook stages
-constexpr int RF_ROW = 0;                          // [768] u16 local row of a pair
-constexpr int RF_K = 2048;                         // [768] u16 entry of a pair
-constexpr int RF_D = 4096;                         // [768] f32 canonical distance of a pair
-constexpr int RF_OVER = 8192;                      // [128] u16 rows that need all K entries
-constexpr int RF_RED = 9216;                       // [256] f32 + [256] int block reduction
-constexpr int RF_AP = 11264;                       // [512] f32 second-level (plain fp32) distances of one row
-constexpr int RF_OBASE = 13312;                    // [128] u16 first pair of a second-level row
-constexpr int RF_OCNT = 13568;                     // [128] u16 its pair count
-constexpr int RF_OEPS = 13824;                     // [128] f32 its eps2
-constexpr int RF_PAIRS = 768;                      // pair list capacity (128 rows x 6)
+constexpr int RF_PAIRS = WG_ROWS * 6;              // pair list capacity
+constexpr int RF_ROW = 0;                          // [RF_PAIRS] u16 local row of a pair
+constexpr int RF_K = RF_ROW + RF_PAIRS * 2;        // [RF_PAIRS] u16 entry of a pair
+constexpr int RF_D = RF_K + RF_PAIRS * 2;          // [RF_PAIRS] f32 canonical distance of a pair
+constexpr int RF_OVER = RF_D + RF_PAIRS * 4;       // [WG_ROWS] u16 rows that need more than their candidate list
+constexpr int RF_RED = RF_OVER + WG_ROWS * 2;      // [NT] f32 + [NT] int block reduction
+constexpr int RF_AP = RF_RED + NT * 8;             // [K] f32 second-level (plain fp32) distances of one row
+constexpr int RF_OBASE = RF_AP + K * 4;            // [WG_ROWS] u16 first pair of a second-level row
+constexpr int RF_OCNT = RF_OBASE + WG_ROWS * 2;    // [WG_ROWS] u16 its pair count
+constexpr int RF_OEPS = RF_OCNT + WG_ROWS * 2;     // [WG_ROWS] f32 its eps2
+static_assert(RF_OEPS + WG_ROWS * 4 <= OFF_EE, "refine regions must fit in the codebook stages");
 
 struct PackHeader {
     float emax;        // upper bound of max_k |e_k|_2 (inf if the codebook is not finite)
@@ -142,19 +148,20 @@ __global__ void vq_pack_err_kernel(const float* __restrict__ E, const _Float16* 
 // 16-byte chunks, chunk c of row r lands at chunk c ^ (r & 15)
 // per-lane byte offsets of the 8 DMA pieces a wave issues per chunk (constant across chunks: the chunk moves the
 // uniform base, so an issue is one instruction, no vector address arithmetic)
-__device__ __forceinline__ void chunk_offsets(unsigned (&voff)[8], int wave, int lane) {
+constexpr int PPW = 32 / NW;                       // DMA pieces (1 KiB = two image rows) per wave per chunk
+__device__ __forceinline__ void chunk_offsets(unsigned (&voff)[PPW], int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = 2 * (wave * 8 + i) + (lane >> 5);
+    for (int i = 0; i < PPW; ++i) {
+        const int row = 2 * (wave * PPW + i) + (lane >> 5);
         voff[i] = (unsigned)(row * (D * 2) + 16 * ((lane & 31) ^ (row & 15)));
     }
 }
 
-__device__ __forceinline__ void issue_chunk(const char* __restrict__ img_chunk, const unsigned (&voff)[8], char* stage, int wave) {
+__device__ __forceinline__ void issue_chunk(const char* __restrict__ img_chunk, const unsigned (&voff)[PPW], char* stage, int wave) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < PPW; ++i)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img_chunk + voff[i]),
-                                         (__attribute__((address_space(3))) void*)(stage + (wave * 8 + i) * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(stage + (wave * PPW + i) * 1024), 16, 0, 0);
 }
 
 __device__ __forceinline__ f16x8 efrag(const char* stage, int row, int chunk) {
@@ -289,14 +296,13 @@ __device__ __forceinline__ void chain_pair(const float* __restrict__ zr, const f
     dot = b;
 }
 
-__global__ __launch_bounds__(256, 2) void vq_filter_kernel(const float* __restrict__ z, const float* __restrict__ E, long M,
+__global__ __launch_bounds__(NT, 8 / NW) void vq_filter_kernel(const float* __restrict__ z, const float* __restrict__ E, long M,
                                                            const char* __restrict__ packed, int64_t* __restrict__ idx,
                                                            unsigned long long* __restrict__ slow_rows,
                                                            unsigned long long* __restrict__ dbg) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     float* ee_s = reinterpret_cast<float*>(lds + OFF_EE);
-    if (threadIdx.x < 2) reinterpret_cast<int*>(lds + OFF_CNT)[threadIdx.x] = 0;   // refine counters (first use is barriers away)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -319,16 +325,16 @@ __global__ __launch_bounds__(256, 2) void vq_filter_kernel(const float* __restri
         // rows [64 half, 64 half + 64) of the workgroup tile: 16 DMAs per wave; LDS chunk `lane` <- source chunk lane ^ (row & 15)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int lrow = wave * 16 + i;                       // 0..63 inside this half
-            long gr = (long)blockIdx.x * WG_ROWS + 64 * half + lrow;
+            const int lrow = wave * 16 + i;                       // inside this half
+            long gr = (long)blockIdx.x * WG_ROWS + (WG_ROWS / 2) * half + lrow;
             if (gr >= M) gr = M - 1;
             const float* src = z + gr * D + 4 * (lane ^ (lrow & 15));
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(lds + lrow * 1024), 16, 0, 0);
         }
         __syncthreads();                                          // landed for every wave
-        if ((wave >> 1) == half) {
-            const int lrow = (wave & 1) * 32 + r;
+        if (wave / (NW / 2) == half) {
+            const int lrow = (wave % (NW / 2)) * 32 + r;
             const float* zrow = reinterpret_cast<const float*>(lds + lrow * 1024);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -339,8 +345,8 @@ __global__ __launch_bounds__(256, 2) void vq_filter_kernel(const float* __restri
         }
         __syncthreads();                                          // consumed: the area may be overwritten
     }
-    ee_s[tid] = ee_g[tid];
-    ee_s[tid + 256] = ee_g[tid + 256];
+    for (int i = tid; i < K; i += NT) ee_s[i] = ee_g[i];
+    if (tid < 2) reinterpret_cast<int*>(lds + OFF_CNT)[tid] = 0;   // refine counters (the row staging is over; first use is barriers away)
     float mx = 0.f, ss = 0.f;
 #pragma unroll
     for (int s = 0; s < KS; ++s)
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void vq_filter_kernel(const float* __restri
 
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
     // ---- stream the codebook: chunk c in stage c & 1; scores of chunk c are absorbed while chunk c+1 multiplies
-    unsigned voff[8];
+    unsigned voff[PPW];
     chunk_offsets(voff, wave, lane);
     const char* img_b = reinterpret_cast<const char*>(img);
     issue_chunk(img_b, voff, lds, wave);
@@ -481,7 +487,7 @@ __global__ __launch_bounds__(256, 2) void vq_filter_kernel(const float* __restri
     float* s_d = reinterpret_cast<float*>(lds + RF_D);
     uint16_t* s_over = reinterpret_cast<uint16_t*>(lds + RF_OVER);
     float* s_v = reinterpret_cast<float*>(lds + RF_RED);
-    int* s_i = reinterpret_cast<int*>(lds + RF_RED + 1024);
+    int* s_i = reinterpret_cast<int*>(lds + RF_RED + NT * 4);
     float* s_ap = reinterpret_cast<float*>(lds + RF_AP);
     uint16_t* s_obase = reinterpret_cast<uint16_t*>(lds + RF_OBASE);
     uint16_t* s_ocnt = reinterpret_cast<uint16_t*>(lds + RF_OCNT);
@@ -526,14 +532,14 @@ __global__ __launch_bounds__(256, 2) void vq_filter_kernel(const float* __restri
         const float zz_a = wave_sum(z4[0] * z4[0] + z4[1] * z4[1] + z4[2] * z4[2] + z4[3] * z4[3]);
         f32x4 nx[16];                                             // next batch: 16 coalesced row loads always in flight behind the math
 #pragma unroll
-        for (int u = 0; u < 16; ++u) nx[u] = *reinterpret_cast<const f32x4*>(E + (long)(4 * u + wave) * D + 4 * lane);
-        for (int i0 = 0; i0 < K / 4; i0 += 16) {
+        for (int u = 0; u < 16; ++u) nx[u] = *reinterpret_cast<const f32x4*>(E + (long)(NW * u + wave) * D + 4 * lane);
+        for (int i0 = 0; i0 < K / NW; i0 += 16) {
             f32x4 e4[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) e4[u] = nx[u];
-            if (i0 + 16 < K / 4) {
+            if (i0 + 16 < K / NW) {
 #pragma unroll
-                for (int u = 0; u < 16; ++u) nx[u] = *reinterpret_cast<const f32x4*>(E + (long)(4 * (i0 + 16 + u) + wave) * D + 4 * lane);
+                for (int u = 0; u < 16; ++u) nx[u] = *reinterpret_cast<const f32x4*>(E + (long)(NW * (i0 + 16 + u) + wave) * D + 4 * lane);
             }
             float pd[16];
 #pragma unroll
@@ -555,21 +561,26 @@ __global__ __launch_bounds__(256, 2) void vq_filter_kernel(const float* __restri
             tot += __shfl_xor(tot, 1);
             if ((lane & 3) == 0) {
                 const int u = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-                const int kk = 4 * (i0 + u) + wave;
+                const int kk = NW * (i0 + u) + wave;
                 s_ap[kk] = (zz_a + ee_s[kk]) - 2.0f * tot;
             }
         }
         __syncthreads();
-        float mn = fminf(s_ap[tid], s_ap[tid + 256]);
+        float mn = INFINITY;
+#pragma unroll
+        for (int u = 0; u < K / NT; ++u) mn = fminf(mn, s_ap[tid + NT * u]);
 #pragma unroll
         for (int w = 32; w > 0; w >>= 1) mn = fminf(mn, __shfl_xor(mn, w));
         if (lane == 0) s_v[wave] = mn;
         const int base_o = s_tot[0];
         __syncthreads();
-        const float thr2 = fminf(fminf(s_v[0], s_v[1]), fminf(s_v[2], s_v[3])) + s_oeps[o];
+        float mn_all = s_v[0];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int kk = tid + 256 * u;
+        for (int w = 1; w < NW; ++w) mn_all = fminf(mn_all, s_v[w]);
+        const float thr2 = mn_all + s_oeps[o];
+#pragma unroll
+        for (int u = 0; u < K / NT; ++u) {
+            const int kk = tid + NT * u;
             if (s_ap[kk] <= thr2) {
                 const int pos = atomicAdd(&s_tot[0], 1);
                 if (pos < RF_PAIRS) { s_row[pos] = (uint16_t)ov; s_k[pos] = (uint16_t)kk; }
@@ -589,7 +600,7 @@ __global__ __launch_bounds__(256, 2) void vq_filter_kernel(const float* __restri
         __syncthreads();
     }
     const int total = s_tot[0];
-    for (int s0 = 0; s0 < total; s0 += 64) {
+    for (int s0 = 0; s0 < total; s0 += NT / 4) {
         if (s0 + wave * 16 < total) {                             // wave-uniform: this wave has at least one pair
             const int slot = s0 + (tid >> 2), q = tid & 3;
             const bool act = slot < total;
@@ -632,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void vq_filter_kernel(const float* __restri
         const float* zr = z + gr * D;
         float bv = INFINITY;
         int bi = 0x7fffffff;
-        for (int kk = tid; kk < K; kk += 256) {
+        for (int kk = tid; kk < K; kk += NT) {
             float zz2, dot2;
             chain_pair(zr, E + (long)kk * D, zz2, dot2);
             const float t = zz2 + ee_s[kk];
@@ -642,7 +653,7 @@ __global__ __launch_bounds__(256, 2) void vq_filter_kernel(const float* __restri
         s_v[tid] = bv;
         s_i[tid] = bi;
         __syncthreads();
-        for (int w = 128; w > 0; w >>= 1) {
+        for (int w = NT / 2; w > 0; w >>= 1) {
             if (tid < w && dvq_argmin_better(s_v[tid + w], s_i[tid + w], s_v[tid], s_i[tid])) {
                 s_v[tid] = s_v[tid + w];
                 s_i[tid] = s_i[tid + w];
@@ -729,7 +740,7 @@ extern "C" int dvq_vq_argmin_fast(const float* z, const float* E, const void* pa
     }
     const char* pk = (const char*)packed;
     DVQ_PROF("vq_argmin_fast", 2.0 * M * K * D, (double)M * D * 4 + (double)K * D * 2 + (double)M * 8, st);
-    DVQ_LAUNCH(vq_filter_kernel, dim3((unsigned)s.n_wg), dim3(256), LDS_BYTES, st, z, E, (long)M, pk, idx,
+    DVQ_LAUNCH(vq_filter_kernel, dim3((unsigned)s.n_wg), dim3(NT), LDS_BYTES, st, z, E, (long)M, pk, idx,
                        slow_rows, getenv("DVQ_VQ_DBG") ? (unsigned long long*)s.dbg : nullptr);
     DVQ_CHECK_LAUNCH("vq_filter");
     return DVQ_OK;

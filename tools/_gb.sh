@@ -1,1 +1,1 @@
-for a in 0 3 4 5; do DVQ_GEMM_ABL=$a python tools/_gemm_bench.py 2>&1 | tail -1; done
+for a in 0 6 4 5; do DVQ_GEMM_ABL=$a timeout 100 python tools/_gemm_clk.py 2>&1 | grep "blocks:" | tail -1; done
