@@ -1,3 +1,5 @@
+"""Diagnostic (GPU box): per-workgroup phase durations of the VQ fast kernel from its DVQ_VQ_DBG stamps (100 MHz
+s_memrealtime): start spread, rows -> registers, chunk loop, epilogue + refine, pair / slow-row counts."""
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dvqvae_amd
