@@ -65,7 +65,8 @@ constexpr int RF_AP = RF_RED + NT * 8;             // [K] f32 second-level (plai
 constexpr int RF_OBASE = RF_AP + K * 4;            // [WG_ROWS] u16 first pair of a second-level row
 constexpr int RF_OCNT = RF_OBASE + WG_ROWS * 2;    // [WG_ROWS] u16 its pair count
 constexpr int RF_OEPS = RF_OCNT + WG_ROWS * 2;     // [WG_ROWS] f32 its eps2
-static_assert(RF_OEPS + WG_ROWS * 4 <= OFF_EE, "refine regions must fit in the codebook stages");
+constexpr int RF_OKEEP = RF_OEPS + WG_ROWS * 4;    // [WG_ROWS][4] u16 its candidates from the lane half whose list is complete
+static_assert(RF_OKEEP + WG_ROWS * 8 <= OFF_EE, "refine regions must fit in the codebook stages");
 
 struct PackHeader {
     float emax;        // upper bound of max_k |e_k|_2 (inf if the codebook is not finite)
@@ -492,6 +493,7 @@ __global__ __launch_bounds__(NT, 8 / NW) void vq_filter_kernel(const float* __re
     uint16_t* s_obase = reinterpret_cast<uint16_t*>(lds + RF_OBASE);
     uint16_t* s_ocnt = reinterpret_cast<uint16_t*>(lds + RF_OCNT);
     float* s_oeps = reinterpret_cast<float*>(lds + RF_OEPS);
+    uint16_t* s_okeep = reinterpret_cast<uint16_t*>(lds + RF_OKEEP);
     __syncthreads();                                              // every wave is done with the stages
     int base = 0;
     if (owner && unique) idx[grow] = (m1 <= thr) ? decode_entry(m1, 0) : decode_entry(p1, 1);
@@ -512,9 +514,19 @@ __global__ __launch_bounds__(NT, 8 / NW) void vq_filter_kernel(const float* __re
         } else {
             // !complete: finite row, more than four scores of one lane within eps -> second-level filter below;
             // c == 0: NaN/Inf or out-of-range magnitudes -> all K entries canonically (bit 15)
+            // bits 13 / 14: which lane half (entry index bit 2) hides more scores than its list holds and must be rescanned;
+            // the other half's (complete) list is kept
             const int o = atomicAdd(&s_tot[1], 1);
-            s_over[o] = (uint16_t)(rl | (complete ? 0x8000 : 0));
+            const bool inc0 = m4 <= thr, inc1 = p4 <= thr;
+            s_over[o] = (uint16_t)(rl | (complete ? 0x8000 : 0) | (inc0 ? 0x2000 : 0) | (inc1 ? 0x4000 : 0));
             s_oeps[o] = 0.00018311f * (zn + emax) * (zn + emax);
+            int nk = 0;
+            auto keep = [&](bool take, int v) {
+                if (take) { s_okeep[4 * o + 1 + nk] = (uint16_t)v; ++nk; }
+            };
+            if (!inc0) { keep(m1 <= thr, decode_entry(m1, 0)); keep(m2 <= thr, decode_entry(m2, 0)); keep(m3 <= thr, decode_entry(m3, 0)); }
+            if (!inc1) { keep(p1 <= thr, decode_entry(p1, 1)); keep(p2 <= thr, decode_entry(p2, 1)); keep(p3 <= thr, decode_entry(p3, 1)); }
+            s_okeep[4 * o] = (uint16_t)nk;
         }
     }
     __syncthreads();
@@ -525,21 +537,26 @@ __global__ __launch_bounds__(NT, 8 / NW) void vq_filter_kernel(const float* __re
     // |approx_k - true_k| <= gamma_260 (|z| + |e_k|)^2, and so does the canonical chain, hence the canonical winner
     // is within 4 gamma_260 (|z| + Emax)^2 < eps2 = (2^-13 + 2^-14) (|z| + Emax)^2 of the approximate minimum.
     for (int o = 0; o < n_over; ++o) {
-        const int ov = s_over[o];
-        if (ov & 0x8000) continue;
+        const int ovf = s_over[o];
+        if (ovf & 0x8000) continue;
+        const int ov = ovf & 0x1fff;
+        const bool both = (ovf & 0x6000) == 0x6000;
+        const int hsel = (ovf & 0x4000) ? 1 : 0;                  // the half to scan when only one is incomplete
+        const int n_scan = both ? K : K / 2;
+        auto entry_of = [&](int e) { return both ? e : 8 * (e >> 2) + 4 * hsel + (e & 3); };
         const long gr = (long)blockIdx.x * WG_ROWS + ov;
         const f32x4 z4 = *reinterpret_cast<const f32x4*>(z + gr * D + 4 * lane);
         const float zz_a = wave_sum(z4[0] * z4[0] + z4[1] * z4[1] + z4[2] * z4[2] + z4[3] * z4[3]);
         f32x4 nx[16];                                             // next batch: 16 coalesced row loads always in flight behind the math
 #pragma unroll
-        for (int u = 0; u < 16; ++u) nx[u] = *reinterpret_cast<const f32x4*>(E + (long)(NW * u + wave) * D + 4 * lane);
-        for (int i0 = 0; i0 < K / NW; i0 += 16) {
+        for (int u = 0; u < 16; ++u) nx[u] = *reinterpret_cast<const f32x4*>(E + (long)entry_of(NW * u + wave) * D + 4 * lane);
+        for (int i0 = 0; i0 < n_scan / NW; i0 += 16) {
             f32x4 e4[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) e4[u] = nx[u];
-            if (i0 + 16 < K / NW) {
+            if (i0 + 16 < n_scan / NW) {
 #pragma unroll
-                for (int u = 0; u < 16; ++u) nx[u] = *reinterpret_cast<const f32x4*>(E + (long)(NW * (i0 + 16 + u) + wave) * D + 4 * lane);
+                for (int u = 0; u < 16; ++u) nx[u] = *reinterpret_cast<const f32x4*>(E + (long)entry_of(NW * (i0 + 16 + u) + wave) * D + 4 * lane);
             }
             float pd[16];
 #pragma unroll
@@ -561,14 +578,15 @@ __global__ __launch_bounds__(NT, 8 / NW) void vq_filter_kernel(const float* __re
             tot += __shfl_xor(tot, 1);
             if ((lane & 3) == 0) {
                 const int u = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-                const int kk = NW * (i0 + u) + wave;
-                s_ap[kk] = (zz_a + ee_s[kk]) - 2.0f * tot;
+                const int e = NW * (i0 + u) + wave;                    // scan index; s_ap is indexed by it
+                s_ap[e] = (zz_a + ee_s[entry_of(e)]) - 2.0f * tot;
             }
         }
         __syncthreads();
         float mn = INFINITY;
 #pragma unroll
-        for (int u = 0; u < K / NT; ++u) mn = fminf(mn, s_ap[tid + NT * u]);
+        for (int u = 0; u < K / NT; ++u)
+            if (tid + NT * u < n_scan) mn = fminf(mn, s_ap[tid + NT * u]);
 #pragma unroll
         for (int w = 32; w > 0; w >>= 1) mn = fminf(mn, __shfl_xor(mn, w));
         if (lane == 0) s_v[wave] = mn;
@@ -580,17 +598,21 @@ __global__ __launch_bounds__(NT, 8 / NW) void vq_filter_kernel(const float* __re
         const float thr2 = mn_all + s_oeps[o];
 #pragma unroll
         for (int u = 0; u < K / NT; ++u) {
-            const int kk = tid + NT * u;
-            if (s_ap[kk] <= thr2) {
+            const int e = tid + NT * u;
+            if (e < n_scan && s_ap[e] <= thr2) {
                 const int pos = atomicAdd(&s_tot[0], 1);
-                if (pos < RF_PAIRS) { s_row[pos] = (uint16_t)ov; s_k[pos] = (uint16_t)kk; }
+                if (pos < RF_PAIRS) { s_row[pos] = (uint16_t)ov; s_k[pos] = (uint16_t)entry_of(e); }
             }
+        }
+        if (!both && tid < s_okeep[4 * o]) {                      // the complete half's own candidates
+            const int pos = atomicAdd(&s_tot[0], 1);
+            if (pos < RF_PAIRS) { s_row[pos] = (uint16_t)ov; s_k[pos] = s_okeep[4 * o + 1 + tid]; }
         }
         __syncthreads();
         if (tid == 0) {
             const int c_o = s_tot[0] - base_o;
             if (c_o < 1 || c_o > 64 || base_o + c_o > RF_PAIRS) {   // (c_o < 1 cannot happen for finite data) -> all K entries
-                s_over[o] = (uint16_t)(ov | 0x8000);
+                s_over[o] = (uint16_t)(ovf | 0x8000);
                 s_tot[0] = base_o;
             } else {
                 s_obase[o] = (uint16_t)base_o;
@@ -633,13 +655,13 @@ __global__ __launch_bounds__(NT, 8 / NW) void vq_filter_kernel(const float* __re
             const int ok2 = s_k[b0 + i];
             if (dvq_argmin_better(od, ok2, d, k)) { d = od; k = ok2; }
         }
-        idx[(long)blockIdx.x * WG_ROWS + s_over[tid]] = k;
+        idx[(long)blockIdx.x * WG_ROWS + (s_over[tid] & 0x1fff)] = k;
     }
     // what is left (NaN/Inf, out-of-range magnitudes, > 64 second-level candidates): all K entries canonically, the whole
     // workgroup per row, one single-lane chain per entry
     for (int o = 0; o < n_over; ++o) {
         if (!(s_over[o] & 0x8000)) continue;
-        const long gr = (long)blockIdx.x * WG_ROWS + (s_over[o] & 0x7fff);
+        const long gr = (long)blockIdx.x * WG_ROWS + (s_over[o] & 0x1fff);
         const float* zr = z + gr * D;
         float bv = INFINITY;
         int bi = 0x7fffffff;
