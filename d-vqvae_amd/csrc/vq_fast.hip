@@ -158,6 +158,11 @@ __device__ __forceinline__ void chunk_offsets(unsigned (&voff)[PPW], int wave, i
     }
 }
 
+__device__ __forceinline__ void issue_piece(const char* __restrict__ img_chunk, unsigned voff, char* stage, int wave, int i) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img_chunk + voff),
+                                     (__attribute__((address_space(3))) void*)(stage + (wave * PPW + i) * 1024), 16, 0, 0);
+}
+
 __device__ __forceinline__ void issue_chunk(const char* __restrict__ img_chunk, const unsigned (&voff)[PPW], char* stage, int wave) {
 #pragma unroll
     for (int i = 0; i < PPW; ++i)
@@ -410,7 +415,6 @@ __global__ __launch_bounds__(NT, 8 / NW) void vq_filter_kernel(const float* __re
     for (int c = 0; c < NCHUNK; ++c) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's DMA pieces of chunk c (the compiler does not see the asm readers)
         __syncthreads();                                          // chunk c landed everywhere; the other stage is free
-        if (c + 1 < NCHUNK) issue_chunk(img_b + (c + 1) * CHUNK_B, voff, lds + ((c + 1) & 1) * CHUNK_B, wave);
         f32x16 (&cur)[2] = (c & 1) ? accB : accA;
         f32x16 (&prev)[2] = (c & 1) ? accA : accB;
         // Issue order per k-step s: [|e|^2 quad of score group s/2+1 (even s)], fragments of step s+PF, wait for step s's
@@ -427,6 +431,9 @@ __global__ __launch_bounds__(NT, 8 / NW) void vq_filter_kernel(const float* __re
         if (c > 0) lds_read16(ev[0], ee_a + 256 * (c - 1));
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
+            // the next chunk's DMA pieces go out one per k-step, in the vector-heavy gaps: issued back to back behind the
+            // barrier (with the burst of first fragment reads) each cost 100-185 issue cycles, here a fraction of that
+            if (c + 1 < NCHUNK && s < PPW) issue_piece(img_b + (c + 1) * CHUNK_B, voff[s], lds + ((c + 1) & 1) * CHUNK_B, wave, s);
             if (c > 0 && (s & 1) == 0 && s / 2 + 1 < KS / 2) {
                 const int g = s / 2 + 1;
                 lds_read16(ev[g], ee_a + 256 * (c - 1) + 128 * (g >> 2) + 32 * (g & 3));
