@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--vq-iters", type=int, default=20)
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernel launches with HIP events")
     ap.add_argument("--vq-only", action="store_true", help="only the VQ argmin microbench (BASELINE config 2)")
+    ap.add_argument("--vq-tie-prone", action="store_true",
+                    help="also time the reference-init codebook U(+-1/K) (SURVEY 8d second run); off by default so that the "
+                         "fast kernel's rocprofv3 average reflects the headline workload only")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl = RCCL on GPUs)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="every rank on cuda:0 with gloo: exercises the N > 1 path on a one-GPU box (numbers meaningless)")
@@ -159,6 +162,8 @@ def vq_microbench(args, lib, _lib, ops, dev, K):
     # SURVEY 8(d) second run: the reference's initial codebook U(+-1/K) against the same O(1) rows -- ill-conditioned
     # (fp32 itself cancels |z|^2 against a 1e-2 spread).  Forced fast kernel vs exact kernel; the VectorQuantizer module
     # watches the kernel's slow-row counter and uses the exact kernel there (tests/test_gpu_parity.py).
+    if not args.vq_tie_prone:
+        return res
     Et = (torch.rand(K, D, device=dev) * 2 - 1) / K
     pt = ops.vq_pack(Et)
     slow = torch.zeros(1, dtype=torch.int64, device=dev)

@@ -18,4 +18,5 @@ BENCH_ARGS="--vq-only" run vq_pmc_fetch --kernel-trace --pmc FETCH_SIZE
 BENCH_ARGS="--vq-only" run vq_pmc_write --kernel-trace --pmc WRITE_SIZE
 BENCH_ARGS="--steps 1 --warmup 1 --no-cpu-baseline" run bench_pmc_fetch --kernel-trace --pmc FETCH_SIZE
 BENCH_ARGS="--steps 1 --warmup 1 --no-cpu-baseline" run bench_pmc_write --kernel-trace --pmc WRITE_SIZE
+timeout 300 python3 bench.py --vq-only --vq-tie-prone > $OUT/vq_tie_prone.json 2> $OUT/vq_tie_prone.log; echo "tie_prone rc=$?"
 find $OUT -name "*.csv" | head -30

@@ -53,6 +53,9 @@ def main():
         j = os.path.join(src, f"{stem}.json")
         if os.path.exists(j) and os.path.getsize(j):
             shutil.copy(j, os.path.join(dst, f"{tag}_{stem}_bench_under_rocprofv3.json"))
+    tp = os.path.join(src, "vq_tie_prone.json")
+    if os.path.exists(tp) and os.path.getsize(tp):
+        shutil.copy(tp, os.path.join(dst, f"{tag}_vq_tie_prone_regime.json"))
     rows = traffic(src, "bench") + [dict(r, scope="vq microbench") for r in traffic(src, "vq")]
     if rows:
         json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only), KB counters "
