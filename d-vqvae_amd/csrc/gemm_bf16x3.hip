@@ -17,6 +17,16 @@
 #include "gemm_common.h"
 #include <vector>
 
+// Diagnostics (per-block phase stamps, loop ablations: tools/gemm_phase_stamps.py) are compiled in only with
+// -DDVQ_GEMM_DIAG (make EXTRA=-DDVQ_GEMM_DIAG): in the shipped build the predicates below are constant false.
+#ifdef DVQ_GEMM_DIAG
+#define DVQ_ABL_IS(p, v) ((p).dbg_abl == (v))
+#define DVQ_CLK(p) ((p).dbg_clk)
+#else
+#define DVQ_ABL_IS(p, v) false
+#define DVQ_CLK(p) ((unsigned long long*)nullptr)
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -292,7 +302,7 @@ struct DmaCursor {
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                if (p.dbg_abl == 6) { w_ptr[pl][g] += BK; continue; }          // diag: no weight pieces
+                if (DVQ_ABL_IS(p, 6)) { w_ptr[pl][g] += BK; continue; }          // diag: no weight pieces
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[pl][g],
                                                  (__attribute__((address_space(3))) void*)(stage + D_A_BYTES + pl * D_WPL_BYTES +
                                                                                           (32 * wave + 16 * g) * 64), 16, 0, 0);
@@ -341,11 +351,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(const GemmParam
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
 
-    if (p.dbg_clk && blockIdx.x == 0 && tid == 0) {
+    if (DVQ_CLK(p) && blockIdx.x == 0 && tid == 0) {
         p.dbg_clk[0] = __builtin_amdgcn_s_memtime();
         p.dbg_clk[1] = __builtin_amdgcn_s_memrealtime();
     }
-    if (p.dbg_clk && tid == 0) p.dbg_clk[8 + 4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    if (DVQ_CLK(p) && tid == 0) p.dbg_clk[8 + 4 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     DmaCursor cur;
     cur.open(p, 0, m0, n0, wave, lane);
     cur.issue(p, m0, n0, wave, lane, smem_c);
@@ -365,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(const GemmParam
                                                            // everybody is done reading the other stage
         const bool more = cur.valid();
         if (more) {
-            if (p.dbg_abl == 5) { cur.k_left -= BK; if (cur.k_left <= 0) cur.open(p, cur.s + 1, m0, n0, wave, lane); }   // diag: no DMA
+            if (DVQ_ABL_IS(p, 5)) { cur.k_left -= BK; if (cur.k_left <= 0) cur.open(p, cur.s + 1, m0, n0, wave, lane); }   // diag: no DMA
             else cur.issue(p, m0, n0, wave, lane, smem_c + (stage ^ 1) * D_STAGE);
         }
         const char* st = smem_c + stage * D_STAGE;
@@ -376,14 +386,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(const GemmParam
             for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    w[jn][pl] = *reinterpret_cast<const bf16x8*>(st + w_off[jn] + (p.dbg_abl == 3 ? 0 : pl * D_WPL_BYTES + 16 * ((2 * ks + h) ^ w_sw[jn])));
+                    w[jn][pl] = *reinterpret_cast<const bf16x8*>(st + w_off[jn] + (DVQ_ABL_IS(p, 3) ? 0 : pl * D_WPL_BYTES + 16 * ((2 * ks + h) ^ w_sw[jn])));
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int c0 = 4 * ks + 2 * h;
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(st + a_off[i] + 16 * (c0 ^ a_sw[i]));
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(st + a_off[i] + 16 * ((c0 + 1) ^ a_sw[i]));
                 bf16x8 a[3];
-                if (p.dbg_abl == 4) {                       // diag: no split arithmetic
+                if (DVQ_ABL_IS(p, 4)) {                       // diag: no split arithmetic
                     a[0] = __builtin_bit_cast(bf16x8, lo); a[1] = __builtin_bit_cast(bf16x8, hi); a[2] = a[0];
                 } else split_frag(lo, hi, a);
 #pragma unroll
@@ -411,18 +421,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(const GemmParam
         if (!more) break;
         stage ^= 1;
     }
-    if (p.dbg_clk && blockIdx.x == 0 && tid == 0) {
+    if (DVQ_CLK(p) && blockIdx.x == 0 && tid == 0) {
         p.dbg_clk[2] = __builtin_amdgcn_s_memtime();
         p.dbg_clk[3] = __builtin_amdgcn_s_memrealtime();
     }
-    if (p.dbg_clk && tid == 0) p.dbg_clk[8 + 4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    if (DVQ_CLK(p) && tid == 0) p.dbg_clk[8 + 4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
     if constexpr (SWAP) {
         gemm_epilogue_t<EPI>(p, acc, m0, n0, nt, tid);
     } else {
         __syncthreads();
         gemm_epilogue<EPI>(p, acc, m0, n0, mt, nt, tid, reinterpret_cast<float*>(smem_c));
     }
-    if (p.dbg_clk) {
+    if (DVQ_CLK(p)) {
         __syncthreads();
         if (tid == 0) p.dbg_clk[8 + 4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
     }
@@ -448,10 +458,12 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
     for (int s = 0; s < p.nsrc; ++s) ksum += p.src[s].K;
     static unsigned long long* clk_buf = nullptr;
     GemmParams q = p;
+#ifdef DVQ_GEMM_DIAG
     if (getenv("DVQ_GEMM_CLK")) {
         if (!clk_buf) (void)hipMalloc(&clk_buf, 64 + 32 * 65536);
         q.dbg_clk = clk_buf;
     }
+#endif
     {
         DVQ_PROF(names[EPI], 2.0 * (double)p.M * p.N * ksum, ((double)p.M + p.N) * ksum * 4, stream);
         DVQ_LAUNCH((gemm_bf16x3_dma_kernel<EPI>), dim3((unsigned)grid), dim3(256), D_SMEM, stream, q);
