@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--points", type=int, default=1024)
     ap.add_argument("--codebook", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-grasps", type=int, default=128, help="bounded CPU-baseline sample (grasps)")
+    ap.add_argument("--cpu-grasps", type=int, default=512, help="bounded CPU-baseline sample (grasps)")
     ap.add_argument("--vq-iters", type=int, default=20)
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernel launches with HIP events")
     ap.add_argument("--vq-only", action="store_true", help="only the VQ argmin microbench (BASELINE config 2)")

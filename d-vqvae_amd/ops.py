@@ -54,12 +54,14 @@ def _stream(dev: torch.device) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
 
 
-_ws: Dict[Tuple[int, str], Tensor] = {}
+_ws: Dict[Tuple[int, int, str], Tensor] = {}
 
 
 def workspace(nbytes: int, dev: torch.device, tag: str = "main") -> Tensor:
-    """Grow-only per-device scratch (stream-ordered reuse on torch's current stream)."""
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), tag)
+    """Grow-only scratch per (device, current stream): reuse is ordered by the stream the ops are enqueued on, so two
+    streams driving the library concurrently never share a buffer."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, int(torch.cuda.current_stream(idx).cuda_stream), tag)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         _ws.pop(key, None)

@@ -473,6 +473,28 @@ def test_quantizer_switches_to_exact_kernel_when_ill_conditioned():
     assert not vq._regime_state["prefer_exact"]
 
 
+def test_ops_on_two_streams_do_not_share_scratch():
+    """Kernels are enqueued on the caller's current stream and the scratch is per (device, stream): two streams running
+    different problems concurrently must both get the single-stream answers."""
+    E = gpu(synth.synthetic_normal((512, 256), 13, "vqstr/E"))
+    za = gpu(synth.synthetic_normal((8192, 256), 13, "vqstr/za"))
+    zb = gpu(synth.synthetic_normal((8192, 256), 13, "vqstr/zb"))
+    pk = ops.vq_pack(E)
+    want_a, want_b = ops.vq_argmin(za, E, fast=False), ops.vq_argmin(zb, E, fast=False)
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    outs_a, outs_b = [], []
+    for _ in range(10):
+        with torch.cuda.stream(sa):
+            outs_a.append(ops.vq_argmin(za, E, fast=False))
+            outs_a.append(ops.vq_argmin(za, E, packed=pk))
+        with torch.cuda.stream(sb):
+            outs_b.append(ops.vq_argmin(zb, E, packed=pk))
+            outs_b.append(ops.vq_argmin(zb, E, fast=False))
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, want_a) for o in outs_a) and all(torch.equal(o, want_b) for o in outs_b)
+
+
 def test_vq_fast_scales_and_tie_prone_codebook():
     for scale_z, scale_e in [(1.0, 1.0 / 512), (100.0, 0.01), (1e-3, 1e3), (30.0, 30.0)]:
         E = synth.synthetic_uniform((512, 256), 10, f"vqs/E/{scale_e}", -scale_e, scale_e)
