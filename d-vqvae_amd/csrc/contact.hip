@@ -100,15 +100,14 @@ extern "C" int dvq_nn_points(const float* src, int64_t src_batch_stride, int64_t
     DVQ_REQUIRE(src && trg && dist && idx, "nn_points: null pointer");
     DVQ_REQUIRE(B <= 65535LL * 65535LL, "nn_points: B too large");
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DvqOncePerDevice attr_once;
+    if (attr_once.first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nn_points_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, NN_MAX_TRG * 12);
         if (e != hipSuccess) {
             dvq_set_error("nn_points: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return DVQ_ELAUNCH;
         }
-        attr_set = true;
     }
     for (int64_t b0 = 0; b0 < B; b0 += 65535) {                  // gridDim.y limit
         const int64_t nb = B - b0 < 65535 ? B - b0 : 65535;

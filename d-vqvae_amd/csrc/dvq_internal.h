@@ -19,6 +19,19 @@ void dvq_set_error(const char* fmt, ...);
         }                                           \
     } while (0)
 
+// Function attributes (dynamic LDS limit) are per device: one process may drive several GPUs.
+struct DvqOncePerDevice {
+    unsigned long long mask[2] = {0, 0};
+    bool first() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        d &= 127;
+        const bool f = !((mask[d >> 6] >> (d & 63)) & 1ull);
+        mask[d >> 6] |= 1ull << (d & 63);
+        return f;
+    }
+};
+
 // Launch with the thread's sticky HIP error cleared first: hipGetLastError() after the launch must report THIS launch,
 // not an unrelated earlier failure of another library in the same thread (e.g. a device probe before the runtime was up).
 #define DVQ_LAUNCH(...)                  \

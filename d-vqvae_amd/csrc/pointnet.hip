@@ -362,11 +362,10 @@ int dvq_launch_pn_trunk(const float* pc, int C, int N, long B, const float* tran
                         const uint16_t* W2p, const float* b2, const uint16_t* W3p, const float* b3, float* partial,
                         hipStream_t st) {
     const int tiles = (N + 127) / 128;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DvqOncePerDevice attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_trunk_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_trunk_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
-        attr_set = true;
     }
     const long grid = B * tiles;
     DVQ_REQUIRE(grid < (1L << 31), "pointnet: grid too large");

@@ -757,15 +757,14 @@ extern "C" int dvq_vq_argmin_fast(const float* z, const float* E, const void* pa
         return DVQ_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DvqOncePerDevice attr_once;
+    if (attr_once.first()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vq_filter_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) {
             dvq_set_error("vq_argmin_fast: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return DVQ_ELAUNCH;
         }
-        attr_set = true;
     }
     const char* pk = (const char*)packed;
     DVQ_PROF("vq_argmin_fast", 2.0 * M * K * D, (double)M * D * 4 + (double)K * D * 2 + (double)M * 8, st);
