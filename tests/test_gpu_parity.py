@@ -473,6 +473,35 @@ def test_quantizer_switches_to_exact_kernel_when_ill_conditioned():
     assert not vq._regime_state["prefer_exact"]
 
 
+def test_vq_fast_fuzz_shapes_scales_and_degenerate_rows():
+    """160 random problems: ragged and large M, global and per-row scales over 12 decades, rows sitting near entries,
+    duplicated entries, sparse rows, offset data (cancellation), NaN / Inf rows -- fast kernel == exact kernel everywhere."""
+    rng = np.random.default_rng(0)
+    torch.manual_seed(1)
+    sizes = [1, 2, 31, 32, 33, 127, 128, 129, 255, 257, 1000, 4097, 30000, 65536, 70001, 200000]
+    for it in range(160):
+        M = int(rng.choice(sizes)) if it % 4 else int(rng.integers(1, 3000))
+        kind = it % 8
+        E = torch.randn(512, 256, device=DEV)
+        z = torch.randn(M, 256, device=DEV)
+        if kind == 1:
+            E, z = E * 10 ** float(rng.uniform(-6, 6)), z * 10 ** float(rng.uniform(-6, 6))
+        elif kind == 2:
+            z = E[torch.randint(0, 512, (M,), device=DEV)] + 10 ** float(rng.uniform(-6, -1)) * z
+        elif kind == 3:
+            E[torch.randint(0, 512, (40,), device=DEV)] = E[0].clone()
+        elif kind == 4:
+            z = z * torch.rand(M, 1, device=DEV) * 100
+        elif kind == 5:
+            z[:, 64:] = 0
+        elif kind == 6:
+            E, z = E + 5.0, z + 5.0
+        elif kind == 7 and M > 10:
+            z[int(rng.integers(0, M))] = float("nan")
+            z[int(rng.integers(0, M)), 3] = float("inf")
+        _fast_vs_exact(z, E, f"fuzz case {it} (M={M}, kind={kind})")
+
+
 def test_ops_on_two_streams_do_not_share_scratch():
     """Kernels are enqueued on the caller's current stream and the scratch is per (device, stream): two streams running
     different problems concurrently must both get the single-stream answers."""
