@@ -35,6 +35,33 @@ def test_linear(M, N, K):
         assert_close(y, ref.float(), atol=2e-5, rtol=1e-5)
 
 
+def test_linear_fuzz_shapes_planes_and_batch_invariance():
+    """60 random (M, N, K): on-the-fly and pre-split weight planes give the same bits, results within fp32-GEMM accuracy of
+    the fp64 product, and every row of a batched call equals the same row computed in a smaller batch (the accumulation
+    order does not depend on the M tiling)."""
+    from dvqvae_amd import packing
+    rng = np.random.default_rng(3)
+    for it in range(60):
+        M = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 300, 1000, 4097]))
+        N = int(rng.choice([1, 3, 6, 31, 32, 33, 55, 127, 128, 129, 256, 384, 1000, 1024]))
+        K = 32 * int(rng.integers(1, 50))
+        x = torch.randn(M, K, device=DEV) * float(10 ** rng.uniform(-2, 2))
+        w = torch.randn(N, K, device=DEV) / np.sqrt(K)
+        b = torch.randn(N, device=DEV) if it % 3 else None
+        relu = bool(it % 2)
+        y = ops.linear(x, w, b, relu=relu)
+        yp = ops.linear(x, w, b, relu=relu, planes=packing.split_bf16x3(w))
+        assert torch.equal(y, yp), f"case {it}: planes path differs"
+        ref = x.double() @ w.double().t() + (b.double() if b is not None else 0)
+        if relu:
+            ref = ref.clamp_min(0)
+        scale = float((x.double().abs() @ w.double().abs().t()).max())
+        assert float((y.double() - ref).abs().max()) <= 4e-6 * scale + 1e-30, f"case {it}: M={M} N={N} K={K}"
+        lo = int(rng.integers(0, M))
+        hi = min(M, lo + int(rng.integers(1, 70)))
+        assert torch.equal(ops.linear(x[lo:hi], w, b, relu=relu), y[lo:hi]), f"case {it}: rows {lo}:{hi} depend on the batch"
+
+
 def test_linear_multi_source_and_strided_views():
     M = 300
     xs = [synth.synthetic_normal((M, k), 2, f"lm/x/{i}") for i, k in enumerate((64, 512, 1024))]
