@@ -188,9 +188,11 @@ def vq_microbench(args, lib, _lib, ops, dev, K):
     return res
 
 
-def cpu_baseline(sd, arrays, n_grasps, points, codebook):
+def cpu_baseline(sd, arrays, n_grasps, points, codebook, net=None, dev=None):
     """The CPU oracle (port of the reference's algorithm, naive 9-forward prior as the reference runs it),
-    batched B=64 -- a STRONGER baseline than the reference's own B=1 loop, which is also timed on 8 grasps."""
+    batched B=64 -- a STRONGER baseline than the reference's own B=1 loop, which is also timed on 8 grasps.
+    With ``net``: the HIP path is run on the same 64 grasps and compared with the oracle (the checker, never the thing
+    measured): code match rates and the largest parameter difference go into the ``parity`` object."""
     import torch
     from dvqvae_amd import synth
     from oracle import dvq_oracle, mano_oracle
@@ -206,8 +208,9 @@ def cpu_baseline(sd, arrays, n_grasps, points, codebook):
         dvq_oracle.gen(cpu_sd, obj[:2], q[:2], mano)                      # warm-up
         t0 = time.perf_counter()
         done = 0
+        o_out = None
         while done < n_grasps and (done == 0 or time.perf_counter() - t0 < 30.0):     # bounded: <= ~30 s
-            dvq_oracle.gen(cpu_sd, obj, q, mano)
+            o_out = dvq_oracle.gen(cpu_sd, obj, q, mano, return_aux=True)
             done += bsz
             log(f"cpu baseline: {done} grasps in {time.perf_counter() - t0:.1f} s")
         dt = time.perf_counter() - t0
@@ -215,10 +218,23 @@ def cpu_baseline(sd, arrays, n_grasps, points, codebook):
         for b in range(8):
             dvq_oracle.gen(cpu_sd, obj[b:b + 1], q[b:b + 1], mano)
         dt1 = time.perf_counter() - t1
+    parity = None
+    if net is not None:
+        with torch.no_grad():
+            recon, pos, aux = net.gen(obj.to(dev), noise=q.to(dev), return_aux=True)
+        o_recon, o_pos, o_aux = o_out
+        idx_ok = (aux["idx6"].cpu() == o_aux["idx6"]).reshape(bsz, -1).all(dim=1)
+        code_ok = (aux["codes"].cpu() == o_aux["codes"]).reshape(bsz, -1).all(dim=1)
+        both = idx_ok & code_ok
+        d = torch.cat([(recon.cpu() - o_recon).abs(), (pos.cpu() - o_pos).abs()], dim=1)
+        parity = {"grasps": bsz, "checker": "oracle/dvq_oracle.py (CPU fp32 port, pinned to the reference's goldens)",
+                  "idx6_match_rate": float(idx_ok.float().mean()), "sampled_codes_match_rate": float(code_ok.float().mean()),
+                  "max_abs_param_diff_on_matched_codes": float(d[both].max()) if bool(both.any()) else None,
+                  "tolerance": 1e-5}
     return {"value": done / dt, "unit": "grasps/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{done} grasps as batches of {bsz} (N={points}, K={codebook}, naive 9-forward prior), {dt:.1f} s; "
                       f"reference-faithful B=1 loop on 8 grasps: {8 / dt1:.2f} grasps/s",
-            "b1_loop_grasps_per_s": 8 / dt1}
+            "b1_loop_grasps_per_s": 8 / dt1}, parity
 
 
 def main():
@@ -320,7 +336,7 @@ def main():
 
         out["roofline_vq_argmin"] = vq_microbench(args, lib, _lib, ops, dev, K)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(sd, arrays, args.cpu_grasps, N, K)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(sd, arrays, args.cpu_grasps, N, K, net, dev)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     dist.barrier()
