@@ -148,7 +148,7 @@ def vq_microbench(args, lib, _lib, ops, dev, K):
            "bit_match_vs_exact_fp32_kernel": float((idx == exact).float().mean()),
            "index_match_rate_vs_torch_gpu_expr": float((idx == ref_idx).float().mean()),
            "workload": "VectorQuantizer K=512 D=256 argmin-only, M=65536; duration = every kernel of one call "
-                       "(bf16-MFMA filter + exact fp32 refine), codebook packed once",
+                       "(one kernel: fp16-MFMA filter + exact fp32 refine in the workgroup), codebook packed once",
            "timing": "one HIP-event pair around a train of back-to-back calls on the launch stream, 6 rotating 64 MiB inputs",
            "kernels_us": {k: v["ms"] / v["count"] * 1e3 for k, v in pk.items()}}
     # the exact fp32-MFMA kernel, for comparison

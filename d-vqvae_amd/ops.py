@@ -128,7 +128,7 @@ def vq_fast_supported(K: int, D: int) -> bool:
 
 
 def vq_pack(E: Tensor) -> Tensor:
-    """Packed image of a codebook for the fast path (bf16 MFMA fragments of -2E, canonical |e_k|^2, max |e_k|).
+    """Packed image of a codebook for the fast path (fp16 image of -2 sE E, canonical |e_k|^2, max |e_k|, measured rounding error).
     Build it once per codebook state and pass it to ``vq_argmin(..., packed=)``; it is NOT cached here because a
     raw pointer cannot tell a recycled allocation from the same codebook."""
     lib = _lib.load()
@@ -148,7 +148,7 @@ def vq_pack(E: Tensor) -> Tensor:
 def vq_argmin(z: Tensor, E: Tensor, return_dist: bool = False, fast: Optional[bool] = None,
               packed: Optional[Tensor] = None, slow_rows: Optional[Tensor] = None):
     """idx[m] = argmin_k (|z_m|^2 + |E_k|^2) - 2 z_m.E_k in the canonical fp32 order -> int64 [M].
-    K=512/D=256 on dense rows takes the filter+refine kernels (same indices, bit for bit); everything else
+    K=512/D=256 on dense rows takes the fast kernel (fp16-MFMA filter + exact refine in one launch; same indices, bit for bit); everything else
     (and ``return_dist``) the exact fp32-MFMA kernel.  ``fast`` forces the choice; ``packed`` = vq_pack(E) skips the
     per-call codebook packing (three tiny kernels); ``slow_rows`` (int64 [1] on the device, accumulated, never reset)
     counts the rows the fast kernel could not decide from their candidate lists (see dvq.h)."""
