@@ -35,6 +35,9 @@
 // Algorithmic HBM bytes per row: D*4 (z) + 8 (int64 index); the codebook (K*D*4) is read once.
 #include "dvq_internal.h"
 
+#ifndef DVQ_PF
+#define DVQ_PF 2      // fragment prefetch depth of the chunk loop in k-steps (2, 3, 4, 6 measured: no difference)
+#endif
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -193,27 +196,28 @@ __device__ __forceinline__ void lds_read16(f32x4& d, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(addr));
 }
 // wait until at most n younger LDS reads are outstanding; the operands pin the consumers below the wait
+#define DVQ_LGKM_CASE(N, ...) case N: asm volatile("s_waitcnt lgkmcnt(" #N ")" : __VA_ARGS__); break;
 template <class A, class B>
 __device__ __forceinline__ void lds_wait(int n, A& a, B& b) {   // (never pass one object twice: the copy would be made before the wait)
     switch (n) {
-        case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); break;
-        case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a), "+v"(b)); break;
-        case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(b)); break;
-        case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a), "+v"(b)); break;
-        default: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a), "+v"(b)); break;
+        DVQ_LGKM_CASE(0, "+v"(a), "+v"(b)) DVQ_LGKM_CASE(1, "+v"(a), "+v"(b)) DVQ_LGKM_CASE(2, "+v"(a), "+v"(b))
+        DVQ_LGKM_CASE(3, "+v"(a), "+v"(b)) DVQ_LGKM_CASE(4, "+v"(a), "+v"(b)) DVQ_LGKM_CASE(5, "+v"(a), "+v"(b))
+        DVQ_LGKM_CASE(6, "+v"(a), "+v"(b)) DVQ_LGKM_CASE(7, "+v"(a), "+v"(b)) DVQ_LGKM_CASE(8, "+v"(a), "+v"(b))
+        DVQ_LGKM_CASE(9, "+v"(a), "+v"(b)) DVQ_LGKM_CASE(10, "+v"(a), "+v"(b)) DVQ_LGKM_CASE(11, "+v"(a), "+v"(b))
+        DVQ_LGKM_CASE(12, "+v"(a), "+v"(b)) DVQ_LGKM_CASE(13, "+v"(a), "+v"(b)) DVQ_LGKM_CASE(14, "+v"(a), "+v"(b))
+        default: asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(a), "+v"(b)); break;
     }
 }
+// wait until at most n younger LDS reads are outstanding; the operands pin the consumers below the wait
 template <class A, class B, class C>
 __device__ __forceinline__ void lds_wait(int n, A& a, B& b, C& c) {
     switch (n) {
-        case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c)); break;
-        case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a), "+v"(b), "+v"(c)); break;
-        case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(b), "+v"(c)); break;
-        case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a), "+v"(b), "+v"(c)); break;
-        case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a), "+v"(b), "+v"(c)); break;
-        case 5: asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a), "+v"(b), "+v"(c)); break;
-        case 6: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a), "+v"(b), "+v"(c)); break;
-        default: asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(a), "+v"(b), "+v"(c)); break;
+        DVQ_LGKM_CASE(0, "+v"(a), "+v"(b), "+v"(c)) DVQ_LGKM_CASE(1, "+v"(a), "+v"(b), "+v"(c)) DVQ_LGKM_CASE(2, "+v"(a), "+v"(b), "+v"(c))
+        DVQ_LGKM_CASE(3, "+v"(a), "+v"(b), "+v"(c)) DVQ_LGKM_CASE(4, "+v"(a), "+v"(b), "+v"(c)) DVQ_LGKM_CASE(5, "+v"(a), "+v"(b), "+v"(c))
+        DVQ_LGKM_CASE(6, "+v"(a), "+v"(b), "+v"(c)) DVQ_LGKM_CASE(7, "+v"(a), "+v"(b), "+v"(c)) DVQ_LGKM_CASE(8, "+v"(a), "+v"(b), "+v"(c))
+        DVQ_LGKM_CASE(9, "+v"(a), "+v"(b), "+v"(c)) DVQ_LGKM_CASE(10, "+v"(a), "+v"(b), "+v"(c)) DVQ_LGKM_CASE(11, "+v"(a), "+v"(b), "+v"(c))
+        DVQ_LGKM_CASE(12, "+v"(a), "+v"(b), "+v"(c)) DVQ_LGKM_CASE(13, "+v"(a), "+v"(b), "+v"(c)) DVQ_LGKM_CASE(14, "+v"(a), "+v"(b), "+v"(c))
+        default: asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(a), "+v"(b), "+v"(c)); break;
     }
 }
 
@@ -224,6 +228,22 @@ __device__ __forceinline__ void top4(float s, float& m1, float& m2, float& m3, f
     m3 = __builtin_amdgcn_fmed3f(m2, m3, s);
     m2 = __builtin_amdgcn_fmed3f(m1, m2, s);
     m1 = __builtin_amdgcn_fmed3f(m1, s, -3.0e38f);
+}
+
+// Number of hand-issued LDS reads younger than the last one k-step s waits for, from the chunk loop's issue order:
+//   prologue: fragments of steps 0 .. PF-1 (two reads each), then (c > 0) the |e|^2 quads of score groups 0 .. QF-1;
+//   step t:   (c > 0, t even, t/2 + QF < KS/2) quad of group t/2 + QF; (t + PF < KS) the two fragments of step t + PF; wait(t).
+// wait(s) needs both fragments of step s and (c > 0) the quad of group s/2.
+constexpr int lds_younger(int s, bool quads, int PF, int QF, int KSn) {
+    int pos = 0, need = -1, frag_pos = -1, quad_pos = -1;
+    for (int t = 0; t < PF; ++t) { pos += 2; if (t == s) frag_pos = pos; }
+    if (quads) for (int g = 0; g < QF; ++g) { pos += 1; if (g == s / 2) quad_pos = pos; }
+    for (int t = 0; t <= s; ++t) {
+        if (quads && (t & 1) == 0 && t / 2 + QF < KSn / 2) { pos += 1; if (t / 2 + QF == s / 2) quad_pos = pos; }
+        if (t + PF < KSn) { pos += 2; if (t + PF == s) frag_pos = pos; }
+    }
+    need = frag_pos > quad_pos ? frag_pos : quad_pos;
+    return pos - need;
 }
 
 // one score s = acc / (sz sE) + ee, its 8-bit entry id replacing the low mantissa byte, top-4 update.  The id comes
@@ -421,32 +441,31 @@ __global__ __launch_bounds__(NT, 8 / NW) void vq_filter_kernel(const float* __re
         // fragments (and the quad its scores need, which is older), two MFMAs, two scores of the previous chunk.
         f16x8 ef[KS][2];
         f32x4 ev[KS / 2];
-        constexpr int PF = 2;
+        constexpr int PF = DVQ_PF, QF = 2;                     // fragments PF k-steps ahead, quads QF score groups ahead
         const int soff = (c & 1) * CHUNK_B;
 #pragma unroll
         for (int s = 0; s < PF; ++s) {
             lds_read16(ef[s][0], fa[s], soff);
             lds_read16(ef[s][1], fa[s], soff + 16384);
         }
-        if (c > 0) lds_read16(ev[0], ee_a + 256 * (c - 1));
+        if (c > 0) {
+#pragma unroll
+            for (int g = 0; g < QF; ++g) lds_read16(ev[g], ee_a + 256 * (c - 1) + 128 * (g >> 2) + 32 * (g & 3));
+        }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             // the next chunk's DMA pieces go out one per k-step, in the vector-heavy gaps: issued back to back behind the
             // barrier (with the burst of first fragment reads) each cost 100-185 issue cycles, here a fraction of that
             if (c + 1 < NCHUNK && s < PPW) issue_piece(img_b + (c + 1) * CHUNK_B, voff[s], lds + ((c + 1) & 1) * CHUNK_B, wave, s);
-            if (c > 0 && (s & 1) == 0 && s / 2 + 1 < KS / 2) {
-                const int g = s / 2 + 1;
+            if (c > 0 && (s & 1) == 0 && s / 2 + QF < KS / 2) {
+                const int g = s / 2 + QF;
                 lds_read16(ev[g], ee_a + 256 * (c - 1) + 128 * (g >> 2) + 32 * (g & 3));
             }
             if (s + PF < KS) {
                 lds_read16(ef[s + PF][0], fa[s + PF], soff);
                 lds_read16(ef[s + PF][1], fa[s + PF], soff + 16384);
             }
-            // reads younger than the last one step s needs (its own fragments; at s = 0 the quad read behind the prologue)
-            const bool quad_prev = c > 0 && s >= 1 && ((s - 1) & 1) == 0 && (s - 1) / 2 + 1 < KS / 2;
-            const bool quad_this = c > 0 && (s & 1) == 0 && s / 2 + 1 < KS / 2;
-            const int younger = s == 0 ? (c > 0 ? 3 : 4)
-                                       : (s + 1 < KS ? 2 : 0) + (s + 2 < KS ? 2 : 0) + (quad_prev ? 1 : 0) + (quad_this ? 1 : 0);
+            const int younger = lds_younger(s, c > 0, PF, QF, KS);
             if (c > 0) lds_wait(younger, ef[s][0], ef[s][1], ev[s / 2]);
             else lds_wait(younger, ef[s][0], ef[s][1]);
             cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ef[s][0], zh[s], s == 0 ? zero16 : cur[0], 0, 0, 0);
