@@ -8,9 +8,12 @@ from ._base import PackedModule
 _TRUNK = ((64, None), (128, 64), (1024, 128))          # (out, in) of conv1..3; conv1's in = channel
 
 
-def _add_trunk(mod: nn.Module, channel: int, n_bn: int):
+def _add_convs(mod: nn.Module, channel: int):
     for i, (o, n) in enumerate(_TRUNK, 1):
         setattr(mod, f"conv{i}", nn.Conv1d(channel if n is None else n, o, 1))
+
+
+def _add_bns(mod: nn.Module, n_bn: int):
     for i, width in enumerate((64, 128, 1024, 512, 256)[:n_bn], 1):
         setattr(mod, f"bn{i}", nn.BatchNorm1d(width))
 
@@ -20,9 +23,10 @@ class STN3d(nn.Module):
 
     def __init__(self, channel):
         super().__init__()
-        _add_trunk(self, channel, 5)
+        _add_convs(self, channel)                         # registration order = the reference's (state_dict key order)
         self.fc1, self.fc2, self.fc3 = nn.Linear(1024, 512), nn.Linear(512, 256), nn.Linear(256, 9)
         self.relu = nn.ReLU()
+        _add_bns(self, 5)
 
 
 class PointNetEncoder(PackedModule):
@@ -32,7 +36,8 @@ class PointNetEncoder(PackedModule):
             raise NotImplementedError("the grasp path uses global_feat=True, feature_transform=False "
                                       "(every call site: gen_net.py:17-18,30, DVQVAE.py:18-20,35)")
         self.stn = STN3d(channel)
-        _add_trunk(self, channel, 3)
+        _add_convs(self, channel)
+        _add_bns(self, 3)
         self.global_feat, self.feature_transform = global_feat, feature_transform
 
     def _pack(self):

@@ -53,6 +53,24 @@ def test_state_dict_layout_matches_survey_appendix_b():
     assert "emb_3.linear_log_var.weight" in dsd and "fing_5.stn.fc3.bias" in dsd and "GatedPixelCNN.embedding.weight" not in dsd
 
 
+def test_state_dict_layout_equals_the_reference_key_for_key():
+    """tests/golden/g0_state_dict_layout.json was dumped from the imported reference (tools/make_golden.py layout):
+    every key, shape and dtype of the modules a checkpoint is loaded into must be identical, in the same order."""
+    import json
+    import os
+    from dvqvae_amd.network.DVQVAE import DVQVAE
+    from dvqvae_amd.network.VQVAE import VQVAE
+    from dvqvae_amd.network.gen_net import GenNet
+    from dvqvae_amd.network.pixelcnn.models import GatedPixelCNN
+    from dvqvae_amd.network.pointnet_encoder import PointNetEncoder
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g0_state_dict_layout.json")))
+    mods = {"GenNet": GenNet(), "DVQVAE": DVQVAE(obj_inchannel=4), "GatedPixelCNN": GatedPixelCNN(512, 512, 15, 128),
+            "PointNetEncoder4": PointNetEncoder(channel=4), "VQVAE": VQVAE(0, 0, 0, 128, 256, 0.25)}
+    for name, mod in mods.items():
+        mine = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in mod.state_dict().items()]
+        assert mine == ref[name], f"{name}: state_dict layout differs from the reference"
+
+
 def test_shard_range_covers_everything_once():
     for total in (0, 1, 7, 64, 65537):
         for world in (1, 2, 3, 8):

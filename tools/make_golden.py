@@ -307,8 +307,25 @@ def g8_dvqvae():
     save("g8_dvqvae", emb_idx=emb_idx.squeeze(1), obj_emb=obj_emb)
 
 
+def g0_state_dict_layout():
+    """Every state_dict key with its shape and dtype, for the modules a checkpoint is loaded into (data, not source)."""
+    import json
+    out = {}
+    for name, mod in (("GenNet", RefGenNet()), ("DVQVAE", ref_dvq.DVQVAE(obj_inchannel=4)),
+                      ("GatedPixelCNN", RefPixelCNN(512, 512, 15, 128)), ("PointNetEncoder4", RefPointNet(channel=4)),
+                      ("VQVAE", RefVQVAE(0, 0, 0, 128, 256, 0.25))):
+        out[name] = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in mod.state_dict().items()]
+    with open(os.path.join(ROOT, "tests", "golden", "g0_state_dict_layout.json"), "w") as f:
+        json.dump(out, f)
+    print("g0_state_dict_layout", {k: len(v) for k, v in out.items()})
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "layout":
+        g0_state_dict_layout()
+        return
     check_multinomial_equivalence()
+    g0_state_dict_layout()
     sampler = RaceSampler()
     torch.Tensor.multinomial = lambda self, n, *a, **k: sampler(self, n, *a, **k)   # (6)
     g1_pointnet()
