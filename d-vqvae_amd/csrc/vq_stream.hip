@@ -1,0 +1,708 @@
+// Fast VQ nearest-codebook-entry for the headline shape (K = 512, D = 256): same indices as the exact kernel
+// (vq.hip / oracle/vq_canonical.c), bit for bit, with z streamed from HBM exactly once UNDER the matrix work.
+// Reference: VectorQuantizer.forward(z, istrain=False), network/vqvae/quantizer.py:46-49.
+//
+// Structure (persistent, codebook in registers, z through LDS):
+//   * one 512-thread workgroup per CU walks over up to 8 tiles of 32 rows (tile = blockIdx + j * gridDim);
+//   * wave w keeps codebook entries [64w, 64w+64) -- fp16 of -2 sE e_k, all 256 dims -- as the MFMA A operand in
+//     128 VGPRs for the whole kernel (8 waves x 64 entries = the whole codebook, 256 KB of the CU's 512 KB of VGPRs);
+//   * a tile's 32 fp32 rows arrive HBM -> LDS by global_load_lds (whole 1 KiB rows, 3-deep ring = 96 KB, each wave owns
+//     4 rows so only its own vmcnt orders the hand-off), are converted to fp16 ONCE (each wave its 4 rows: |z|^2, the
+//     measured rounding error |z - h(z)|, eps_row) and written to a padded fp16 tile (528-byte rows: conflict-free
+//     ds_read_b128 fragments with one address register and immediate offsets);
+//   * every wave multiplies the tile with its 64 entries: 16 fragment reads feed 32 v_mfma_f32_32x32x16_f16, the
+//     accumulators START at sE |e_k|^2 (read from LDS straight into the accumulator registers), so they END as the
+//     scores sE (|e_k|^2 - 2 z.e_k): no per-score arithmetic beyond id packing and a lane-local top-2 (3 VALU per score);
+//   * the two waves of a SIMD (w, w+4) run half a tile apart -- one in its matrix phase while the other scores /
+//     converts / merges -- separated by s_barrier (the matrix pipe and the vector issue of a SIMD are shared);
+//   * per tile, 16 (wave, lane-half) slots per row hold (min, second) packed scores; the merge finds the row minimum,
+//     the slots within eps_row of it, and either decides the row or appends (row, entry) pairs to a list;
+//   * after the last tile: the canonical fp32 evaluation d_k = (zz + ee_k) - 2 dot_k (k-ordered fmaf chains, four lanes
+//     per chain) of the listed pairs, ds_min_u64 of (ordered distance bits, entry) per row = torch.argmin's order
+//     (first minimum, NaN first).  Rows with NaN/Inf, fp16 overflow or an overflowing list: all K entries canonically.
+//
+// Error bound (filter keeps the exact winner).  No per-row scaling: h(.) = round to fp16 with subnormals flushed (MODE
+// register: the conversion instruction flushes, so what the matrix core sees is what the error was measured on).
+// With dz_j = z_j - h(z_j), de_kj = e_kj - h(-2 sE e_kj)/(-2 sE) (exact in fp32), products h.h exact in the MFMA's fp32:
+//   |S_k/sE - (true_k - |z|^2)| <= 2 (|dz||e_k| + |z||de_k| + |dz||de_k|) + gamma'_259 (|e_k|^2 + 2|z||e_k|)    (filter)
+//   |d_k - true_k|              <= gamma_260 (|z| + |e_k|)^2                                                   (exact side)
+//   |packed(S_k) - S_k|         <= 2^-18 |S_k|                                                  (5-bit id in the mantissa)
+// hence packed(S_k*) <= min_k packed(S_k) + sE eps_row with
+//   eps_row = 4 (|dz| Emax + |z| dEmax + |dz| dEmax) + (2^-13 + 2^-14) (|z| + Emax)^2,
+// |dz| measured by the kernel's own conversion, dEmax by dvq_vq_pack, norms rounded up.  A slot whose SECOND score is
+// within eps may hide a third: all 32 entries of that slot are listed, so the list always contains the exact winner.
+// Algorithmic HBM bytes per row: D*4 (z) + 8 (int64 index); the codebook (K*D*4) is read once.
+#include "dvq_internal.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int K = 512, D = 256;
+constexpr int NWV = 8;                             // waves per workgroup = 64-entry slices of the codebook
+constexpr int NT = 64 * NWV;                       // 512 threads, one workgroup per CU
+constexpr int TILE = 32;                           // rows per tile
+constexpr int MAX_TILES = 8;                       // tiles per workgroup per launch (row-result table, slow list)
+constexpr int RING = 3;                            // fp32 staging ring depth (tiles)
+constexpr int EXP_LIMIT = 40;                      // |log2(max codebook magnitude)| beyond this -> exact fallback
+
+constexpr int Z16_ROW = 528;                       // padded fp16 row: 512 B + 16 B (shifts consecutive rows by one bank group)
+constexpr int Z16_BUF = TILE * Z16_ROW;            // 16 896
+constexpr int MS_ROW = 136;                        // merge slots of a row: 16 x 8 B + 8 B pad
+constexpr int MS_BUF = TILE * MS_ROW;              // 4 352
+constexpr int PAIR_CAP = 2048;
+
+constexpr int L_RING = 0;                                  // RING x 32 KB fp32 tiles
+constexpr int L_Z16 = L_RING + RING * TILE * D * 4;        // 2 x fp16 tile
+constexpr int L_MS = L_Z16 + 2 * Z16_BUF;                  // 2 x merge slots
+constexpr int L_RS = L_MS + 2 * MS_BUF;                    // 4 x [32] {eps sE, flag}
+constexpr int L_EES = L_RS + 4 * TILE * 8;                 // [K] f32: sE |e_k|^2 (accumulator start values)
+constexpr int L_RES = L_EES + K * 4;                       // [MAX_TILES*32] u64 row results (ordered distance bits : entry)
+constexpr int L_PAIR = L_RES + MAX_TILES * TILE * 8;       // [PAIR_CAP] u32 (rowslot << 16 | entry)
+constexpr int L_SLOW = L_PAIR + PAIR_CAP * 4;              // [MAX_TILES*32] u16 rowslots for the all-entries path
+constexpr int L_CNT = L_SLOW + MAX_TILES * TILE * 2;       // [0] pairs, [1] slow rows
+constexpr int L_DBG = L_CNT + 64;                          // [8 waves][32] u32 phase stamps (DVQ_VQ_DBG only)
+constexpr int LDS_BYTES = L_DBG + NWV * 32 * 4;
+constexpr int DBG_WG_BYTES = 64 + NWV * 32 * 4;            // per-workgroup debug record in the workspace
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+
+struct PackHeader {
+    float emax;        // upper bound of max_k |e_k|_2 (inf if the codebook is not finite)
+    int sexp;          // codebook scale sE = 2^sexp
+    int valid;         // 0: codebook magnitudes outside the filter's range -> every row takes the exact path
+    int K, D;
+    float demax;       // upper bound of max_k |e_k - image_k / (-2 sE)|_2: the image's MEASURED fp16 rounding error
+    int layout;        // 3: image in MFMA-fragment order (below)
+};
+constexpr size_t PK_OFF_EE = 256;                          // [K] f32 canonical |e_k|^2
+constexpr size_t PK_OFF_IMG = PK_OFF_EE + (size_t)K * 4;   // fp16 image, fragment order
+constexpr size_t PK_BYTES = PK_OFF_IMG + (size_t)K * D * 2;
+
+__device__ __forceinline__ float pow2f(int e) { return __int_as_float((e + 127) << 23); }   // e in [-126, 127]
+
+// image position (in fp16 elements) of dim j of entry k: fragment f = ((w*2 + jn)*16 + s), lane = 32 h + r, element e
+//   k = 64 w + 32 jn + r,  j = 16 s + 8 h + e      (lane l of wave w loads 16 B at f*1024 + 16 l: coalesced)
+__host__ __device__ __forceinline__ int img_pos(int k, int j) {
+    const int w = k >> 6, jn = (k >> 5) & 1, r = k & 31, s = j >> 4, h = (j >> 3) & 1, e = j & 7;
+    return ((((w * 2 + jn) * 16 + s) * 64 + (h * 32 + r)) << 3) + e;
+}
+
+// ------------------------------------------------------------------------------------------------ pack
+__global__ void vq_pack_norm_kernel(const float* __restrict__ E, float* __restrict__ ee, PackHeader* hdr) {
+    __shared__ float red[K];
+    __shared__ float redm[K];
+    const int k = threadIdx.x;                                   // blockDim = K
+    const float* p = E + k * D;
+    float acc = 0.f, mx = 0.f;
+    bool finite = true;
+    for (int j = 0; j < D; ++j) {
+        acc = fmaf(p[j], p[j], acc);                             // canonical chain (same as rownorm_kernel)
+        finite = finite && (fabsf(p[j]) <= 3.0e38f);
+        mx = fmaxf(mx, fabsf(p[j]));
+    }
+    ee[k] = acc;
+    red[k] = (finite && acc <= 3.0e38f) ? acc : INFINITY;
+    redm[k] = finite ? mx : INFINITY;
+    __syncthreads();
+    for (int o = K / 2; o > 0; o >>= 1) {
+        if (k < o) {
+            red[k] = fmaxf(red[k], red[k + o]);
+            redm[k] = fmaxf(redm[k], redm[k + o]);
+        }
+        __syncthreads();
+    }
+    if (k == 0) {
+        hdr->emax = sqrtf(red[0]) * 1.00001f;
+        const float m2 = 2.0f * redm[0];                         // the image holds -2 e
+        const int e = (int)((__float_as_uint(m2) >> 23) & 0xff) - 127;
+        const bool ok = redm[0] > 0.f && e >= -EXP_LIMIT && e <= EXP_LIMIT && red[0] <= 3.0e38f;
+        hdr->sexp = ok ? 13 - e : 0;
+        hdr->valid = ok ? 1 : 0;
+        hdr->K = K;
+        hdr->D = D;
+        hdr->layout = 3;
+    }
+}
+
+// image: fp16 of -2 sE e in fragment order; subnormal results are stored as zero (the matrix core may flush them)
+__global__ void vq_pack_img_kernel(const float* __restrict__ E, const PackHeader* __restrict__ hdr, _Float16* __restrict__ img) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= K * D) return;
+    _Float16 hv = (_Float16)(-2.0f * pow2f(hdr->sexp) * E[gid]);
+    if (fabsf((float)hv) < 6.103515625e-05f) hv = (_Float16)0.f;
+    img[img_pos(gid / D, gid % D)] = hv;
+}
+
+// measured rounding error of the image, per entry, as a 2-norm in codebook units; its maximum goes into the header
+__global__ void vq_pack_err_kernel(const float* __restrict__ E, const _Float16* __restrict__ img, PackHeader* hdr) {
+    __shared__ float red[K];
+    const int k = threadIdx.x;                                   // blockDim = K
+    const float m2s = -2.0f * pow2f(hdr->sexp);
+    float acc = 0.f;
+    for (int j = 0; j < D; ++j) {
+        const float sv = m2s * E[k * D + j];                     // exact (power-of-two scale, range checked by `valid`)
+        const float d = sv - (float)img[img_pos(k, j)];          // exact: fp32 values at most 11 significant bits apart (or sv itself)
+        acc = fmaf(d, d, acc);
+    }
+    red[k] = acc;
+    __syncthreads();
+    for (int o = K / 2; o > 0; o >>= 1) {
+        if (k < o) red[k] = fmaxf(red[k], red[k + o]);
+        __syncthreads();
+    }
+    if (k == 0) hdr->demax = hdr->valid ? sqrtf(red[0]) / fabsf(m2s) * 1.0001f : INFINITY;
+}
+
+// ------------------------------------------------------------------------------------------------ LDS access by hand
+// Every LDS access between the first LDS-DMA issue and the end of the tile loop is inline asm: the compiler cannot tell
+// which LDS bytes a pending global_load_lds will write and would put s_waitcnt vmcnt(0) in front of each access it sees,
+// which serialises the HBM stream with the compute.  Waits are by count; the "+v" operands pin the consumers below them.
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)p;
+}
+template <int OFF, class V>
+__device__ __forceinline__ void ds_rd128(V& d, unsigned a) {
+    static_assert(sizeof(V) == 16, "16-byte destination");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF));
+}
+template <int OFF, class V>
+__device__ __forceinline__ void ds_rd64(V& d, unsigned a) {
+    static_assert(sizeof(V) == 8, "8-byte destination");
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(a), "n"(OFF));
+}
+template <int OFF, class V>
+__device__ __forceinline__ void ds_wr64(unsigned a, const V& v) {
+    static_assert(sizeof(V) == 8, "8-byte source");
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(a), "v"(v), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void ds_wr32(unsigned a, unsigned v) { asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ __forceinline__ void ds_wr16(unsigned a, unsigned v) { asm volatile("ds_write_b16 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ __forceinline__ unsigned ds_add_rtn(unsigned a, unsigned v) {
+    unsigned r;
+    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(a), "v"(v) : "memory");
+    return r;
+}
+#define DVQ_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+__device__ __forceinline__ void wg_barrier() {                    // LDS writes of this wave done, then the workgroup barrier; VMEM stays in flight
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// 16-lane all-reduce by DPP (xor 1, xor 2, half mirror, mirror): every lane of a row of 16 gets the result
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);
+    v += dpp_f<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ float min_nc(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -3.0e38f); }   // one instruction (fminf adds a canonicalising v_max); in-range scores are far above -3e38
+__device__ __forceinline__ float row16_min(float v) {
+    v = min_nc(v, dpp_f<0xB1>(v));
+    v = min_nc(v, dpp_f<0x4E>(v));
+    v = min_nc(v, dpp_f<0x141>(v));
+    v = min_nc(v, dpp_f<0x140>(v));
+    return v;
+}
+
+// entry of accumulator register i (0..15) of entry tile jn, lane half h, wave w (v_mfma_f32_32x32x16 D layout)
+__device__ __forceinline__ int entry_of(int w, int jn, int i, int h) { return 64 * w + 32 * jn + 8 * (i >> 2) + 4 * h + (i & 3); }
+
+// torch.argmin order as one unsigned key: smaller distance first, equal distances -> lower entry, NaN before everything
+__device__ __forceinline__ unsigned long long order_key(float d, int k) {
+    const unsigned b = __float_as_uint(d);
+    const unsigned u = (d != d) ? 0u : ((b & 0x80000000u) ? ~b : (b | 0x80000000u));
+    return ((unsigned long long)u << 32) | (unsigned)k;
+}
+
+// ------------------------------------------------------------------------------------------------ refine chains
+// Canonical chains threaded through 4 lanes: lane q of a group holds floats [64q, 64q+64) of its z row and of its
+// candidate's codebook row (all loads issued up front: ONE memory latency), then the k-ordered fmaf chain runs as four
+// 64-step rounds, round q continuing from the accumulator lane q-1 produced.  Bit-identical to a single 256-step chain.
+__device__ __forceinline__ void chain_pair_x4(const float* __restrict__ zr, const float* __restrict__ er, int q, bool active,
+                                              float& zz, float& dot) {
+    f32x4 x[16], y[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {                              // idle lanes load nothing (a shared dummy row would hot-spot one L2 channel)
+        x[u] = active ? *reinterpret_cast<const f32x4*>(zr + 64 * q + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+        y[u] = active ? *reinterpret_cast<const f32x4*>(er + 64 * q + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float a = 0.f, b = 0.f;
+    const int lane = threadIdx.x & 63, base = lane & ~3;
+#pragma unroll
+    for (int round = 0; round < 4; ++round) {
+        const float a_in = round ? __shfl(a, base + round - 1) : 0.f;
+        const float b_in = round ? __shfl(b, base + round - 1) : 0.f;
+        float ta = a_in, tb = b_in;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                ta = fmaf(x[u][c], x[u][c], ta);
+                tb = fmaf(x[u][c], y[u][c], tb);
+            }
+        if (q == round) { a = ta; b = tb; }
+    }
+    zz = __shfl(a, base + 3);
+    dot = __shfl(b, base + 3);
+}
+
+// full-row single-lane form (all-entries fallback)
+__device__ __forceinline__ void chain_pair(const float* __restrict__ zr, const float* __restrict__ er, float& zz, float& dot) {
+    float a = 0.f, b = 0.f;
+    for (int j0 = 0; j0 < D; j0 += 32) {
+        f32x4 x[8], y[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            x[u] = *reinterpret_cast<const f32x4*>(zr + j0 + 4 * u);
+            y[u] = *reinterpret_cast<const f32x4*>(er + j0 + 4 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                a = fmaf(x[u][c], x[u][c], a);
+                b = fmaf(x[u][c], y[u][c], b);
+            }
+    }
+    zz = a;
+    dot = b;
+}
+
+// ------------------------------------------------------------------------------------------------ the kernel's phases
+struct Ctx {
+    const float* z;
+    long M;
+    long tile0;          // first tile of this launch
+    int G;               // workgroups (tile stride)
+    int ntl;             // tiles of this workgroup
+    int wave, lane, grp; // grp: 0 = waves 0-3 (matrix phase first), 1 = waves 4-7 (half a tile later)
+    unsigned lds0;       // LDS byte address of the dynamic segment
+    float emax, demax, sEf;
+    bool e_valid;
+    bool dbg;            // DVQ_VQ_DBG: phase stamps of two tiles go to LDS (and from there to the workspace)
+};
+
+// shader-clock stamp `slot` of this wave (tiles 2 and 5 only: slots 0-15 / 16-31)
+__device__ __forceinline__ void stamp(const Ctx& c, int t, int slot) {
+    if (c.dbg && (t == 2 || t == 5)) {
+        const unsigned v = (unsigned)__builtin_amdgcn_s_memtime();
+        if (c.lane == 0) ds_wr32(c.lds0 + L_DBG + (c.wave * 32 + (t == 5 ? 16 : 0) + slot) * 4, v);
+    }
+}
+
+// DMA the wave's 4 rows of local tile j into ring slot j % RING
+__device__ __forceinline__ void issue_tile(const Ctx& c, int j, char* lds) {
+    const long tile = c.tile0 + (long)blockIdx.x + (long)j * c.G;
+    char* dst = lds + L_RING + (j % RING) * (TILE * D * 4) + (c.wave * 4) * 1024;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        long gr = tile * TILE + c.wave * 4 + q;
+        if (gr >= c.M) gr = c.M - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(c.z + gr * D + 4 * c.lane),
+                                         (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
+    }
+}
+
+// fp32 -> fp16 conversion of the wave's 4 rows of local tile j (16 lanes per row, 16 floats per lane), row statistics.
+// wait for this wave's DMAs of local tile j: they (and everything issued before them) are the oldest outstanding
+// vector-memory operations of the wave; younger: the DMAs of tiles j+1 and j+2 (if those tiles exist)
+__device__ __forceinline__ void wait_tile(const Ctx& c, int j) {
+    const int younger = (j + 2 < c.ntl) ? 8 : (j + 1 < c.ntl) ? 4 : 0;
+    if (younger == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ void convert_tile(const Ctx& c, int j, char* lds, bool waited = false) {
+    const int g = c.lane >> 4, i = c.lane & 15;
+    const int row_t = c.wave * 4 + g;
+    if (!waited) wait_tile(c, j);
+    const unsigned ra = c.lds0 + L_RING + (j % RING) * (TILE * D * 4) + row_t * 1024 + 16 * i;
+    f32x4 x[4];
+    ds_rd128<0>(x[0], ra);
+    ds_rd128<256>(x[1], ra);
+    ds_rd128<512>(x[2], ra);
+    ds_rd128<768>(x[3], ra);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+    stamp(c, j - 1, 4);
+    if (j + RING < c.ntl) issue_tile(c, j + RING, lds);          // the slot's bytes are in registers: refill it
+    float ss = 0.f, dsq = 0.f;
+    const unsigned wa = c.lds0 + L_Z16 + (j & 1) * Z16_BUF + row_t * Z16_ROW + 8 * i;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f16x2 lo, hi;
+        lo[0] = (_Float16)x[q][0]; lo[1] = (_Float16)x[q][1];
+        hi[0] = (_Float16)x[q][2]; hi[1] = (_Float16)x[q][3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float hv = (float)(e < 2 ? lo[e] : hi[e - 2]);
+            const float d = x[q][e] - hv;                            // exact
+            ss = fmaf(x[q][e], x[q][e], ss);
+            dsq = fmaf(d, d, dsq);
+        }
+        f32x2 pk;
+        pk[0] = __builtin_bit_cast(float, lo);
+        pk[1] = __builtin_bit_cast(float, hi);
+        if (q == 0) ds_wr64<0>(wa, pk);
+        else if (q == 1) ds_wr64<128>(wa, pk);
+        else if (q == 2) ds_wr64<256>(wa, pk);
+        else ds_wr64<384>(wa, pk);
+    }
+    ss = row16_sum(ss);
+    dsq = row16_sum(dsq);
+    const float zn = __builtin_amdgcn_sqrtf(ss) * 1.0001f;
+    const float dzn = __builtin_amdgcn_sqrtf(dsq) * 1.0001f;
+    const float eps = 4.004f * (dzn * c.emax + zn * c.demax + dzn * c.demax) + 0.00018311f * (zn + c.emax) * (zn + c.emax);
+    const float epsS = eps * c.sEf;
+    const bool bad = !c.e_valid || !(ss <= 3.0e38f) || !(dsq <= 3.0e38f) || !(epsS <= 3.0e38f);   // NaN/Inf, fp16 overflow
+    if (i == 0) {
+        f32x2 rs;
+        rs[0] = epsS;
+        rs[1] = __uint_as_float(bad ? 1u : 0u);
+        ds_wr64<0>(c.lds0 + L_RS + (j & 3) * (TILE * 8) + row_t * 8, rs);
+    }
+}
+
+// matrix phase of local tile t: accumulators start at sE |e_k|^2, 16 fragment reads, 32 MFMAs
+__device__ __forceinline__ void mfma_tile(const Ctx& c, int t, const f16x8 (&af)[2][16], f32x16 (&acc)[2]) {
+    const int r = c.lane & 31, h = c.lane >> 5;
+    const unsigned ea = c.lds0 + L_EES + (64 * c.wave + 4 * h) * 4;
+    const unsigned za = c.lds0 + L_Z16 + (t & 1) * Z16_BUF + r * Z16_ROW + 16 * h;
+    f32x4 ci[2][4];
+    ds_rd128<0>(ci[0][0], ea);   ds_rd128<32>(ci[0][1], ea);  ds_rd128<64>(ci[0][2], ea);  ds_rd128<96>(ci[0][3], ea);
+    ds_rd128<128>(ci[1][0], ea); ds_rd128<160>(ci[1][1], ea); ds_rd128<192>(ci[1][2], ea); ds_rd128<224>(ci[1][3], ea);
+    f16x8 bf[16];
+    constexpr int PF = 4;
+    ds_rd128<0>(bf[0], za); ds_rd128<32>(bf[1], za); ds_rd128<64>(bf[2], za); ds_rd128<96>(bf[3], za);
+    // the 8 start-value reads are older than every fragment read: waiting for fragment 0 covers them
+    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(ci[0][0]), "+v"(ci[0][1]), "+v"(ci[0][2]), "+v"(ci[0][3]), "+v"(ci[1][0]),
+                 "+v"(ci[1][1]), "+v"(ci[1][2]), "+v"(ci[1][3]), "+v"(bf[0]));
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[jn][4 * q + e] = ci[jn][q][e];
+#define DVQ_STEP(S, YOUNGER)                                                                                    \
+    {                                                                                                           \
+        if (S + PF < 16) ds_rd128<32 * ((S + PF) & 15)>(bf[(S + PF) & 15], za);                                 \
+        if (S > 0) asm volatile("s_waitcnt lgkmcnt(" #YOUNGER ")" : "+v"(bf[S]));                               \
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][S], bf[S], acc[0], 0, 0, 0);                      \
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][S], bf[S], acc[1], 0, 0, 0);                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                      \
+    }
+    // YOUNGER = fragment reads issued after fragment S at the point of the wait = min(PF, 15 - S)
+    DVQ_STEP(0, 4) DVQ_STEP(1, 4) DVQ_STEP(2, 4) DVQ_STEP(3, 4) DVQ_STEP(4, 4) DVQ_STEP(5, 4) DVQ_STEP(6, 4) DVQ_STEP(7, 4)
+    DVQ_STEP(8, 4) DVQ_STEP(9, 4) DVQ_STEP(10, 4) DVQ_STEP(11, 4) DVQ_STEP(12, 3) DVQ_STEP(13, 2) DVQ_STEP(14, 1) DVQ_STEP(15, 0)
+#undef DVQ_STEP
+}
+
+// scores of local tile t: 5-bit id into the low mantissa bits, lane-local (min, second), one 8-byte slot per (wave, lane half)
+__device__ __forceinline__ void score_tile(const Ctx& c, int t, const f32x16 (&acc)[2]) {
+    const int r = c.lane & 31, h = c.lane >> 5;
+    float m1 = INFINITY, m2 = INFINITY;
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float p = __uint_as_float((__float_as_uint(acc[jn][i]) & ~31u) | (unsigned)(16 * jn + i));
+            m2 = __builtin_amdgcn_fmed3f(m1, m2, p);
+            m1 = min_nc(m1, p);
+        }
+    f32x2 v;
+    v[0] = m1;
+    v[1] = m2;
+    ds_wr64<0>(c.lds0 + L_MS + (t & 1) * MS_BUF + r * MS_ROW + (2 * c.wave + h) * 8, v);
+}
+
+// merge of local tile tm: this wave's 4 rows (16 slots each), rows 16 grp + 4 (wave & 3) + g
+__device__ __forceinline__ void merge_tile(const Ctx& c, int tm) {
+    const int g = c.lane >> 4, i = c.lane & 15;
+    const int r = 16 * c.grp + 4 * (c.wave & 3) + g;
+    f32x2 sl, rs;
+    ds_rd64<0>(sl, c.lds0 + L_MS + (tm & 1) * MS_BUF + r * MS_ROW + i * 8);
+    ds_rd64<0>(rs, c.lds0 + L_RS + (tm & 3) * (TILE * 8) + r * 8);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sl), "+v"(rs));
+    const float m1 = sl[0], m2 = sl[1];
+    const float rmin = row16_min(m1);
+    const float thr = rmin + rs[0];
+    const bool bad = __float_as_uint(rs[1]) != 0u;
+    const bool c1 = m1 <= thr, c2 = m2 <= thr;
+    const unsigned long long b1 = __ballot(c1), b2 = __ballot(c2);
+    const unsigned s1 = (unsigned)(b1 >> (16 * g)) & 0xffffu, s2 = (unsigned)(b2 >> (16 * g)) & 0xffffu;
+    const int n1 = __popc(s1), n2 = __popc(s2);
+    const long grow = (c.tile0 + (long)blockIdx.x + (long)tm * c.G) * TILE + r;
+    const bool live = grow < c.M;
+    const unsigned rowslot = (unsigned)(tm * TILE + r);
+    const int w_src = i >> 1, h_src = i & 1;
+    const bool slow = bad || n1 == 0;
+    const bool unique = !slow && n1 == 1 && n2 == 0;
+    const bool amb = live && !slow && !unique;
+    // one reservation per ambiguous row (leader lane i == 0): single candidates take one pair, a slot whose second score
+    // is within eps takes all its 32 entries
+    const int need = (n1 - n2) + 32 * n2;
+    unsigned pos = 0;
+    if (amb && i == 0) pos = ds_add_rtn(c.lds0 + L_CNT, (unsigned)need);
+    pos = (unsigned)__builtin_amdgcn_readlane((int)pos, 0) * (g == 0) + (unsigned)__builtin_amdgcn_readlane((int)pos, 16) * (g == 1) +
+          (unsigned)__builtin_amdgcn_readlane((int)pos, 32) * (g == 2) + (unsigned)__builtin_amdgcn_readlane((int)pos, 48) * (g == 3);
+    const bool fits = pos + (unsigned)need <= (unsigned)PAIR_CAP;
+    if (live && unique && c1) {
+        const unsigned id = __float_as_uint(m1) & 31u;
+        const unsigned k = (unsigned)entry_of(w_src, id >> 4, id & 15, h_src);
+        f32x2 kv;
+        kv[0] = __uint_as_float(k);
+        kv[1] = __uint_as_float(0u);
+        ds_wr64<0>(c.lds0 + L_RES + rowslot * 8, kv);
+    }
+    if (amb && fits && c1) {
+        const unsigned lt = (1u << i) - 1u;
+        const unsigned off = pos + (unsigned)__popc(s1 & ~s2 & lt) + 32u * (unsigned)__popc(s2 & lt);
+        if (c2) {
+            for (int e = 0; e < 32; ++e)
+                ds_wr32(c.lds0 + L_PAIR + (off + e) * 4, (rowslot << 16) | (unsigned)entry_of(w_src, e >> 4, e & 15, h_src));
+        } else {
+            const unsigned id = __float_as_uint(m1) & 31u;
+            ds_wr32(c.lds0 + L_PAIR + off * 4, (rowslot << 16) | (unsigned)entry_of(w_src, id >> 4, id & 15, h_src));
+        }
+    }
+    if (live && i == 0 && (slow || (amb && !fits))) {
+        const unsigned sp = ds_add_rtn(c.lds0 + L_CNT + 4, 1u);
+        ds_wr16(c.lds0 + L_SLOW + sp * 2, rowslot);
+    }
+}
+
+__global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restrict__ z, const float* __restrict__ E, long M,
+                                                          long tile0, long n_tiles, const char* __restrict__ packed,
+                                                          int64_t* __restrict__ idx, unsigned long long* __restrict__ slow_rows,
+                                                          unsigned long long* __restrict__ dbg) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const int tid = threadIdx.x;
+    Ctx c;
+    c.z = z;
+    c.M = M;
+    c.tile0 = tile0;
+    c.G = (int)gridDim.x;
+    c.ntl = (int)((n_tiles - (long)blockIdx.x + c.G - 1) / c.G);          // blockIdx.x < n_tiles by construction
+    c.lane = tid & 63;
+    c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    c.grp = c.wave >> 2;
+    c.lds0 = lds_addr(lds);
+    c.dbg = dbg != nullptr;
+    const float* ee_g = reinterpret_cast<const float*>(packed + PK_OFF_EE);
+    // fp16 subnormals flush to zero in conversions (MODE.FP_DENORM[3:2] = 0): the rounding error is measured on exactly
+    // the values the matrix core multiplies (measured on gfx950: the MFMA keeps fp16 subnormal inputs; this does not rely on it)
+    __builtin_amdgcn_s_setreg((2 - 1) << 11 | 6 << 6 | 1, 0);            // hwreg(HW_REG_MODE, offset 6, width 2) <- 0
+
+    // ---- prologue.  Vector-memory issue order: tile 0, the codebook slice (128 VGPRs), |e|^2, the header, tiles 1..RING-1.
+    // All by hand (inline asm / LDS-DMA), completed by wait_tile(0)'s counted wait: a compiler-visible load would be waited
+    // for with vmcnt(0) at its first use, i.e. together with every tile in flight.
+    for (int u = tid; u < MAX_TILES * TILE; u += NT) reinterpret_cast<unsigned long long*>(lds + L_RES)[u] = ~0ull;
+    for (int u = tid; u < PAIR_CAP; u += NT) reinterpret_cast<unsigned*>(lds + L_PAIR)[u] = ~0u;   // holes of refused reservations stay invalid
+    if (tid < 2) reinterpret_cast<unsigned*>(lds + L_CNT)[tid] = 0u;
+    if (c.ntl > 0) issue_tile(c, 0, lds);
+    f16x8 af[2][16];
+    {
+        const char* img = packed + PK_OFF_IMG + (size_t)c.wave * (32 * 1024);
+#pragma unroll
+        for (int f = 0; f < 32; ++f)
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(af[f >> 4][f & 15]) : "v"((unsigned)(f * 1024 + c.lane * 16)), "s"(img));
+    }
+    float ee_mine;                                                         // NT == K
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(ee_mine) : "v"((unsigned)(tid * 4)), "s"(ee_g));
+    f32x4 h0, h1;                                                          // header words 0-3, 4-7 (every lane the same address)
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(h0) : "v"(0u), "s"(packed));
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(h1) : "v"(0u), "s"(packed));
+    for (int j = 1; j < RING && j < c.ntl; ++j) issue_tile(c, j, lds);
+    wait_tile(c, 0);
+    asm volatile("" : "+v"(ee_mine), "+v"(h0), "+v"(h1));
+#pragma unroll
+    for (int f = 0; f < 32; ++f) asm volatile("" : "+v"(af[f >> 4][f & 15]));
+    // (element values copied out first: __builtin_bit_cast applied directly to a vector-element expression reads element 0)
+    const float w_emax = h0[0], w_sexp = h0[1], w_valid = h0[2], w_demax = h1[1];
+    c.emax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w_emax)));
+    const int sexp = __builtin_amdgcn_readfirstlane(__float_as_int(w_sexp));
+    c.e_valid = __builtin_amdgcn_readfirstlane(__float_as_int(w_valid)) != 0;
+    c.demax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w_demax)));
+    c.sEf = c.e_valid ? pow2f(sexp) : 1.0f;
+    ds_wr32(c.lds0 + L_EES + tid * 4, __float_as_uint(ee_mine * c.sEf));
+    convert_tile(c, 0, lds, true);
+    wg_barrier();
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+
+    // ---- tile loop: waves 0-3 multiply tile t while waves 4-7 score tile t-1 / convert tile t+1 / merge tile t-2, then swap
+    f32x16 acc[2];
+    for (int t = 0; t <= c.ntl; ++t) {
+        stamp(c, t, 0);
+        if (c.grp == 0) {
+            if (t < c.ntl) mfma_tile(c, t, af, acc);
+            stamp(c, t, 1);
+            wg_barrier();
+            stamp(c, t, 2);
+            if (t < c.ntl) score_tile(c, t, acc);
+            stamp(c, t, 3);
+            if (t + 1 < c.ntl) convert_tile(c, t + 1, lds);
+            stamp(c, t, 5);
+            if (t >= 1) merge_tile(c, t - 1);
+            stamp(c, t, 6);
+            wg_barrier();
+            stamp(c, t, 7);
+        } else {
+            if (t >= 1) score_tile(c, t - 1, acc);
+            stamp(c, t, 3);
+            if (t + 1 < c.ntl) convert_tile(c, t + 1, lds);
+            stamp(c, t, 5);
+            if (t >= 2) merge_tile(c, t - 2);
+            stamp(c, t, 6);
+            wg_barrier();
+            stamp(c, t, 2);
+            if (t < c.ntl) mfma_tile(c, t, af, acc);
+            stamp(c, t, 1);
+            wg_barrier();
+            stamp(c, t, 7);
+        }
+    }
+    if (c.grp == 1) merge_tile(c, c.ntl - 1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
+
+    // ---- refine: canonical distances of the listed pairs, four lanes per chain; key minimum per row
+    unsigned long long* s_res = reinterpret_cast<unsigned long long*>(lds + L_RES);
+    const unsigned* s_pair = reinterpret_cast<const unsigned*>(lds + L_PAIR);
+    const uint16_t* s_slow = reinterpret_cast<const uint16_t*>(lds + L_SLOW);
+    const unsigned* s_cnt = reinterpret_cast<const unsigned*>(lds + L_CNT);
+    const int total = (int)min(s_cnt[0], (unsigned)PAIR_CAP);
+    const int n_slow = (int)s_cnt[1];
+    auto grow_of = [&](int rowslot) { return (c.tile0 + (long)blockIdx.x + (long)(rowslot >> 5) * c.G) * TILE + (rowslot & 31); };
+    for (int s0 = 0; s0 < total; s0 += NT / 4) {
+        if (s0 + c.wave * 16 < total) {                           // wave-uniform: this wave has at least one pair
+            const int slot = s0 + (tid >> 2), q = tid & 3;
+            const unsigned pr = slot < total ? s_pair[slot] : ~0u;
+            const bool act = pr != ~0u;                           // ~0: hole left by a reservation that did not fit
+            const int rowslot = (int)(pr >> 16), k = (int)(pr & 0xffffu);
+            float zz, dot;
+            chain_pair_x4(z + grow_of(rowslot) * D, E + (long)k * D, q, act, zz, dot);
+            if (act && q == 0) {
+                const float tsum = zz + ee_g[k];
+                atomicMin(&s_res[rowslot], order_key(tsum - 2.0f * dot, k));
+            }
+        }
+    }
+    // what is left (NaN/Inf, fp16 overflow, invalid codebook image, overflowing list): all K entries canonically,
+    // the whole workgroup per row, one single-lane chain per entry (NT == K)
+    for (int o = 0; o < n_slow; ++o) {
+        const int rowslot = s_slow[o];
+        float zz2, dot2;
+        chain_pair(z + grow_of(rowslot) * D, E + (long)tid * D, zz2, dot2);
+        const float tsum = zz2 + ee_g[tid];
+        atomicMin(&s_res[rowslot], order_key(tsum - 2.0f * dot2, tid));
+    }
+    if (slow_rows && n_slow > 0 && tid == 0) atomicAdd(slow_rows, (unsigned long long)n_slow);
+    __syncthreads();
+    if (tid < c.ntl * TILE) {
+        const long gr = grow_of(tid);
+        if (gr < M) idx[gr] = (int64_t)(unsigned)(s_res[tid] & 0xffffffffull);
+    }
+    if (dbg && tid == 0) {
+        const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(dbg) + (size_t)blockIdx.x * DBG_WG_BYTES);
+        o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3;
+        o[4] = (unsigned long long)total; o[5] = (unsigned long long)n_slow;
+        o[6] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));   // HW_ID
+        o[7] = (unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));  // XCC_ID
+    }
+    if (dbg && tid < NWV * 32)
+        reinterpret_cast<unsigned*>(reinterpret_cast<char*>(dbg) + (size_t)blockIdx.x * DBG_WG_BYTES + 64)[tid] =
+            reinterpret_cast<const unsigned*>(lds + L_DBG)[tid];
+}
+
+struct DevInfo {
+    int cus;
+};
+
+int device_cus() {
+    static int cus[128] = {0};
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d &= 127;
+    int v = __atomic_load_n(&cus[d], __ATOMIC_RELAXED);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) v = 256;
+        __atomic_store_n(&cus[d], v, __ATOMIC_RELAXED);
+    }
+    return v;
+}
+
+}  // namespace
+
+extern "C" int dvq_vq_fast_supported(int Kq, int Dq) { return Kq == K && Dq == D; }
+
+extern "C" size_t dvq_vq_pack_bytes(int Kq, int Dq) { return dvq_vq_fast_supported(Kq, Dq) ? PK_BYTES : 0; }
+
+extern "C" int dvq_vq_pack(const float* E, int Kq, int Dq, void* packed, size_t packed_bytes, dvq_stream_t stream) {
+    DVQ_REQUIRE(dvq_vq_fast_supported(Kq, Dq), "vq_pack: the fast path supports K=%d, D=%d only (got %d, %d)", K, D, Kq, Dq);
+    DVQ_REQUIRE(E && packed && dvq_aligned16(E) && dvq_aligned16(packed), "vq_pack: null/unaligned pointer");
+    DVQ_REQUIRE(packed_bytes >= PK_BYTES, "vq_pack: buffer %zu < %zu bytes", packed_bytes, PK_BYTES);
+    hipStream_t st = (hipStream_t)stream;
+    char* pk = (char*)packed;
+    DVQ_LAUNCH(vq_pack_norm_kernel, dim3(1), dim3(K), 0, st, E, (float*)(pk + PK_OFF_EE), (PackHeader*)pk);
+    DVQ_CHECK_LAUNCH("vq_pack_norm");
+    DVQ_LAUNCH(vq_pack_img_kernel, dim3((K * D + 255) / 256), dim3(256), 0, st, E, (const PackHeader*)pk,
+                       (_Float16*)(pk + PK_OFF_IMG));
+    DVQ_CHECK_LAUNCH("vq_pack_img");
+    DVQ_LAUNCH(vq_pack_err_kernel, dim3(1), dim3(K), 0, st, E, (const _Float16*)(pk + PK_OFF_IMG), (PackHeader*)pk);
+    DVQ_CHECK_LAUNCH("vq_pack_err");
+    return DVQ_OK;
+}
+
+extern "C" size_t dvq_vq_fast_workspace_bytes(int64_t M, int Kq, int Dq) {
+    (void)M;
+    if (!dvq_vq_fast_supported(Kq, Dq)) return 256;
+    return dvq_round_up((size_t)1024 * DBG_WG_BYTES, 256);        // per-workgroup phase stamps (DVQ_VQ_DBG only)
+}
+
+extern "C" int dvq_vq_argmin_fast(const float* z, const float* E, const void* packed, int64_t M, int Kq, int Dq,
+                                  int64_t* idx, unsigned long long* slow_rows, void* workspace, size_t workspace_bytes,
+                                  dvq_stream_t stream) {
+    DVQ_REQUIRE(dvq_vq_fast_supported(Kq, Dq), "vq_argmin_fast: supports K=%d, D=%d only (got %d, %d)", K, D, Kq, Dq);
+    DVQ_REQUIRE(M >= 0 && M < (1L << 31), "vq_argmin_fast: bad M");
+    if (M == 0) return DVQ_OK;
+    DVQ_REQUIRE(z && E && packed && idx && workspace, "vq_argmin_fast: null pointer");
+    DVQ_REQUIRE(dvq_aligned16(z) && dvq_aligned16(E) && dvq_aligned16(packed) && dvq_aligned16(workspace),
+                "vq_argmin_fast: pointers must be 16-byte aligned (z must be dense [M,256])");
+    if (workspace_bytes < dvq_vq_fast_workspace_bytes(M, Kq, Dq)) {
+        dvq_set_error("vq_argmin_fast: workspace %zu < %zu bytes", workspace_bytes, dvq_vq_fast_workspace_bytes(M, Kq, Dq));
+        return DVQ_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    static DvqOncePerDevice attr_once;
+    if (attr_once.first()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vq_stream_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) {
+            dvq_set_error("vq_argmin_fast: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return DVQ_ELAUNCH;
+        }
+    }
+    const char* pk = (const char*)packed;
+    const int cus = device_cus();
+    const long tiles = (M + TILE - 1) / TILE;
+    const long per_launch = (long)cus * MAX_TILES;                 // one workgroup per CU, <= MAX_TILES tiles each
+    const bool want_dbg = getenv("DVQ_VQ_DBG") != nullptr;
+    DVQ_PROF("vq_argmin_fast", 2.0 * M * K * D, (double)M * D * 4 + (double)K * D * 4 + (double)M * 8, st);
+    for (long t0 = 0; t0 < tiles; t0 += per_launch) {
+        const long nt = (tiles - t0 < per_launch) ? tiles - t0 : per_launch;
+        const unsigned grid = (unsigned)(nt < cus ? nt : cus);
+        DVQ_LAUNCH(vq_stream_kernel, dim3(grid), dim3(NT), LDS_BYTES, st, z, E, (long)M, t0, nt, pk, idx, slow_rows,
+                   (want_dbg && t0 == 0) ? (unsigned long long*)workspace : nullptr);
+        DVQ_CHECK_LAUNCH("vq_stream");
+    }
+    return DVQ_OK;
+}

@@ -1,37 +1,66 @@
-"""Diagnostic (GPU box): per-workgroup phase durations of the VQ fast kernel from its DVQ_VQ_DBG stamps (100 MHz
-s_memrealtime): start spread, rows -> registers, chunk loop, epilogue + refine, pair / slow-row counts."""
+"""Diagnostic (GPU box): per-workgroup phase durations of the VQ streaming kernel from its DVQ_VQ_DBG stamps (100 MHz
+s_memrealtime): start spread, prologue (codebook to registers, first tile converted), tile loop, refine tail;
+pair / slow-row counts; plus a back-to-back timing of the call and the bit match against the exact kernel."""
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dvqvae_amd
 from dvqvae_amd import ops, _lib
-os.environ["DVQ_VQ_DBG"] = "1"
 dev = "cuda:0"
-M = 65536
-z = torch.randn(M, 256, device=dev); E = torch.randn(512, 256, device=dev)
+M = int(os.environ.get("VQ_M", 65536))
+torch.manual_seed(0)
+zs = [torch.randn(M, 256, device=dev) for _ in range(6)]
+z = zs[0]
+E = torch.randn(512, 256, device=dev)
 pk = ops.vq_pack(E)
+idx = ops.vq_argmin(z, E, packed=pk)
+ex = ops.vq_argmin(z, E, fast=False)
+torch.cuda.synchronize()
+print("bit match vs exact kernel:", float((idx == ex).float().mean()), " mismatches:", int((idx != ex).sum()))
+for i in range(6):
+    ops.vq_argmin(zs[i], E, packed=pk)
+torch.cuda.synchronize()
+n = 60
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for i in range(n):
+    ops.vq_argmin(zs[i % 6], E, packed=pk)
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) * 1e3 / n
+alg = M * 256 * 4 + 512 * 256 * 4 + M * 8
+print(f"train of {n} calls: {us:.2f} us per call = {alg / us / 1e3:.1f} GB/s = {alg / us / 1e3 / 8000:.3f} of 8 TB/s")
+
+os.environ["DVQ_VQ_DBG"] = "1"
 for _ in range(3):
     idx = ops.vq_argmin(z, E, packed=pk)
 torch.cuda.synchronize()
 lib = _lib.load()
 nws = lib.dvq_vq_fast_workspace_bytes(M, 512, 256)
 ws = ops.workspace(nws, torch.device(dev))
-raw = ws[:nws].cpu().numpy()
-n_wg = M // 128
-full = np.frombuffer(raw.tobytes()[: n_wg * 64], dtype=np.uint64).reshape(n_wg, 8).astype(np.int64)
+n_wg = min(256, (M + 31) // 32)
+REC = 64 + 8 * 32 * 4
+raw = ws[: n_wg * REC].cpu().numpy().tobytes()
+full = np.stack([np.frombuffer(raw[w * REC: w * REC + 64], dtype=np.uint64) for w in range(n_wg)]).astype(np.int64)
+st = np.stack([np.frombuffer(raw[w * REC + 64: (w + 1) * REC], dtype=np.uint32) for w in range(n_wg)]).astype(np.int64).reshape(n_wg, 8, 2, 16)
 dbg = full[:, :4]
 t0 = dbg[:, 0].min()
 rel = (dbg - t0) * 0.01   # us (100 MHz)
 print("start  min/med/max us:", rel[:, 0].min(), np.median(rel[:, 0]), rel[:, 0].max())
-print("prologue (z in regs) dur med/max:", np.median(rel[:, 1] - rel[:, 0]), (rel[:, 1] - rel[:, 0]).max())
-print("chunk loop dur med/max:", np.median(rel[:, 2] - rel[:, 1]), (rel[:, 2] - rel[:, 1]).max())
-print("epilogue+refine dur med/max:", np.median(rel[:, 3] - rel[:, 2]), (rel[:, 3] - rel[:, 2]).max())
+print("prologue dur med/max:", np.median(rel[:, 1] - rel[:, 0]), (rel[:, 1] - rel[:, 0]).max())
+print("tile loop dur med/max:", np.median(rel[:, 2] - rel[:, 1]), (rel[:, 2] - rel[:, 1]).max())
+print("refine tail dur med/max:", np.median(rel[:, 3] - rel[:, 2]), (rel[:, 3] - rel[:, 2]).max())
 print("end  min/med/max us:", rel[:, 3].min(), np.median(rel[:, 3]), rel[:, 3].max())
-
-ep = rel[:, 3] - rel[:, 2]
 tot, nov = full[:, 4], full[:, 5]
-print("pairs per WG mean/max:", tot.mean(), tot.max(), " overflow rows total:", nov.sum(), " WGs with overflow:", (nov > 0).sum())
-for lo, hi in [(0, 17), (17, 33), (33, 65), (65, 1000)]:
-    m = (tot >= lo) & (tot < hi) & (nov == 0)
-    if m.any(): print(f"pairs in [{lo},{hi}) no overflow: n={m.sum()} refine med/max = {np.median(ep[m]):.2f} {ep[m].max():.2f}")
-m = nov > 0
-if m.any(): print(f"overflow WGs: n={m.sum()} refine med/max = {np.median(ep[m]):.2f} {ep[m].max():.2f}")
+print("pairs per WG mean/max:", tot.mean(), tot.max(), " slow rows total:", nov.sum(), " WGs with slow rows:", (nov > 0).sum())
+# in-loop stamps (shader clock, 32-bit): slots 0 iteration start, 1 after mfma, 2 after the barrier in front of / behind it,
+# 3 after score, 4 after the DMA wait + LDS read of convert, 5 after convert, 6 after merge, 7 iteration end
+def d(a, b, grp, tile):
+    w = slice(0, 4) if grp == 0 else slice(4, 8)
+    v = ((st[:, w, tile, b] - st[:, w, tile, a]) & 0xffffffff).reshape(-1)
+    return f"{np.median(v):7.0f} /{np.percentile(v, 90):7.0f}"
+for tile, name in ((0, "t=2"), (1, "t=5")):
+    print(f"-- iteration {name}: median / p90 shader cycles")
+    print("  grp0: mfma", d(0, 1, 0, tile), " barrier", d(1, 2, 0, tile), " score", d(2, 3, 0, tile), " cvt wait+read", d(3, 4, 0, tile),
+          " cvt body", d(4, 5, 0, tile), " merge", d(5, 6, 0, tile), " barrier", d(6, 7, 0, tile), " total", d(0, 7, 0, tile))
+    print("  grp1: score", d(0, 3, 1, tile), " cvt wait+read", d(3, 4, 1, tile), " cvt body", d(4, 5, 1, tile), " merge", d(5, 6, 1, tile),
+          " barrier", d(6, 2, 1, tile), " mfma", d(2, 1, 1, tile), " barrier", d(1, 7, 1, tile), " total", d(0, 7, 1, tile))
