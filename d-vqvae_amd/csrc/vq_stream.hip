@@ -33,6 +33,7 @@
 // within eps may hide a third: all 32 entries of that slot are listed, so the list always contains the exact winner.
 // Algorithmic HBM bytes per row: D*4 (z) + 8 (int64 index); the codebook (K*D*4) is read once.
 #include "dvq_internal.h"
+#include <type_traits>
 
 namespace {
 
@@ -330,7 +331,6 @@ __device__ __forceinline__ void convert_tile(const Ctx& c, int j, char* lds, boo
     ds_rd128<512>(x[2], ra);
     ds_rd128<768>(x[3], ra);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
-    stamp(c, j - 1, 4);
     if (j + RING < c.ntl) issue_tile(c, j + RING, lds);          // the slot's bytes are in registers: refill it
     float ss = 0.f, dsq = 0.f;
     const unsigned wa = c.lds0 + L_Z16 + (j & 1) * Z16_BUF + row_t * Z16_ROW + 8 * i;
@@ -477,6 +477,170 @@ __device__ __forceinline__ void merge_tile(const Ctx& c, int tm) {
     }
 }
 
+// one of the wave's 4 row DMAs of local tile j (the pipelined loop spreads them over four MFMA gaps)
+__device__ __forceinline__ void issue_row(const Ctx& c, int j, int q, char* lds) {
+    const long tile = c.tile0 + (long)blockIdx.x + (long)j * c.G;
+    char* dst = lds + L_RING + (j % RING) * (TILE * D * 4) + (c.wave * 4 + q) * 1024;
+    long gr = tile * TILE + c.wave * 4 + q;
+    if (gr >= c.M) gr = c.M - 1;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(c.z + gr * D + 4 * c.lane),
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+}
+
+// scores of accumulator registers [B, E): id = idbase + register index in the low 5 mantissa bits, top-2 update
+template <int B, int E>
+__device__ __forceinline__ void score(const f32x16& a, int idbase, float& m1, float& m2) {
+#pragma unroll
+    for (int i = B; i < E; ++i) {
+        const float p = __uint_as_float((__float_as_uint(a[i]) & ~31u) | (unsigned)(idbase + i));
+        m2 = __builtin_amdgcn_fmed3f(m1, m2, p);
+        m1 = min_nc(m1, p);
+    }
+}
+
+__device__ __forceinline__ void write_slot(const Ctx& c, int t, float m1, float m2) {
+    f32x2 v;
+    v[0] = m1;
+    v[1] = m2;
+    ds_wr64<0>(c.lds0 + L_MS + (t & 1) * MS_BUF + (c.lane & 31) * MS_ROW + (2 * c.wave + (c.lane >> 5)) * 8, v);
+}
+
+// d = h - x with h the low (HI = 0) or high (HI = 1) fp16 half of `hp`: one v_fma_mix_f32 (exact; the sign does not matter)
+template <int HI>
+__device__ __forceinline__ float mix_diff(float hp, float x) {
+    float d;
+    if (HI) asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hp), "v"(x));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hp), "v"(x));
+    return d;
+}
+
+// fp32 -> fp16 conversion of the wave's 4 rows of a tile in pieces (the pipelined loop puts one piece into each MFMA gap)
+struct Convert {
+    f32x4 x[4];
+    float ss, dsq;
+    f32x2 pk;
+    __device__ __forceinline__ void read(const Ctx& c, int j) {          // after wait_tile(c, j)
+        const int g = c.lane >> 4, i = c.lane & 15;
+        const unsigned ra = c.lds0 + L_RING + (j % RING) * (TILE * D * 4) + (c.wave * 4 + g) * 1024 + 16 * i;
+        ds_rd128<0>(x[0], ra);
+        ds_rd128<256>(x[1], ra);
+        ds_rd128<512>(x[2], ra);
+        ds_rd128<768>(x[3], ra);
+        ss = 0.f;
+        dsq = 0.f;
+    }
+    template <int Q>
+    __device__ __forceinline__ void cvt(const Ctx& c, int j) {           // quad Q: convert, store into the fp16 image of tile j
+        const int g = c.lane >> 4, i = c.lane & 15;
+        f32x2 a, b;
+        a[0] = x[Q][0]; a[1] = x[Q][1]; b[0] = x[Q][2]; b[1] = x[Q][3];
+        const f16x2 lo = __builtin_convertvector(a, f16x2), hi = __builtin_convertvector(b, f16x2);
+        pk[0] = __builtin_bit_cast(float, lo);
+        pk[1] = __builtin_bit_cast(float, hi);
+        ds_wr64<128 * Q>(c.lds0 + L_Z16 + (j & 1) * Z16_BUF + (c.wave * 4 + g) * Z16_ROW + 8 * i, pk);
+    }
+    template <int Q>
+    __device__ __forceinline__ void err(float lo_hi0, float lo_hi1) {   // sums of squares of quad Q (pk of that quad)
+        const float d0 = mix_diff<0>(lo_hi0, x[Q][0]), d1 = mix_diff<1>(lo_hi0, x[Q][1]);
+        const float d2 = mix_diff<0>(lo_hi1, x[Q][2]), d3 = mix_diff<1>(lo_hi1, x[Q][3]);
+        ss = fmaf(x[Q][0], x[Q][0], ss); ss = fmaf(x[Q][1], x[Q][1], ss);
+        ss = fmaf(x[Q][2], x[Q][2], ss); ss = fmaf(x[Q][3], x[Q][3], ss);
+        dsq = fmaf(d0, d0, dsq); dsq = fmaf(d1, d1, dsq); dsq = fmaf(d2, d2, dsq); dsq = fmaf(d3, d3, dsq);
+    }
+    __device__ __forceinline__ void finish(const Ctx& c, int j) {        // ss, dsq already reduced over the row's 16 lanes
+        const int g = c.lane >> 4, i = c.lane & 15;
+        const float zn = __builtin_amdgcn_sqrtf(ss) * 1.0001f;
+        const float dzn = __builtin_amdgcn_sqrtf(dsq) * 1.0001f;
+        const float eps = 4.004f * (dzn * c.emax + zn * c.demax + dzn * c.demax) + 0.00018311f * (zn + c.emax) * (zn + c.emax);
+        const float epsS = eps * c.sEf;
+        const bool bad = !c.e_valid || !(ss <= 3.0e38f) || !(dsq <= 3.0e38f) || !(epsS <= 3.0e38f);   // NaN/Inf, fp16 overflow
+        if (i == 0) {
+            f32x2 rs;
+            rs[0] = epsS;
+            rs[1] = __uint_as_float(bad ? 1u : 0u);
+            ds_wr64<0>(c.lds0 + L_RS + (j & 3) * (TILE * 8) + (c.wave * 4 + g) * 8, rs);
+        }
+    }
+};
+
+// merge of a tile in stages (rows 4 wave + g, 16 slots each); same decisions as merge_tile
+struct Merge {
+    f32x2 sl, rs;
+    float m1, m2, rmin;
+    unsigned s1, s2;
+    bool c1, c2;
+    __device__ __forceinline__ void read(const Ctx& c, int tm) {
+        const int g = c.lane >> 4, i = c.lane & 15;
+        const int r = 4 * c.wave + g;
+        ds_rd64<0>(sl, c.lds0 + L_MS + (tm & 1) * MS_BUF + r * MS_ROW + i * 8);
+        ds_rd64<0>(rs, c.lds0 + L_RS + (tm & 3) * (TILE * 8) + r * 8);
+    }
+    __device__ __forceinline__ void min_a() {                            // after the wait that pins sl, rs
+        m1 = sl[0];
+        m2 = sl[1];
+        rmin = min_nc(m1, dpp_f<0xB1>(m1));
+        rmin = min_nc(rmin, dpp_f<0x4E>(rmin));
+    }
+    __device__ __forceinline__ void min_b(const Ctx& c) {
+        const int g = c.lane >> 4;
+        rmin = min_nc(rmin, dpp_f<0x141>(rmin));
+        rmin = min_nc(rmin, dpp_f<0x140>(rmin));
+        const float thr = rmin + rs[0];
+        c1 = m1 <= thr;
+        c2 = m2 <= thr;
+        const unsigned long long b1 = __ballot(c1), b2 = __ballot(c2);
+        s1 = (unsigned)(b1 >> (16 * g)) & 0xffffu;
+        s2 = (unsigned)(b2 >> (16 * g)) & 0xffffu;
+    }
+    __device__ __forceinline__ void act(const Ctx& c, int tm) {
+        const int g = c.lane >> 4, i = c.lane & 15;
+        const int r = 4 * c.wave + g;
+        const int n1 = __popc(s1), n2 = __popc(s2);
+        const bool bad = __float_as_uint(rs[1]) != 0u;
+        const long grow = (c.tile0 + (long)blockIdx.x + (long)tm * c.G) * TILE + r;
+        const bool live = grow < c.M && tm >= 0;                        // (the pipelined loop also merges "tiles" -2, -1)
+        const unsigned rowslot = (unsigned)(tm * TILE + r);
+        const int w_src = i >> 1, h_src = i & 1;
+        const bool slow = bad || n1 == 0;
+        const bool unique = !slow && n1 == 1 && n2 == 0;
+        const bool amb = live && !slow && !unique;
+        if (live && unique && c1) {
+            const unsigned id = __float_as_uint(m1) & 31u;
+            f32x2 kv;
+            kv[0] = __uint_as_float((unsigned)entry_of(w_src, id >> 4, id & 15, h_src));
+            kv[1] = __uint_as_float(0u);
+            ds_wr64<0>(c.lds0 + L_RES + rowslot * 8, kv);
+        }
+        if (__ballot(live && !unique) == 0ull) return;                  // common case: every row of the wave decided
+        // one reservation per ambiguous row (leader lane i == 0): single candidates take one pair, a slot whose second
+        // score is within eps takes all its 32 entries
+        const int need = (n1 - n2) + 32 * n2;
+        unsigned pos = 0;
+        if (amb && i == 0) pos = ds_add_rtn(c.lds0 + L_CNT, (unsigned)need);
+        pos = (unsigned)__builtin_amdgcn_readlane((int)pos, 0) * (g == 0) + (unsigned)__builtin_amdgcn_readlane((int)pos, 16) * (g == 1) +
+              (unsigned)__builtin_amdgcn_readlane((int)pos, 32) * (g == 2) + (unsigned)__builtin_amdgcn_readlane((int)pos, 48) * (g == 3);
+        const bool fits = pos + (unsigned)need <= (unsigned)PAIR_CAP;
+        if (amb && fits && c1) {
+            const unsigned lt = (1u << i) - 1u;
+            const unsigned off = pos + (unsigned)__popc(s1 & ~s2 & lt) + 32u * (unsigned)__popc(s2 & lt);
+            if (c2) {
+                for (int e = 0; e < 32; ++e)
+                    ds_wr32(c.lds0 + L_PAIR + (off + e) * 4, (rowslot << 16) | (unsigned)entry_of(w_src, e >> 4, e & 15, h_src));
+            } else {
+                const unsigned id = __float_as_uint(m1) & 31u;
+                ds_wr32(c.lds0 + L_PAIR + off * 4, (rowslot << 16) | (unsigned)entry_of(w_src, id >> 4, id & 15, h_src));
+            }
+        }
+        if (live && i == 0 && (slow || (amb && !fits))) {
+            const unsigned sp = ds_add_rtn(c.lds0 + L_CNT + 4, 1u);
+            ds_wr16(c.lds0 + L_SLOW + sp * 2, rowslot);
+        }
+    }
+};
+
+// ABL: timing-only ablations for diagnostics (DVQ_VQ_ABL; results invalid unless 0): 1 no DMA wait/issue, 2 no conversion,
+// 4 no merge, 8 no scoring, 16 no MFMA, 32 no barrier in the loop
+template <int ABL, bool DBG>
 __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restrict__ z, const float* __restrict__ E, long M,
                                                           long tile0, long n_tiles, const char* __restrict__ packed,
                                                           int64_t* __restrict__ idx, unsigned long long* __restrict__ slow_rows,
@@ -536,39 +700,240 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
     wg_barrier();
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
 
-    // ---- tile loop: waves 0-3 multiply tile t while waves 4-7 score tile t-1 / convert tile t+1 / merge tile t-2, then swap
-    f32x16 acc[2];
-    for (int t = 0; t <= c.ntl; ++t) {
-        stamp(c, t, 0);
-        if (c.grp == 0) {
-            if (t < c.ntl) mfma_tile(c, t, af, acc);
-            stamp(c, t, 1);
-            wg_barrier();
-            stamp(c, t, 2);
-            if (t < c.ntl) score_tile(c, t, acc);
-            stamp(c, t, 3);
-            if (t + 1 < c.ntl) convert_tile(c, t + 1, lds);
-            stamp(c, t, 5);
-            if (t >= 1) merge_tile(c, t - 1);
-            stamp(c, t, 6);
-            wg_barrier();
-            stamp(c, t, 7);
-        } else {
-            if (t >= 1) score_tile(c, t - 1, acc);
-            stamp(c, t, 3);
-            if (t + 1 < c.ntl) convert_tile(c, t + 1, lds);
-            stamp(c, t, 5);
-            if (t >= 2) merge_tile(c, t - 2);
-            stamp(c, t, 6);
-            wg_barrier();
-            stamp(c, t, 2);
-            if (t < c.ntl) mfma_tile(c, t, af, acc);
-            stamp(c, t, 1);
-            wg_barrier();
-            stamp(c, t, 7);
+    // ---- tile loop, software-pipelined by hand: 32 MFMA gaps per tile, the vector work of three other tiles in the gaps
+    //   G0-3   acc0 <- k-steps 0-3 of tile t (starting from sE|e|^2)   | scores of acc1 (tile t-1), slot write
+    //   G4-9   acc1 <- k-steps 0-3, then both accumulators alternate   | merge of tile t-2
+    //   G9-22  k-steps 4-11                                            | tile t+1: DMA wait, fp32 -> fp16, row statistics; DMAs of tile t+4
+    //   G24    barrier (fp16 tile t+1 and the slots of tile t-1 complete; every wave is done reading... see DESIGN)
+    //   G24-27 acc0 <- k-steps 12-15                                   | start values of the next tile
+    //   G28-31 acc1 <- k-steps 12-15                                   | scores of acc0 (tile t); first fragments of tile t+1
+    // LDS waits are by count of the fragment / start-value reads that are ALWAYS issued behind the awaited one; the other
+    // LDS operations in between only make a wait longer than necessary, never shorter.
+    f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    f16x8 bf[16];
+    f32x4 ci0[4], ci1[4];                                               // start values: read into the (just scored, free) accumulator's registers
+    float m1 = INFINITY, m2 = INFINITY;
+    const int r_l = c.lane & 31, h_l = c.lane >> 5;
+    const unsigned ea = c.lds0 + L_EES + (64 * c.wave + 4 * h_l) * 4;
+    const unsigned zbase = c.lds0 + L_Z16 + r_l * Z16_ROW + 16 * h_l;
+    ds_rd128<0>(bf[0], zbase); ds_rd128<32>(bf[1], zbase); ds_rd128<64>(bf[2], zbase);
+    ds_rd128<0>(ci0[0], ea); ds_rd128<32>(ci0[1], ea); ds_rd128<64>(ci0[2], ea); ds_rd128<96>(ci0[3], ea);
+    ds_rd128<96>(bf[3], zbase);
+    Convert cv;
+    Merge mg;
+#define DVQ_MF0(S) if (!(ABL & 16)) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][S], bf[S], acc0, 0, 0, 0)
+#define DVQ_MF1(S) if (!(ABL & 16)) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][S], bf[S], acc1, 0, 0, 0)
+#define DVQ_SB() __builtin_amdgcn_sched_barrier(0)
+// vector work is anchored in its gap: without a use the compiler sinks it to the end of the loop body, behind every MFMA
+#define DVQ_PIN2(A, B) asm volatile("" : "+v"(A), "+v"(B))
+#define DVQ_WAITF(N, S) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(bf[S]))
+#define DVQ_RDF(S) ds_rd128<32 * (S)>(bf[S], za)
+#define DVQ_STAMP(SLOT) if (DBG) stamp(c, t, SLOT)
+#ifndef DVQ_UNCOND
+#define DVQ_UNCOND 1   // 1: the per-tile work of non-existing tiles runs (no effect) instead of being branched around
+#endif
+    // The tile loop is rotated: `front(t)` = gaps 0-23 of tile t and the barrier, `back(t)` = gaps 24-31 (which prefetch tile
+    // t+1's first fragments and start values).  Every control-flow join (loop header, loop exit) sits right behind the
+    // barrier's lgkmcnt(0): no hand-issued LDS read is ever in flight across a join, where the register allocator may
+    // insert copies of what it believes are finished values.
+    // Nothing in the body is conditional on t except the DMA issue: tile "-1" is scored, tiles "-2", "-1" are merged (not
+    // live: no effect) and the tile behind the last one is converted (from stale ring bytes, never used).
+    auto front = [&](const int t) __attribute__((always_inline)) {
+        const bool do_dma = !(ABL & 1) && t + 1 + RING < c.ntl;
+        const bool has_prev = DVQ_UNCOND || t >= 1, do_merge = DVQ_UNCOND || t >= 2, do_cvt = DVQ_UNCOND || t + 1 < c.ntl;
+        const unsigned za = zbase + (t & 1) * Z16_BUF;
+        DVQ_STAMP(0);
+        // G0-3.  LDS reads pending at this point, in issue order: fragments 0, 1, 2, the four start values of acc0, fragment 3
+        if (!(ABL & 8) && has_prev) { score<0, 6>(acc1, 16, m1, m2); DVQ_PIN2(m1, m2); }
+        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(ci0[0]), "+v"(ci0[1]), "+v"(ci0[2]), "+v"(ci0[3]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]));
+        {
+            f32x16 st;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) st[4 * q + e] = ci0[q][e];
+            if (!(ABL & 16)) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bf[0], st, 0, 0, 0);
         }
+        DVQ_SB();
+        DVQ_MF0(1);
+        if (!(ABL & 8) && has_prev) { score<6, 11>(acc1, 16, m1, m2); DVQ_PIN2(m1, m2); }
+        DVQ_SB();
+        DVQ_MF0(2);
+        if (!(ABL & 8) && has_prev) {
+            score<11, 16>(acc1, 16, m1, m2);
+            write_slot(c, t - 1, m1, m2);
+        }
+        ds_rd128<128>(ci1[0], ea); ds_rd128<160>(ci1[1], ea); ds_rd128<192>(ci1[2], ea); ds_rd128<224>(ci1[3], ea);
+        DVQ_SB();
+        DVQ_WAITF(4, 3); DVQ_MF0(3);
+        DVQ_SB();
+        // G4-7
+        DVQ_RDF(4);
+        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(ci1[0]), "+v"(ci1[1]), "+v"(ci1[2]), "+v"(ci1[3]));
+        if (!(ABL & 4) && do_merge) mg.read(c, t - 2);
+        {
+            f32x16 st;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) st[4 * q + e] = ci1[q][e];
+            if (!(ABL & 16)) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][0], bf[0], st, 0, 0, 0);
+        }
+        DVQ_SB();
+        DVQ_MF1(1);
+        DVQ_SB();
+        DVQ_RDF(5);
+        DVQ_MF1(2);
+        if (!(ABL & 4) && do_merge) {
+            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(mg.sl), "+v"(mg.rs));
+            mg.min_a(); DVQ_PIN2(mg.rmin, mg.m1);
+        }
+        DVQ_SB();
+        DVQ_MF1(3);
+        if (!(ABL & 4) && do_merge) { mg.min_b(c); DVQ_PIN2(mg.s1, mg.s2); }
+        DVQ_SB();
+        DVQ_STAMP(1);
+        // G8-23: k-steps 4-11, both accumulators
+        DVQ_RDF(6);
+        DVQ_WAITF(2, 4); DVQ_MF0(4);
+        if (!(ABL & 4) && do_merge) mg.act(c, t - 2);
+        DVQ_SB();
+        DVQ_MF1(4);
+        if (!(ABL & 2) && do_cvt) {
+            if (!(ABL & 1)) wait_tile(c, t + 1);
+            cv.read(c, t + 1);
+        }
+        DVQ_SB();
+        DVQ_RDF(7);
+        DVQ_WAITF(2, 5); DVQ_MF0(5);
+        DVQ_SB();
+        DVQ_MF1(5);
+        f32x2 pk0, pk1, pk2, pk3;
+        if (!(ABL & 2) && do_cvt) {
+            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(cv.x[0]), "+v"(cv.x[1]), "+v"(cv.x[2]), "+v"(cv.x[3]));
+            cv.template cvt<0>(c, t + 1); pk0 = cv.pk;
+        }
+        DVQ_SB();
+        DVQ_RDF(8);
+        DVQ_WAITF(2, 6); DVQ_MF0(6);
+        if (!(ABL & 2) && do_cvt) { cv.template err<0>(pk0[0], pk0[1]); DVQ_PIN2(cv.ss, cv.dsq); }
+        if (do_dma) issue_row(c, t + 1 + RING, 0, lds);
+        DVQ_SB();
+        DVQ_MF1(6);
+        if (!(ABL & 2) && do_cvt) { cv.template cvt<1>(c, t + 1); pk1 = cv.pk; }
+        if (do_dma) issue_row(c, t + 1 + RING, 1, lds);
+        DVQ_SB();
+        DVQ_RDF(9);
+        DVQ_WAITF(2, 7); DVQ_MF0(7);
+        if (!(ABL & 2) && do_cvt) { cv.template err<1>(pk1[0], pk1[1]); DVQ_PIN2(cv.ss, cv.dsq); }
+        if (do_dma) issue_row(c, t + 1 + RING, 2, lds);
+        DVQ_SB();
+        DVQ_MF1(7);
+        if (!(ABL & 2) && do_cvt) { cv.template cvt<2>(c, t + 1); pk2 = cv.pk; }
+        if (do_dma) issue_row(c, t + 1 + RING, 3, lds);
+        DVQ_SB();
+        DVQ_RDF(10);
+        DVQ_WAITF(2, 8); DVQ_MF0(8);
+        if (!(ABL & 2) && do_cvt) { cv.template err<2>(pk2[0], pk2[1]); DVQ_PIN2(cv.ss, cv.dsq); }
+        DVQ_SB();
+        DVQ_MF1(8);
+        if (!(ABL & 2) && do_cvt) { cv.template cvt<3>(c, t + 1); pk3 = cv.pk; }
+        DVQ_SB();
+        DVQ_RDF(11);
+        DVQ_WAITF(2, 9); DVQ_MF0(9);
+        if (!(ABL & 2) && do_cvt) { cv.template err<3>(pk3[0], pk3[1]); DVQ_PIN2(cv.ss, cv.dsq); }
+        DVQ_SB();
+        DVQ_MF1(9);
+        if (!(ABL & 2) && do_cvt) { cv.ss = row16_sum(cv.ss); DVQ_PIN2(cv.ss, cv.dsq); }
+        DVQ_SB();
+        DVQ_RDF(12);
+        DVQ_WAITF(2, 10); DVQ_MF0(10);
+        if (!(ABL & 2) && do_cvt) { cv.dsq = row16_sum(cv.dsq); DVQ_PIN2(cv.ss, cv.dsq); }
+        DVQ_SB();
+        DVQ_RDF(13);
+        DVQ_MF1(10);
+        if (!(ABL & 2) && do_cvt) cv.finish(c, t + 1);
+        DVQ_SB();
+        DVQ_RDF(14);
+        DVQ_WAITF(3, 11); DVQ_MF0(11);
+        DVQ_SB();
+        DVQ_RDF(15);
+        DVQ_MF1(11);
+        DVQ_SB();
+        DVQ_STAMP(2);
+        // G24: every LDS operation of this wave complete (fragment reads of this tile included), then the barrier:
+        // behind it the fp16 image of tile t+1 and the slots of tile t-1 are complete, and nobody reads this tile's image any more
+        if (ABL & 32) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[12]), "+v"(bf[13]), "+v"(bf[14]), "+v"(bf[15])::"memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(bf[12]), "+v"(bf[13]), "+v"(bf[14]), "+v"(bf[15])::"memory");
+        DVQ_STAMP(3);
+    };
+    auto back = [&](const int t) __attribute__((always_inline)) {
+        const unsigned za = zbase + ((t + 1) & 1) * Z16_BUF;               // the NEXT tile's image
+        DVQ_MF0(12);
+        DVQ_SB();
+        DVQ_MF0(13);
+        DVQ_SB();
+        DVQ_MF0(14);
+        DVQ_SB();
+        DVQ_MF0(15);
+        DVQ_SB();
+        // G28-31: scores of acc0; its registers then take the next tile's start values; first fragments of tile t+1
+        m1 = INFINITY;
+        m2 = INFINITY;
+        DVQ_RDF(0);
+        DVQ_MF1(12);
+        if (!(ABL & 8)) { score<0, 6>(acc0, 0, m1, m2); DVQ_PIN2(m1, m2); }
+        DVQ_SB();
+        DVQ_RDF(1);
+        DVQ_MF1(13);
+        if (!(ABL & 8)) { score<6, 11>(acc0, 0, m1, m2); DVQ_PIN2(m1, m2); }
+        DVQ_SB();
+        DVQ_RDF(2);
+        DVQ_MF1(14);
+        if (!(ABL & 8)) { score<11, 16>(acc0, 0, m1, m2); DVQ_PIN2(m1, m2); }
+        ds_rd128<0>(ci0[0], ea); ds_rd128<32>(ci0[1], ea); ds_rd128<64>(ci0[2], ea); ds_rd128<96>(ci0[3], ea);
+        DVQ_SB();
+        DVQ_RDF(3);
+        DVQ_MF1(15);
+        DVQ_SB();
+        DVQ_STAMP(4);
+    };
+    if (c.ntl > 0) {
+        front(0);
+        for (int t = 0; t + 1 < c.ntl; ++t) {
+            back(t);
+            front(t + 1);
+        }
+        back(c.ntl - 1);
+        // the last prefetch has no consumer, but its destination registers must stay reserved until the data has landed:
+        // a dead destination is handed to the next value at once, and the read then lands on top of that value
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(ci0[0]), "+v"(ci0[1]), "+v"(ci0[2]),
+                     "+v"(ci0[3])::"memory");
     }
-    if (c.grp == 1) merge_tile(c, c.ntl - 1);
+#undef DVQ_MF0
+#undef DVQ_MF1
+#undef DVQ_SB
+#undef DVQ_WAITF
+#undef DVQ_PIN2
+#undef DVQ_RDF
+#undef DVQ_STAMP
+    // drain: the prefetched fragments / start values of a tile that does not exist are dropped; last scores, last merges
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (c.ntl >= 1) {
+        score<0, 16>(acc1, 16, m1, m2);
+        write_slot(c, c.ntl - 1, m1, m2);
+    }
+    if (c.ntl >= 2) {
+        mg.read(c, c.ntl - 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mg.sl), "+v"(mg.rs));
+        mg.min_a(); mg.min_b(c); mg.act(c, c.ntl - 2);
+    }
+    wg_barrier();
+    if (c.ntl >= 1) {
+        mg.read(c, c.ntl - 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mg.sl), "+v"(mg.rs));
+        mg.min_a(); mg.min_b(c); mg.act(c, c.ntl - 1);
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
@@ -684,8 +1049,15 @@ extern "C" int dvq_vq_argmin_fast(const float* z, const float* E, const void* pa
     hipStream_t st = (hipStream_t)stream;
     static DvqOncePerDevice attr_once;
     if (attr_once.first()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vq_stream_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipSuccess;
+        for (const void* fn : {(const void*)&vq_stream_kernel<0, false>, (const void*)&vq_stream_kernel<0, true>,
+                               (const void*)&vq_stream_kernel<1, true>, (const void*)&vq_stream_kernel<2, true>,
+                               (const void*)&vq_stream_kernel<4, true>, (const void*)&vq_stream_kernel<8, true>,
+                               (const void*)&vq_stream_kernel<16, true>, (const void*)&vq_stream_kernel<32, true>,
+                               (const void*)&vq_stream_kernel<15, true>, (const void*)&vq_stream_kernel<47, true>}) {
+            const hipError_t e1 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            if (e1 != hipSuccess) e = e1;
+        }
         if (e != hipSuccess) {
             dvq_set_error("vq_argmin_fast: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return DVQ_ELAUNCH;
@@ -696,12 +1068,29 @@ extern "C" int dvq_vq_argmin_fast(const float* z, const float* E, const void* pa
     const long tiles = (M + TILE - 1) / TILE;
     const long per_launch = (long)cus * MAX_TILES;                 // one workgroup per CU, <= MAX_TILES tiles each
     const bool want_dbg = getenv("DVQ_VQ_DBG") != nullptr;
+    const char* abl_s = getenv("DVQ_VQ_ABL");                      // diagnostics only (timing of ablated variants)
+    const int abl = abl_s ? atoi(abl_s) : 0;
     DVQ_PROF("vq_argmin_fast", 2.0 * M * K * D, (double)M * D * 4 + (double)K * D * 4 + (double)M * 8, st);
     for (long t0 = 0; t0 < tiles; t0 += per_launch) {
         const long nt = (tiles - t0 < per_launch) ? tiles - t0 : per_launch;
         const unsigned grid = (unsigned)(nt < cus ? nt : cus);
-        DVQ_LAUNCH(vq_stream_kernel, dim3(grid), dim3(NT), LDS_BYTES, st, z, E, (long)M, t0, nt, pk, idx, slow_rows,
-                   (want_dbg && t0 == 0) ? (unsigned long long*)workspace : nullptr);
+        unsigned long long* dbgp = (want_dbg && t0 == 0) ? (unsigned long long*)workspace : nullptr;
+#define DVQ_VQ_GO(A) DVQ_LAUNCH((vq_stream_kernel<A, true>), dim3(grid), dim3(NT), LDS_BYTES, st, z, E, (long)M, t0, nt, pk, idx, slow_rows, dbgp)
+        switch (abl) {
+            case 1: DVQ_VQ_GO(1); break;
+            case 2: DVQ_VQ_GO(2); break;
+            case 4: DVQ_VQ_GO(4); break;
+            case 8: DVQ_VQ_GO(8); break;
+            case 16: DVQ_VQ_GO(16); break;
+            case 32: DVQ_VQ_GO(32); break;
+            case 15: DVQ_VQ_GO(15); break;
+            case 47: DVQ_VQ_GO(47); break;
+            default:
+                if (dbgp) DVQ_VQ_GO(0);
+                else DVQ_LAUNCH((vq_stream_kernel<0, false>), dim3(grid), dim3(NT), LDS_BYTES, st, z, E, (long)M, t0, nt, pk, idx, slow_rows, dbgp);
+                break;
+        }
+#undef DVQ_VQ_GO
         DVQ_CHECK_LAUNCH("vq_stream");
     }
     return DVQ_OK;

@@ -52,15 +52,11 @@ print("refine tail dur med/max:", np.median(rel[:, 3] - rel[:, 2]), (rel[:, 3] -
 print("end  min/med/max us:", rel[:, 3].min(), np.median(rel[:, 3]), rel[:, 3].max())
 tot, nov = full[:, 4], full[:, 5]
 print("pairs per WG mean/max:", tot.mean(), tot.max(), " slow rows total:", nov.sum(), " WGs with slow rows:", (nov > 0).sum())
-# in-loop stamps (shader clock, 32-bit): slots 0 iteration start, 1 after mfma, 2 after the barrier in front of / behind it,
-# 3 after score, 4 after the DMA wait + LDS read of convert, 5 after convert, 6 after merge, 7 iteration end
-def d(a, b, grp, tile):
-    w = slice(0, 4) if grp == 0 else slice(4, 8)
-    v = ((st[:, w, tile, b] - st[:, w, tile, a]) & 0xffffffff).reshape(-1)
+# in-loop stamps (shader clock, 32-bit) of the pipelined iteration: 0 start, 1 after gap 7, 2 in front of the barrier (gap 24),
+# 3 behind it, 4 end of the iteration
+def d(a, b, tile):
+    v = ((st[:, :, tile, b] - st[:, :, tile, a]) & 0xffffffff).reshape(-1)
     return f"{np.median(v):7.0f} /{np.percentile(v, 90):7.0f}"
 for tile, name in ((0, "t=2"), (1, "t=5")):
-    print(f"-- iteration {name}: median / p90 shader cycles")
-    print("  grp0: mfma", d(0, 1, 0, tile), " barrier", d(1, 2, 0, tile), " score", d(2, 3, 0, tile), " cvt wait+read", d(3, 4, 0, tile),
-          " cvt body", d(4, 5, 0, tile), " merge", d(5, 6, 0, tile), " barrier", d(6, 7, 0, tile), " total", d(0, 7, 0, tile))
-    print("  grp1: score", d(0, 3, 1, tile), " cvt wait+read", d(3, 4, 1, tile), " cvt body", d(4, 5, 1, tile), " merge", d(5, 6, 1, tile),
-          " barrier", d(6, 2, 1, tile), " mfma", d(2, 1, 1, tile), " barrier", d(1, 7, 1, tile), " total", d(0, 7, 1, tile))
+    print(f"-- iteration {name}: median / p90 shader cycles:  gaps 0-7", d(0, 1, tile), " gaps 8-23", d(1, 2, tile), " barrier", d(2, 3, tile),
+          " gaps 24-31", d(3, 4, tile), " total", d(0, 4, tile))
