@@ -2,19 +2,19 @@
 // (vq.hip / oracle/vq_canonical.c), bit for bit, with z streamed from HBM exactly once UNDER the matrix work.
 // Reference: VectorQuantizer.forward(z, istrain=False), network/vqvae/quantizer.py:46-49.
 //
-// Structure (persistent, codebook in registers, z through LDS):
+// Structure (persistent, codebook in registers, z through registers and one fp16 LDS tile):
 //   * one 512-thread workgroup per CU walks over up to 8 tiles of 32 rows (tile = blockIdx + j * gridDim);
 //   * wave w keeps codebook entries [64w, 64w+64) -- fp16 of -2 sE e_k, all 256 dims -- as the MFMA A operand in
 //     128 VGPRs for the whole kernel (8 waves x 64 entries = the whole codebook, 256 KB of the CU's 512 KB of VGPRs);
-//   * a tile's 32 fp32 rows arrive HBM -> LDS by global_load_lds (whole 1 KiB rows, 3-deep ring = 96 KB, each wave owns
-//     4 rows so only its own vmcnt orders the hand-off), are converted to fp16 ONCE (each wave its 4 rows: |z|^2, the
-//     measured rounding error |z - h(z)|, eps_row) and written to a padded fp16 tile (528-byte rows: conflict-free
+//   * each wave owns 4 rows of every tile: it loads them HBM -> registers two tiles ahead (16 lanes per row, 16 floats
+//     per lane: 256-byte segments, two alternating register sets), converts them to fp16 ONCE (|h(z)|^2, the measured
+//     rounding error |z - h(z)|, eps_row) and writes them to a padded fp16 tile in LDS (528-byte rows: conflict-free
 //     ds_read_b128 fragments with one address register and immediate offsets);
 //   * every wave multiplies the tile with its 64 entries: 16 fragment reads feed 32 v_mfma_f32_32x32x16_f16, the
 //     accumulators START at sE |e_k|^2 (read from LDS straight into the accumulator registers), so they END as the
 //     scores sE (|e_k|^2 - 2 z.e_k): no per-score arithmetic beyond id packing and a lane-local top-2 (3 VALU per score);
-//   * the two waves of a SIMD (w, w+4) run half a tile apart -- one in its matrix phase while the other scores /
-//     converts / merges -- separated by s_barrier (the matrix pipe and the vector issue of a SIMD are shared);
+//   * the loop is software-pipelined by hand: the 32 MFMA gaps of tile t carry the scores of tile t-1 / t, the merge of
+//     tile t-2, the conversion of tile t+1 and the loads of tile t+3; one s_barrier per tile;
 //   * per tile, 16 (wave, lane-half) slots per row hold (min, second) packed scores; the merge finds the row minimum,
 //     the slots within eps_row of it, and either decides the row or appends (row, entry) pairs to a list;
 //   * after the last tile: the canonical fp32 evaluation d_k = (zz + ee_k) - 2 dot_k (k-ordered fmaf chains, four lanes
@@ -23,15 +23,24 @@
 //
 // Error bound (filter keeps the exact winner).  No per-row scaling: h(.) = round to fp16 with subnormals flushed (MODE
 // register: the conversion instruction flushes, so what the matrix core sees is what the error was measured on).
-// With dz_j = z_j - h(z_j), de_kj = e_kj - h(-2 sE e_kj)/(-2 sE) (exact in fp32), products h.h exact in the MFMA's fp32:
-//   |S_k/sE - (true_k - |z|^2)| <= 2 (|dz||e_k| + |z||de_k| + |dz||de_k|) + gamma'_259 (|e_k|^2 + 2|z||e_k|)    (filter)
-//   |d_k - true_k|              <= gamma_260 (|z| + |e_k|)^2                                                   (exact side)
-//   |packed(S_k) - S_k|         <= 2^-18 |S_k|                                                  (5-bit id in the mantissa)
-// hence packed(S_k*) <= min_k packed(S_k) + sE eps_row with
-//   eps_row = 4 (|dz| Emax + |z| dEmax + |dz| dEmax) + (2^-13 + 2^-14) (|z| + Emax)^2,
-// |dz| measured by the kernel's own conversion, dEmax by dvq_vq_pack, norms rounded up.  A slot whose SECOND score is
-// within eps may hide a third: all 32 entries of that slot are listed, so the list always contains the exact winner.
+// With dz_j = z_j - h(z_j), de_kj = e_kj - h(-2 sE e_kj)/(-2 sE) (exact in fp32), products h.h exact in the MFMA's fp32,
+// T_k = sE (true_k - |z|^2), gamma_n = n 2^-24 (gamma'_n = n 2^-23 allows a truncating accumulator):
+//   |S_k - T_k|         <= sE [2 (|dz||e_k| + |z||de_k| + |dz||de_k|) + gamma'_259 (|e_k|^2 + 2|z||e_k|)]          (filter)
+//   |d_k - true_k|      <= gamma_260 (|z| + |e_k|)^2                                                            (exact side)
+//   |packed(S_k) - S_k| <= 2^-18 |S_k| <= 2^-18 sE (|z| + |e_k|)^2                                 (5-bit id in the mantissa)
+// so for the canonical winner k* and every k:  packed(S_k*) <= packed(S_k) + sE eps_row,
+//   eps_row = 4 (|dz| Emax + |z| dEmax + |dz| dEmax) + (2 gamma'_259 + 2^-17 + 2 gamma_260 = 9.97e-5) (|z| + Emax)^2,
+// |dz| measured by the kernel's own conversion, |z| <= |h(z)| + |dz|, dEmax by dvq_vq_pack, norms rounded up.  A slot whose
+// SECOND score is within eps may hide a third: all 32 entries of that slot are listed, so the list always contains k*.
 // Algorithmic HBM bytes per row: D*4 (z) + 8 (int64 index); the codebook (K*D*4) is read once.
+//
+// Hand-issued LDS reads (inline asm + counted s_waitcnt) carry three rules, each learnt from a wrong result:
+//   (1) the destination of a read is "defined" for the compiler at the asm statement: it must not be copied or reused before
+//       the wait -- so no such read is in flight across a control-flow join (the loop is rotated: joins sit behind the
+//       barrier's lgkmcnt(0)), and a read whose value is never used is still pinned by the wait that completes it;
+//   (2) vector work placed in an MFMA gap is anchored there by an empty asm that uses its result (else the compiler
+//       sinks it to the end of the loop body, behind every MFMA);
+//   (3) __builtin_bit_cast applied directly to a vector-element expression reads element 0: copy the element out first.
 #include "dvq_internal.h"
 #include <type_traits>
 
@@ -46,7 +55,6 @@ constexpr int NWV = 8;                             // waves per workgroup = 64-e
 constexpr int NT = 64 * NWV;                       // 512 threads, one workgroup per CU
 constexpr int TILE = 32;                           // rows per tile
 constexpr int MAX_TILES = 8;                       // tiles per workgroup per launch (row-result table, slow list)
-constexpr int RING = 3;                            // fp32 staging ring depth (tiles)
 constexpr int EXP_LIMIT = 40;                      // |log2(max codebook magnitude)| beyond this -> exact fallback
 
 constexpr int Z16_ROW = 528;                       // padded fp16 row: 512 B + 16 B (shifts consecutive rows by one bank group)
@@ -55,8 +63,7 @@ constexpr int MS_ROW = 136;                        // merge slots of a row: 16 x
 constexpr int MS_BUF = TILE * MS_ROW;              // 4 352
 constexpr int PAIR_CAP = 2048;
 
-constexpr int L_RING = 0;                                  // RING x 32 KB fp32 tiles
-constexpr int L_Z16 = L_RING + RING * TILE * D * 4;        // 2 x fp16 tile
+constexpr int L_Z16 = 0;                                   // 2 x fp16 tile
 constexpr int L_MS = L_Z16 + 2 * Z16_BUF;                  // 2 x merge slots
 constexpr int L_RS = L_MS + 2 * MS_BUF;                    // 4 x [32] {eps sE, flag}
 constexpr int L_EES = L_RS + 4 * TILE * 8;                 // [K] f32: sE |e_k|^2 (accumulator start values)
@@ -157,9 +164,9 @@ __global__ void vq_pack_err_kernel(const float* __restrict__ E, const _Float16* 
 }
 
 // ------------------------------------------------------------------------------------------------ LDS access by hand
-// Every LDS access between the first LDS-DMA issue and the end of the tile loop is inline asm: the compiler cannot tell
-// which LDS bytes a pending global_load_lds will write and would put s_waitcnt vmcnt(0) in front of each access it sees,
-// which serialises the HBM stream with the compute.  Waits are by count; the "+v" operands pin the consumers below them.
+// The tile loop's LDS reads are inline asm with counted waits (the compiler's own waits are lgkmcnt(0) at every use: it
+// cannot keep four fragment reads in flight behind the one an MFMA needs).  The "+v" operands of a wait pin the consumers
+// below it.  See the three rules in the file header.
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(unsigned long)(const __attribute__((address_space(3))) char*)p;
 }
@@ -185,8 +192,7 @@ __device__ __forceinline__ unsigned ds_add_rtn(unsigned a, unsigned v) {
     asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(a), "v"(v) : "memory");
     return r;
 }
-#define DVQ_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-__device__ __forceinline__ void wg_barrier() {                    // LDS writes of this wave done, then the workgroup barrier; VMEM stays in flight
+__device__ __forceinline__ void wg_barrier() {                    // LDS operations of this wave done, then the workgroup barrier; VMEM stays in flight
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
@@ -202,14 +208,8 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += dpp_f<0x140>(v);
     return v;
 }
-__device__ __forceinline__ float min_nc(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -3.0e38f); }   // one instruction (fminf adds a canonicalising v_max); in-range scores are far above -3e38
-__device__ __forceinline__ float row16_min(float v) {
-    v = min_nc(v, dpp_f<0xB1>(v));
-    v = min_nc(v, dpp_f<0x4E>(v));
-    v = min_nc(v, dpp_f<0x141>(v));
-    v = min_nc(v, dpp_f<0x140>(v));
-    return v;
-}
+// one instruction (fminf adds a canonicalising v_max); in-range scores are far above -3e38
+__device__ __forceinline__ float min_nc(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, -3.0e38f); }
 
 // entry of accumulator register i (0..15) of entry tile jn, lane half h, wave w (v_mfma_f32_32x32x16 D layout)
 __device__ __forceinline__ int entry_of(int w, int jn, int i, int h) { return 64 * w + 32 * jn + 8 * (i >> 2) + 4 * h + (i & 3); }
@@ -275,216 +275,36 @@ __device__ __forceinline__ void chain_pair(const float* __restrict__ zr, const f
     dot = b;
 }
 
-// ------------------------------------------------------------------------------------------------ the kernel's phases
+// ------------------------------------------------------------------------------------------------ the kernel's pieces
 struct Ctx {
     const float* z;
     long M;
     long tile0;          // first tile of this launch
     int G;               // workgroups (tile stride)
     int ntl;             // tiles of this workgroup
-    int wave, lane, grp; // grp: 0 = waves 0-3 (matrix phase first), 1 = waves 4-7 (half a tile later)
+    int wave, lane;
     unsigned lds0;       // LDS byte address of the dynamic segment
     float emax, demax, sEf;
     bool e_valid;
-    bool dbg;            // DVQ_VQ_DBG: phase stamps of two tiles go to LDS (and from there to the workspace)
 };
 
-// shader-clock stamp `slot` of this wave (tiles 2 and 5 only: slots 0-15 / 16-31)
+// shader-clock stamp `slot` of this wave (tiles 2 and 5 only: slots 0-15 / 16-31); DVQ_VQ_DBG instantiation only
 __device__ __forceinline__ void stamp(const Ctx& c, int t, int slot) {
-    if (c.dbg && (t == 2 || t == 5)) {
+    if (t == 2 || t == 5) {
         const unsigned v = (unsigned)__builtin_amdgcn_s_memtime();
         if (c.lane == 0) ds_wr32(c.lds0 + L_DBG + (c.wave * 32 + (t == 5 ? 16 : 0) + slot) * 4, v);
     }
 }
 
-// DMA the wave's 4 rows of local tile j into ring slot j % RING
-__device__ __forceinline__ void issue_tile(const Ctx& c, int j, char* lds) {
+// this wave's 4 rows of local tile j, HBM -> registers: lane (g = lane / 16, i = lane % 16) takes floats 4 (i + 16 q) .. +3 of
+// row 4 wave + g, q = 0..3 (per instruction four 256-byte segments); rows behind the end of the data repeat the last row
+__device__ __forceinline__ void load_rows(const Ctx& c, int j, f32x4 (&x)[4]) {
     const long tile = c.tile0 + (long)blockIdx.x + (long)j * c.G;
-    char* dst = lds + L_RING + (j % RING) * (TILE * D * 4) + (c.wave * 4) * 1024;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        long gr = tile * TILE + c.wave * 4 + q;
-        if (gr >= c.M) gr = c.M - 1;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(c.z + gr * D + 4 * c.lane),
-                                         (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
-    }
-}
-
-// fp32 -> fp16 conversion of the wave's 4 rows of local tile j (16 lanes per row, 16 floats per lane), row statistics.
-// wait for this wave's DMAs of local tile j: they (and everything issued before them) are the oldest outstanding
-// vector-memory operations of the wave; younger: the DMAs of tiles j+1 and j+2 (if those tiles exist)
-__device__ __forceinline__ void wait_tile(const Ctx& c, int j) {
-    const int younger = (j + 2 < c.ntl) ? 8 : (j + 1 < c.ntl) ? 4 : 0;
-    if (younger == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (younger == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-__device__ __forceinline__ void convert_tile(const Ctx& c, int j, char* lds, bool waited = false) {
-    const int g = c.lane >> 4, i = c.lane & 15;
-    const int row_t = c.wave * 4 + g;
-    if (!waited) wait_tile(c, j);
-    const unsigned ra = c.lds0 + L_RING + (j % RING) * (TILE * D * 4) + row_t * 1024 + 16 * i;
-    f32x4 x[4];
-    ds_rd128<0>(x[0], ra);
-    ds_rd128<256>(x[1], ra);
-    ds_rd128<512>(x[2], ra);
-    ds_rd128<768>(x[3], ra);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
-    if (j + RING < c.ntl) issue_tile(c, j + RING, lds);          // the slot's bytes are in registers: refill it
-    float ss = 0.f, dsq = 0.f;
-    const unsigned wa = c.lds0 + L_Z16 + (j & 1) * Z16_BUF + row_t * Z16_ROW + 8 * i;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f16x2 lo, hi;
-        lo[0] = (_Float16)x[q][0]; lo[1] = (_Float16)x[q][1];
-        hi[0] = (_Float16)x[q][2]; hi[1] = (_Float16)x[q][3];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float hv = (float)(e < 2 ? lo[e] : hi[e - 2]);
-            const float d = x[q][e] - hv;                            // exact
-            ss = fmaf(x[q][e], x[q][e], ss);
-            dsq = fmaf(d, d, dsq);
-        }
-        f32x2 pk;
-        pk[0] = __builtin_bit_cast(float, lo);
-        pk[1] = __builtin_bit_cast(float, hi);
-        if (q == 0) ds_wr64<0>(wa, pk);
-        else if (q == 1) ds_wr64<128>(wa, pk);
-        else if (q == 2) ds_wr64<256>(wa, pk);
-        else ds_wr64<384>(wa, pk);
-    }
-    ss = row16_sum(ss);
-    dsq = row16_sum(dsq);
-    const float zn = __builtin_amdgcn_sqrtf(ss) * 1.0001f;
-    const float dzn = __builtin_amdgcn_sqrtf(dsq) * 1.0001f;
-    const float eps = 4.004f * (dzn * c.emax + zn * c.demax + dzn * c.demax) + 0.00018311f * (zn + c.emax) * (zn + c.emax);
-    const float epsS = eps * c.sEf;
-    const bool bad = !c.e_valid || !(ss <= 3.0e38f) || !(dsq <= 3.0e38f) || !(epsS <= 3.0e38f);   // NaN/Inf, fp16 overflow
-    if (i == 0) {
-        f32x2 rs;
-        rs[0] = epsS;
-        rs[1] = __uint_as_float(bad ? 1u : 0u);
-        ds_wr64<0>(c.lds0 + L_RS + (j & 3) * (TILE * 8) + row_t * 8, rs);
-    }
-}
-
-// matrix phase of local tile t: accumulators start at sE |e_k|^2, 16 fragment reads, 32 MFMAs
-__device__ __forceinline__ void mfma_tile(const Ctx& c, int t, const f16x8 (&af)[2][16], f32x16 (&acc)[2]) {
-    const int r = c.lane & 31, h = c.lane >> 5;
-    const unsigned ea = c.lds0 + L_EES + (64 * c.wave + 4 * h) * 4;
-    const unsigned za = c.lds0 + L_Z16 + (t & 1) * Z16_BUF + r * Z16_ROW + 16 * h;
-    f32x4 ci[2][4];
-    ds_rd128<0>(ci[0][0], ea);   ds_rd128<32>(ci[0][1], ea);  ds_rd128<64>(ci[0][2], ea);  ds_rd128<96>(ci[0][3], ea);
-    ds_rd128<128>(ci[1][0], ea); ds_rd128<160>(ci[1][1], ea); ds_rd128<192>(ci[1][2], ea); ds_rd128<224>(ci[1][3], ea);
-    f16x8 bf[16];
-    constexpr int PF = 4;
-    ds_rd128<0>(bf[0], za); ds_rd128<32>(bf[1], za); ds_rd128<64>(bf[2], za); ds_rd128<96>(bf[3], za);
-    // the 8 start-value reads are older than every fragment read: waiting for fragment 0 covers them
-    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(ci[0][0]), "+v"(ci[0][1]), "+v"(ci[0][2]), "+v"(ci[0][3]), "+v"(ci[1][0]),
-                 "+v"(ci[1][1]), "+v"(ci[1][2]), "+v"(ci[1][3]), "+v"(bf[0]));
-#pragma unroll
-    for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[jn][4 * q + e] = ci[jn][q][e];
-#define DVQ_STEP(S, YOUNGER)                                                                                    \
-    {                                                                                                           \
-        if (S + PF < 16) ds_rd128<32 * ((S + PF) & 15)>(bf[(S + PF) & 15], za);                                 \
-        if (S > 0) asm volatile("s_waitcnt lgkmcnt(" #YOUNGER ")" : "+v"(bf[S]));                               \
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][S], bf[S], acc[0], 0, 0, 0);                      \
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][S], bf[S], acc[1], 0, 0, 0);                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
-    }
-    // YOUNGER = fragment reads issued after fragment S at the point of the wait = min(PF, 15 - S)
-    DVQ_STEP(0, 4) DVQ_STEP(1, 4) DVQ_STEP(2, 4) DVQ_STEP(3, 4) DVQ_STEP(4, 4) DVQ_STEP(5, 4) DVQ_STEP(6, 4) DVQ_STEP(7, 4)
-    DVQ_STEP(8, 4) DVQ_STEP(9, 4) DVQ_STEP(10, 4) DVQ_STEP(11, 4) DVQ_STEP(12, 3) DVQ_STEP(13, 2) DVQ_STEP(14, 1) DVQ_STEP(15, 0)
-#undef DVQ_STEP
-}
-
-// scores of local tile t: 5-bit id into the low mantissa bits, lane-local (min, second), one 8-byte slot per (wave, lane half)
-__device__ __forceinline__ void score_tile(const Ctx& c, int t, const f32x16 (&acc)[2]) {
-    const int r = c.lane & 31, h = c.lane >> 5;
-    float m1 = INFINITY, m2 = INFINITY;
-#pragma unroll
-    for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float p = __uint_as_float((__float_as_uint(acc[jn][i]) & ~31u) | (unsigned)(16 * jn + i));
-            m2 = __builtin_amdgcn_fmed3f(m1, m2, p);
-            m1 = min_nc(m1, p);
-        }
-    f32x2 v;
-    v[0] = m1;
-    v[1] = m2;
-    ds_wr64<0>(c.lds0 + L_MS + (t & 1) * MS_BUF + r * MS_ROW + (2 * c.wave + h) * 8, v);
-}
-
-// merge of local tile tm: this wave's 4 rows (16 slots each), rows 16 grp + 4 (wave & 3) + g
-__device__ __forceinline__ void merge_tile(const Ctx& c, int tm) {
-    const int g = c.lane >> 4, i = c.lane & 15;
-    const int r = 16 * c.grp + 4 * (c.wave & 3) + g;
-    f32x2 sl, rs;
-    ds_rd64<0>(sl, c.lds0 + L_MS + (tm & 1) * MS_BUF + r * MS_ROW + i * 8);
-    ds_rd64<0>(rs, c.lds0 + L_RS + (tm & 3) * (TILE * 8) + r * 8);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sl), "+v"(rs));
-    const float m1 = sl[0], m2 = sl[1];
-    const float rmin = row16_min(m1);
-    const float thr = rmin + rs[0];
-    const bool bad = __float_as_uint(rs[1]) != 0u;
-    const bool c1 = m1 <= thr, c2 = m2 <= thr;
-    const unsigned long long b1 = __ballot(c1), b2 = __ballot(c2);
-    const unsigned s1 = (unsigned)(b1 >> (16 * g)) & 0xffffu, s2 = (unsigned)(b2 >> (16 * g)) & 0xffffu;
-    const int n1 = __popc(s1), n2 = __popc(s2);
-    const long grow = (c.tile0 + (long)blockIdx.x + (long)tm * c.G) * TILE + r;
-    const bool live = grow < c.M;
-    const unsigned rowslot = (unsigned)(tm * TILE + r);
-    const int w_src = i >> 1, h_src = i & 1;
-    const bool slow = bad || n1 == 0;
-    const bool unique = !slow && n1 == 1 && n2 == 0;
-    const bool amb = live && !slow && !unique;
-    // one reservation per ambiguous row (leader lane i == 0): single candidates take one pair, a slot whose second score
-    // is within eps takes all its 32 entries
-    const int need = (n1 - n2) + 32 * n2;
-    unsigned pos = 0;
-    if (amb && i == 0) pos = ds_add_rtn(c.lds0 + L_CNT, (unsigned)need);
-    pos = (unsigned)__builtin_amdgcn_readlane((int)pos, 0) * (g == 0) + (unsigned)__builtin_amdgcn_readlane((int)pos, 16) * (g == 1) +
-          (unsigned)__builtin_amdgcn_readlane((int)pos, 32) * (g == 2) + (unsigned)__builtin_amdgcn_readlane((int)pos, 48) * (g == 3);
-    const bool fits = pos + (unsigned)need <= (unsigned)PAIR_CAP;
-    if (live && unique && c1) {
-        const unsigned id = __float_as_uint(m1) & 31u;
-        const unsigned k = (unsigned)entry_of(w_src, id >> 4, id & 15, h_src);
-        f32x2 kv;
-        kv[0] = __uint_as_float(k);
-        kv[1] = __uint_as_float(0u);
-        ds_wr64<0>(c.lds0 + L_RES + rowslot * 8, kv);
-    }
-    if (amb && fits && c1) {
-        const unsigned lt = (1u << i) - 1u;
-        const unsigned off = pos + (unsigned)__popc(s1 & ~s2 & lt) + 32u * (unsigned)__popc(s2 & lt);
-        if (c2) {
-            for (int e = 0; e < 32; ++e)
-                ds_wr32(c.lds0 + L_PAIR + (off + e) * 4, (rowslot << 16) | (unsigned)entry_of(w_src, e >> 4, e & 15, h_src));
-        } else {
-            const unsigned id = __float_as_uint(m1) & 31u;
-            ds_wr32(c.lds0 + L_PAIR + off * 4, (rowslot << 16) | (unsigned)entry_of(w_src, id >> 4, id & 15, h_src));
-        }
-    }
-    if (live && i == 0 && (slow || (amb && !fits))) {
-        const unsigned sp = ds_add_rtn(c.lds0 + L_CNT + 4, 1u);
-        ds_wr16(c.lds0 + L_SLOW + sp * 2, rowslot);
-    }
-}
-
-// one of the wave's 4 row DMAs of local tile j (the pipelined loop spreads them over four MFMA gaps)
-__device__ __forceinline__ void issue_row(const Ctx& c, int j, int q, char* lds) {
-    const long tile = c.tile0 + (long)blockIdx.x + (long)j * c.G;
-    char* dst = lds + L_RING + (j % RING) * (TILE * D * 4) + (c.wave * 4 + q) * 1024;
-    long gr = tile * TILE + c.wave * 4 + q;
+    long gr = tile * TILE + c.wave * 4 + (c.lane >> 4);
     if (gr >= c.M) gr = c.M - 1;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(c.z + gr * D + 4 * c.lane),
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    const f32x4* p = reinterpret_cast<const f32x4*>(c.z + gr * D) + (c.lane & 15);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) x[q] = __builtin_nontemporal_load(p + 16 * q);
 }
 
 // scores of accumulator registers [B, E): id = idbase + register index in the low 5 mantissa bits, top-2 update
@@ -516,44 +336,34 @@ __device__ __forceinline__ float mix_diff(float hp, float x) {
 
 // fp32 -> fp16 conversion of the wave's 4 rows of a tile in pieces (the pipelined loop puts one piece into each MFMA gap)
 struct Convert {
-    f32x4 x[4];
-    float ss, dsq;
+    float hh, dsq;                                                     // sum h(z)^2, sum (z - h(z))^2
     f32x2 pk;
-    __device__ __forceinline__ void read(const Ctx& c, int j) {          // after wait_tile(c, j)
-        const int g = c.lane >> 4, i = c.lane & 15;
-        const unsigned ra = c.lds0 + L_RING + (j % RING) * (TILE * D * 4) + (c.wave * 4 + g) * 1024 + 16 * i;
-        ds_rd128<0>(x[0], ra);
-        ds_rd128<256>(x[1], ra);
-        ds_rd128<512>(x[2], ra);
-        ds_rd128<768>(x[3], ra);
-        ss = 0.f;
-        dsq = 0.f;
-    }
+    __device__ __forceinline__ void start() { hh = 0.f; dsq = 0.f; }
     template <int Q>
-    __device__ __forceinline__ void cvt(const Ctx& c, int j) {           // quad Q: convert, store into the fp16 image of tile j
+    __device__ __forceinline__ void cvt(const Ctx& c, int j, const f32x4 (&x)[4]) {   // quad Q: convert, store into the fp16 image of tile j
         const int g = c.lane >> 4, i = c.lane & 15;
         f32x2 a, b;
         a[0] = x[Q][0]; a[1] = x[Q][1]; b[0] = x[Q][2]; b[1] = x[Q][3];
         const f16x2 lo = __builtin_convertvector(a, f16x2), hi = __builtin_convertvector(b, f16x2);
+        hh = __builtin_amdgcn_fdot2(lo, lo, hh, false);
+        hh = __builtin_amdgcn_fdot2(hi, hi, hh, false);
         pk[0] = __builtin_bit_cast(float, lo);
         pk[1] = __builtin_bit_cast(float, hi);
         ds_wr64<128 * Q>(c.lds0 + L_Z16 + (j & 1) * Z16_BUF + (c.wave * 4 + g) * Z16_ROW + 8 * i, pk);
     }
     template <int Q>
-    __device__ __forceinline__ void err(float lo_hi0, float lo_hi1) {   // sums of squares of quad Q (pk of that quad)
+    __device__ __forceinline__ void err(float lo_hi0, float lo_hi1, const f32x4 (&x)[4]) {   // rounding error of quad Q (pk of that quad)
         const float d0 = mix_diff<0>(lo_hi0, x[Q][0]), d1 = mix_diff<1>(lo_hi0, x[Q][1]);
         const float d2 = mix_diff<0>(lo_hi1, x[Q][2]), d3 = mix_diff<1>(lo_hi1, x[Q][3]);
-        ss = fmaf(x[Q][0], x[Q][0], ss); ss = fmaf(x[Q][1], x[Q][1], ss);
-        ss = fmaf(x[Q][2], x[Q][2], ss); ss = fmaf(x[Q][3], x[Q][3], ss);
         dsq = fmaf(d0, d0, dsq); dsq = fmaf(d1, d1, dsq); dsq = fmaf(d2, d2, dsq); dsq = fmaf(d3, d3, dsq);
     }
-    __device__ __forceinline__ void finish(const Ctx& c, int j) {        // ss, dsq already reduced over the row's 16 lanes
+    __device__ __forceinline__ void finish(const Ctx& c, int j) {        // hh, dsq already reduced over the row's 16 lanes
         const int g = c.lane >> 4, i = c.lane & 15;
-        const float zn = __builtin_amdgcn_sqrtf(ss) * 1.0001f;
         const float dzn = __builtin_amdgcn_sqrtf(dsq) * 1.0001f;
-        const float eps = 4.004f * (dzn * c.emax + zn * c.demax + dzn * c.demax) + 0.00018311f * (zn + c.emax) * (zn + c.emax);
+        const float zn = (__builtin_amdgcn_sqrtf(hh) + dzn) * 1.0001f;  // |z| <= |h(z)| + |z - h(z)|
+        const float eps = 4.004f * (dzn * c.emax + zn * c.demax + dzn * c.demax) + 1.01e-4f * (zn + c.emax) * (zn + c.emax);
         const float epsS = eps * c.sEf;
-        const bool bad = !c.e_valid || !(ss <= 3.0e38f) || !(dsq <= 3.0e38f) || !(epsS <= 3.0e38f);   // NaN/Inf, fp16 overflow
+        const bool bad = !c.e_valid || !(hh <= 3.0e38f) || !(dsq <= 3.0e38f) || !(epsS <= 3.0e38f);   // NaN/Inf, fp16 overflow
         if (i == 0) {
             f32x2 rs;
             rs[0] = epsS;
@@ -638,8 +448,8 @@ struct Merge {
     }
 };
 
-// ABL: timing-only ablations for diagnostics (DVQ_VQ_ABL; results invalid unless 0): 1 no DMA wait/issue, 2 no conversion,
-// 4 no merge, 8 no scoring, 16 no MFMA, 32 no barrier in the loop
+// ABL: timing-only ablations for diagnostics (DVQ_VQ_ABL; results invalid unless 0): 1 no row loads, 2 no conversion,
+// 4 no merge, 8 no scoring, 16 no MFMA, 32 no barrier in the loop.  DBG: phase stamps (DVQ_VQ_DBG).
 template <int ABL, bool DBG>
 __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restrict__ z, const float* __restrict__ E, long M,
                                                           long tile0, long n_tiles, const char* __restrict__ packed,
@@ -656,57 +466,54 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
     c.ntl = (int)((n_tiles - (long)blockIdx.x + c.G - 1) / c.G);          // blockIdx.x < n_tiles by construction
     c.lane = tid & 63;
     c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    c.grp = c.wave >> 2;
     c.lds0 = lds_addr(lds);
-    c.dbg = dbg != nullptr;
     const float* ee_g = reinterpret_cast<const float*>(packed + PK_OFF_EE);
     // fp16 subnormals flush to zero in conversions (MODE.FP_DENORM[3:2] = 0): the rounding error is measured on exactly
     // the values the matrix core multiplies (measured on gfx950: the MFMA keeps fp16 subnormal inputs; this does not rely on it)
     __builtin_amdgcn_s_setreg((2 - 1) << 11 | 6 << 6 | 1, 0);            // hwreg(HW_REG_MODE, offset 6, width 2) <- 0
 
-    // ---- prologue.  Vector-memory issue order: tile 0, the codebook slice (128 VGPRs), |e|^2, the header, tiles 1..RING-1.
-    // All by hand (inline asm / LDS-DMA), completed by wait_tile(0)'s counted wait: a compiler-visible load would be waited
-    // for with vmcnt(0) at its first use, i.e. together with every tile in flight.
+    // ---- prologue: the first two tiles and the codebook slice on their way, tables into LDS, tile 0 converted
+    f32x4 x0[4], x1[4];                                                // fp32 rows of the even / odd tiles in flight
+    if (!(ABL & 1)) {
+        load_rows(c, 0, x0);
+        if (c.ntl > 1) load_rows(c, 1, x1);
+    }
+    f16x8 af[2][16];
+    {
+        const f16x8* img = reinterpret_cast<const f16x8*>(packed + PK_OFF_IMG) + (size_t)c.wave * (32 * 64) + c.lane;
+#pragma unroll
+        for (int f = 0; f < 32; ++f) af[f >> 4][f & 15] = img[f * 64];
+    }
+    const PackHeader* hdr = reinterpret_cast<const PackHeader*>(packed);
+    c.emax = hdr->emax;
+    c.demax = hdr->demax;
+    c.e_valid = hdr->valid != 0;
+    c.sEf = c.e_valid ? pow2f(hdr->sexp) : 1.0f;
     for (int u = tid; u < MAX_TILES * TILE; u += NT) reinterpret_cast<unsigned long long*>(lds + L_RES)[u] = ~0ull;
     for (int u = tid; u < PAIR_CAP; u += NT) reinterpret_cast<unsigned*>(lds + L_PAIR)[u] = ~0u;   // holes of refused reservations stay invalid
     if (tid < 2) reinterpret_cast<unsigned*>(lds + L_CNT)[tid] = 0u;
-    if (c.ntl > 0) issue_tile(c, 0, lds);
-    f16x8 af[2][16];
+    reinterpret_cast<float*>(lds + L_EES)[tid] = ee_g[tid] * c.sEf;                               // NT == K
+    Convert cv;
     {
-        const char* img = packed + PK_OFF_IMG + (size_t)c.wave * (32 * 1024);
-#pragma unroll
-        for (int f = 0; f < 32; ++f)
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(af[f >> 4][f & 15]) : "v"((unsigned)(f * 1024 + c.lane * 16)), "s"(img));
+        cv.start();
+        cv.cvt<0>(c, 0, x0); const f32x2 p0 = cv.pk; cv.cvt<1>(c, 0, x0); const f32x2 p1 = cv.pk;
+        cv.cvt<2>(c, 0, x0); const f32x2 p2 = cv.pk; cv.cvt<3>(c, 0, x0); const f32x2 p3 = cv.pk;
+        cv.err<0>(p0[0], p0[1], x0); cv.err<1>(p1[0], p1[1], x0); cv.err<2>(p2[0], p2[1], x0); cv.err<3>(p3[0], p3[1], x0);
+        cv.hh = row16_sum(cv.hh);
+        cv.dsq = row16_sum(cv.dsq);
+        cv.finish(c, 0);
+        if (c.ntl > 2 && !(ABL & 1)) load_rows(c, 2, x0);
     }
-    float ee_mine;                                                         // NT == K
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(ee_mine) : "v"((unsigned)(tid * 4)), "s"(ee_g));
-    f32x4 h0, h1;                                                          // header words 0-3, 4-7 (every lane the same address)
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(h0) : "v"(0u), "s"(packed));
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(h1) : "v"(0u), "s"(packed));
-    for (int j = 1; j < RING && j < c.ntl; ++j) issue_tile(c, j, lds);
-    wait_tile(c, 0);
-    asm volatile("" : "+v"(ee_mine), "+v"(h0), "+v"(h1));
-#pragma unroll
-    for (int f = 0; f < 32; ++f) asm volatile("" : "+v"(af[f >> 4][f & 15]));
-    // (element values copied out first: __builtin_bit_cast applied directly to a vector-element expression reads element 0)
-    const float w_emax = h0[0], w_sexp = h0[1], w_valid = h0[2], w_demax = h1[1];
-    c.emax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w_emax)));
-    const int sexp = __builtin_amdgcn_readfirstlane(__float_as_int(w_sexp));
-    c.e_valid = __builtin_amdgcn_readfirstlane(__float_as_int(w_valid)) != 0;
-    c.demax = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w_demax)));
-    c.sEf = c.e_valid ? pow2f(sexp) : 1.0f;
-    ds_wr32(c.lds0 + L_EES + tid * 4, __float_as_uint(ee_mine * c.sEf));
-    convert_tile(c, 0, lds, true);
-    wg_barrier();
+    __syncthreads();
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
 
-    // ---- tile loop, software-pipelined by hand: 32 MFMA gaps per tile, the vector work of three other tiles in the gaps
+    // ---- tile loop, software-pipelined by hand: 32 MFMA gaps per tile, the vector work of four other tiles in the gaps
     //   G0-3   acc0 <- k-steps 0-3 of tile t (starting from sE|e|^2)   | scores of acc1 (tile t-1), slot write
-    //   G4-9   acc1 <- k-steps 0-3, then both accumulators alternate   | merge of tile t-2
-    //   G9-22  k-steps 4-11                                            | tile t+1: DMA wait, fp32 -> fp16, row statistics; DMAs of tile t+4
-    //   G24    barrier (fp16 tile t+1 and the slots of tile t-1 complete; every wave is done reading... see DESIGN)
-    //   G24-27 acc0 <- k-steps 12-15                                   | start values of the next tile
-    //   G28-31 acc1 <- k-steps 12-15                                   | scores of acc0 (tile t); first fragments of tile t+1
+    //   G4-8   acc1 <- k-steps 0-3, then both accumulators alternate   | merge of tile t-2
+    //   G9-22  k-steps 4-11                                            | tile t+1: fp32 -> fp16, row statistics; loads of tile t+3
+    //   G24    barrier (the fp16 image of tile t+1 and the slots of tile t-1 are complete; nobody reads image t any more)
+    //   G24-27 acc0 <- k-steps 12-15
+    //   G28-31 acc1 <- k-steps 12-15                                   | scores of acc0 (tile t); first reads of tile t+1
     // LDS waits are by count of the fragment / start-value reads that are ALWAYS issued behind the awaited one; the other
     // LDS operations in between only make a wait longer than necessary, never shorter.
     f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
@@ -719,32 +526,24 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
     ds_rd128<0>(bf[0], zbase); ds_rd128<32>(bf[1], zbase); ds_rd128<64>(bf[2], zbase);
     ds_rd128<0>(ci0[0], ea); ds_rd128<32>(ci0[1], ea); ds_rd128<64>(ci0[2], ea); ds_rd128<96>(ci0[3], ea);
     ds_rd128<96>(bf[3], zbase);
-    Convert cv;
     Merge mg;
 #define DVQ_MF0(S) if (!(ABL & 16)) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][S], bf[S], acc0, 0, 0, 0)
 #define DVQ_MF1(S) if (!(ABL & 16)) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][S], bf[S], acc1, 0, 0, 0)
 #define DVQ_SB() __builtin_amdgcn_sched_barrier(0)
-// vector work is anchored in its gap: without a use the compiler sinks it to the end of the loop body, behind every MFMA
 #define DVQ_PIN2(A, B) asm volatile("" : "+v"(A), "+v"(B))
 #define DVQ_WAITF(N, S) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(bf[S]))
 #define DVQ_RDF(S) ds_rd128<32 * (S)>(bf[S], za)
 #define DVQ_STAMP(SLOT) if (DBG) stamp(c, t, SLOT)
-#ifndef DVQ_UNCOND
-#define DVQ_UNCOND 1   // 1: the per-tile work of non-existing tiles runs (no effect) instead of being branched around
-#endif
-    // The tile loop is rotated: `front(t)` = gaps 0-23 of tile t and the barrier, `back(t)` = gaps 24-31 (which prefetch tile
-    // t+1's first fragments and start values).  Every control-flow join (loop header, loop exit) sits right behind the
-    // barrier's lgkmcnt(0): no hand-issued LDS read is ever in flight across a join, where the register allocator may
-    // insert copies of what it believes are finished values.
-    // Nothing in the body is conditional on t except the DMA issue: tile "-1" is scored, tiles "-2", "-1" are merged (not
-    // live: no effect) and the tile behind the last one is converted (from stale ring bytes, never used).
-    auto front = [&](const int t) __attribute__((always_inline)) {
-        const bool do_dma = !(ABL & 1) && t + 1 + RING < c.ntl;
-        const bool has_prev = DVQ_UNCOND || t >= 1, do_merge = DVQ_UNCOND || t >= 2, do_cvt = DVQ_UNCOND || t + 1 < c.ntl;
+    // The loop is rotated: front(t) = gaps 0-23 of tile t and the barrier, back(t) = gaps 24-31 (which issue tile t+1's first
+    // reads).  Nothing in the body is conditional on t except the row loads: tile "-1" is scored, tiles "-2", "-1" are
+    // merged (not live: no effect) and the tile behind the last one is converted (from stale registers, never used).
+    auto front = [&](auto set, const int t) __attribute__((always_inline)) {
+        f32x4 (&x)[4] = decltype(set)::value ? x1 : x0;                   // rows of tile t+1 (its parity picks the set)
+        const bool do_load = !(ABL & 1) && t + 3 < c.ntl;
         const unsigned za = zbase + (t & 1) * Z16_BUF;
         DVQ_STAMP(0);
         // G0-3.  LDS reads pending at this point, in issue order: fragments 0, 1, 2, the four start values of acc0, fragment 3
-        if (!(ABL & 8) && has_prev) { score<0, 6>(acc1, 16, m1, m2); DVQ_PIN2(m1, m2); }
+        if (!(ABL & 8)) { score<0, 6>(acc1, 16, m1, m2); DVQ_PIN2(m1, m2); }
         asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(ci0[0]), "+v"(ci0[1]), "+v"(ci0[2]), "+v"(ci0[3]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]));
         {
             f32x16 st;
@@ -756,10 +555,10 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
         }
         DVQ_SB();
         DVQ_MF0(1);
-        if (!(ABL & 8) && has_prev) { score<6, 11>(acc1, 16, m1, m2); DVQ_PIN2(m1, m2); }
+        if (!(ABL & 8)) { score<6, 11>(acc1, 16, m1, m2); DVQ_PIN2(m1, m2); }
         DVQ_SB();
         DVQ_MF0(2);
-        if (!(ABL & 8) && has_prev) {
+        if (!(ABL & 8)) {
             score<11, 16>(acc1, 16, m1, m2);
             write_slot(c, t - 1, m1, m2);
         }
@@ -767,10 +566,9 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
         DVQ_SB();
         DVQ_WAITF(4, 3); DVQ_MF0(3);
         DVQ_SB();
-        // G4-7
-        DVQ_RDF(4);
-        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(ci1[0]), "+v"(ci1[1]), "+v"(ci1[2]), "+v"(ci1[3]));
-        if (!(ABL & 4) && do_merge) mg.read(c, t - 2);
+        // G4-7 (fragments are read two gaps ahead of their first use: an LDS read lands within one MFMA period of the SIMD)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ci1[0]), "+v"(ci1[1]), "+v"(ci1[2]), "+v"(ci1[3]));
+        if (!(ABL & 4)) mg.read(c, t - 2);
         {
             f32x16 st;
 #pragma unroll
@@ -782,87 +580,76 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
         DVQ_SB();
         DVQ_MF1(1);
         DVQ_SB();
-        DVQ_RDF(5);
+        DVQ_RDF(4);
         DVQ_MF1(2);
-        if (!(ABL & 4) && do_merge) {
+        if (!(ABL & 4)) {
             asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(mg.sl), "+v"(mg.rs));
             mg.min_a(); DVQ_PIN2(mg.rmin, mg.m1);
         }
         DVQ_SB();
         DVQ_MF1(3);
-        if (!(ABL & 4) && do_merge) { mg.min_b(c); DVQ_PIN2(mg.s1, mg.s2); }
+        if (!(ABL & 4)) { mg.min_b(c); DVQ_PIN2(mg.s1, mg.s2); }
         DVQ_SB();
         DVQ_STAMP(1);
         // G8-23: k-steps 4-11, both accumulators
-        DVQ_RDF(6);
-        DVQ_WAITF(2, 4); DVQ_MF0(4);
-        if (!(ABL & 4) && do_merge) mg.act(c, t - 2);
+        DVQ_RDF(5);
+        DVQ_WAITF(1, 4); DVQ_MF0(4);
+        if (!(ABL & 4)) mg.act(c, t - 2);
         DVQ_SB();
         DVQ_MF1(4);
-        if (!(ABL & 2) && do_cvt) {
-            if (!(ABL & 1)) wait_tile(c, t + 1);
-            cv.read(c, t + 1);
-        }
+        if (!(ABL & 2)) cv.start();
         DVQ_SB();
-        DVQ_RDF(7);
-        DVQ_WAITF(2, 5); DVQ_MF0(5);
+        DVQ_RDF(6);
+        DVQ_WAITF(1, 5); DVQ_MF0(5);
         DVQ_SB();
         DVQ_MF1(5);
         f32x2 pk0, pk1, pk2, pk3;
-        if (!(ABL & 2) && do_cvt) {
-            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(cv.x[0]), "+v"(cv.x[1]), "+v"(cv.x[2]), "+v"(cv.x[3]));
-            cv.template cvt<0>(c, t + 1); pk0 = cv.pk;
-        }
+        if (!(ABL & 2)) { cv.template cvt<0>(c, t + 1, x); pk0 = cv.pk; }
         DVQ_SB();
-        DVQ_RDF(8);
-        DVQ_WAITF(2, 6); DVQ_MF0(6);
-        if (!(ABL & 2) && do_cvt) { cv.template err<0>(pk0[0], pk0[1]); DVQ_PIN2(cv.ss, cv.dsq); }
-        if (do_dma) issue_row(c, t + 1 + RING, 0, lds);
+        DVQ_RDF(7);
+        DVQ_WAITF(1, 6); DVQ_MF0(6);
+        if (!(ABL & 2)) { cv.template err<0>(pk0[0], pk0[1], x); DVQ_PIN2(cv.hh, cv.dsq); }
         DVQ_SB();
         DVQ_MF1(6);
-        if (!(ABL & 2) && do_cvt) { cv.template cvt<1>(c, t + 1); pk1 = cv.pk; }
-        if (do_dma) issue_row(c, t + 1 + RING, 1, lds);
+        if (!(ABL & 2)) { cv.template cvt<1>(c, t + 1, x); pk1 = cv.pk; }
         DVQ_SB();
-        DVQ_RDF(9);
-        DVQ_WAITF(2, 7); DVQ_MF0(7);
-        if (!(ABL & 2) && do_cvt) { cv.template err<1>(pk1[0], pk1[1]); DVQ_PIN2(cv.ss, cv.dsq); }
-        if (do_dma) issue_row(c, t + 1 + RING, 2, lds);
+        DVQ_RDF(8);
+        DVQ_WAITF(1, 7); DVQ_MF0(7);
+        if (!(ABL & 2)) { cv.template err<1>(pk1[0], pk1[1], x); DVQ_PIN2(cv.hh, cv.dsq); }
         DVQ_SB();
         DVQ_MF1(7);
-        if (!(ABL & 2) && do_cvt) { cv.template cvt<2>(c, t + 1); pk2 = cv.pk; }
-        if (do_dma) issue_row(c, t + 1 + RING, 3, lds);
+        if (!(ABL & 2)) { cv.template cvt<2>(c, t + 1, x); pk2 = cv.pk; }
         DVQ_SB();
-        DVQ_RDF(10);
-        DVQ_WAITF(2, 8); DVQ_MF0(8);
-        if (!(ABL & 2) && do_cvt) { cv.template err<2>(pk2[0], pk2[1]); DVQ_PIN2(cv.ss, cv.dsq); }
+        DVQ_RDF(9);
+        DVQ_WAITF(1, 8); DVQ_MF0(8);
+        if (!(ABL & 2)) { cv.template err<2>(pk2[0], pk2[1], x); DVQ_PIN2(cv.hh, cv.dsq); }
         DVQ_SB();
         DVQ_MF1(8);
-        if (!(ABL & 2) && do_cvt) { cv.template cvt<3>(c, t + 1); pk3 = cv.pk; }
+        if (!(ABL & 2)) { cv.template cvt<3>(c, t + 1, x); pk3 = cv.pk; }
         DVQ_SB();
-        DVQ_RDF(11);
-        DVQ_WAITF(2, 9); DVQ_MF0(9);
-        if (!(ABL & 2) && do_cvt) { cv.template err<3>(pk3[0], pk3[1]); DVQ_PIN2(cv.ss, cv.dsq); }
+        DVQ_RDF(10);
+        DVQ_WAITF(1, 9); DVQ_MF0(9);
+        if (!(ABL & 2)) { cv.template err<3>(pk3[0], pk3[1], x); DVQ_PIN2(cv.hh, cv.dsq); }
         DVQ_SB();
         DVQ_MF1(9);
-        if (!(ABL & 2) && do_cvt) { cv.ss = row16_sum(cv.ss); DVQ_PIN2(cv.ss, cv.dsq); }
+        if (do_load) load_rows(c, t + 3, x);                            // the set is free: rows of tile t+3 (same parity)
+        if (!(ABL & 2)) { cv.hh = row16_sum(cv.hh); DVQ_PIN2(cv.hh, cv.dsq); }
+        DVQ_SB();
+        DVQ_RDF(11);
+        DVQ_WAITF(1, 10); DVQ_MF0(10);
+        if (!(ABL & 2)) { cv.dsq = row16_sum(cv.dsq); DVQ_PIN2(cv.hh, cv.dsq); }
+        DVQ_SB();
+        DVQ_MF1(10);
+        if (!(ABL & 2)) cv.finish(c, t + 1);
         DVQ_SB();
         DVQ_RDF(12);
-        DVQ_WAITF(2, 10); DVQ_MF0(10);
-        if (!(ABL & 2) && do_cvt) { cv.dsq = row16_sum(cv.dsq); DVQ_PIN2(cv.ss, cv.dsq); }
+        DVQ_WAITF(1, 11); DVQ_MF0(11);
         DVQ_SB();
-        DVQ_RDF(13);
-        DVQ_MF1(10);
-        if (!(ABL & 2) && do_cvt) cv.finish(c, t + 1);
-        DVQ_SB();
-        DVQ_RDF(14);
-        DVQ_WAITF(3, 11); DVQ_MF0(11);
-        DVQ_SB();
-        DVQ_RDF(15);
+        DVQ_RDF(13); DVQ_RDF(14); DVQ_RDF(15);
         DVQ_MF1(11);
         DVQ_SB();
         DVQ_STAMP(2);
-        // G24: every LDS operation of this wave complete (fragment reads of this tile included), then the barrier:
-        // behind it the fp16 image of tile t+1 and the slots of tile t-1 are complete, and nobody reads this tile's image any more
+        // G24: every LDS operation of this wave complete (fragment reads of this tile included), then the barrier
         if (ABL & 32) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[12]), "+v"(bf[13]), "+v"(bf[14]), "+v"(bf[15])::"memory");
         else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(bf[12]), "+v"(bf[13]), "+v"(bf[14]), "+v"(bf[15])::"memory");
         DVQ_STAMP(3);
@@ -898,15 +685,24 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
         DVQ_SB();
         DVQ_STAMP(4);
     };
-    if (c.ntl > 0) {
-        front(0);
-        for (int t = 0; t + 1 < c.ntl; ++t) {
+    // call sequence F1(0) B(0) F0(1) B(1) F1(2) ... B(ntl-1): F_S(t) converts tile t+1 out of register set S = (t+1) & 1
+    {
+        front(std::integral_constant<int, 1>{}, 0);
+        int t = 0;
+        for (; t + 2 < c.ntl; t += 2) {
             back(t);
-            front(t + 1);
+            front(std::integral_constant<int, 0>{}, t + 1);
+            back(t + 1);
+            front(std::integral_constant<int, 1>{}, t + 2);
         }
-        back(c.ntl - 1);
-        // the last prefetch has no consumer, but its destination registers must stay reserved until the data has landed:
-        // a dead destination is handed to the next value at once, and the read then lands on top of that value
+        if (t + 1 < c.ntl) {
+            back(t);
+            front(std::integral_constant<int, 0>{}, t + 1);
+            back(t + 1);
+        } else {
+            back(t);
+        }
+        // the last prefetch has no consumer, but its destination registers must stay reserved until the data has landed
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(ci0[0]), "+v"(ci0[1]), "+v"(ci0[2]),
                      "+v"(ci0[3])::"memory");
     }
@@ -917,23 +713,18 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
 #undef DVQ_PIN2
 #undef DVQ_RDF
 #undef DVQ_STAMP
-    // drain: the prefetched fragments / start values of a tile that does not exist are dropped; last scores, last merges
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (c.ntl >= 1) {
-        score<0, 16>(acc1, 16, m1, m2);
-        write_slot(c, c.ntl - 1, m1, m2);
-    }
+    // last scores, last merges
+    score<0, 16>(acc1, 16, m1, m2);
+    write_slot(c, c.ntl - 1, m1, m2);
     if (c.ntl >= 2) {
         mg.read(c, c.ntl - 2);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mg.sl), "+v"(mg.rs));
         mg.min_a(); mg.min_b(c); mg.act(c, c.ntl - 2);
     }
     wg_barrier();
-    if (c.ntl >= 1) {
-        mg.read(c, c.ntl - 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mg.sl), "+v"(mg.rs));
-        mg.min_a(); mg.min_b(c); mg.act(c, c.ntl - 1);
-    }
+    mg.read(c, c.ntl - 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mg.sl), "+v"(mg.rs));
+    mg.min_a(); mg.min_b(c); mg.act(c, c.ntl - 1);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     const unsigned long long t2 = __builtin_amdgcn_s_memrealtime();
@@ -960,6 +751,7 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
             }
         }
     }
+    const unsigned long long t2b = __builtin_amdgcn_s_memrealtime();
     // what is left (NaN/Inf, fp16 overflow, invalid codebook image, overflowing list): all K entries canonically,
     // the whole workgroup per row, one single-lane chain per entry (NT == K)
     for (int o = 0; o < n_slow; ++o) {
@@ -975,22 +767,20 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
         const long gr = grow_of(tid);
         if (gr < M) idx[gr] = (int64_t)(unsigned)(s_res[tid] & 0xffffffffull);
     }
-    if (dbg && tid == 0) {
-        const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(dbg) + (size_t)blockIdx.x * DBG_WG_BYTES);
-        o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3;
-        o[4] = (unsigned long long)total; o[5] = (unsigned long long)n_slow;
-        o[6] = (unsigned long long)__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));   // HW_ID
-        o[7] = (unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));  // XCC_ID
+    if (DBG && dbg) {
+        if (tid == 0) {
+            const unsigned long long t3 = __builtin_amdgcn_s_memrealtime();
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(dbg) + (size_t)blockIdx.x * DBG_WG_BYTES);
+            o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3;
+            o[4] = (unsigned long long)total; o[5] = (unsigned long long)n_slow;
+            o[6] = t2b;
+            o[7] = (unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));  // XCC_ID
+        }
+        if (tid < NWV * 32)
+            reinterpret_cast<unsigned*>(reinterpret_cast<char*>(dbg) + (size_t)blockIdx.x * DBG_WG_BYTES + 64)[tid] =
+                reinterpret_cast<const unsigned*>(lds + L_DBG)[tid];
     }
-    if (dbg && tid < NWV * 32)
-        reinterpret_cast<unsigned*>(reinterpret_cast<char*>(dbg) + (size_t)blockIdx.x * DBG_WG_BYTES + 64)[tid] =
-            reinterpret_cast<const unsigned*>(lds + L_DBG)[tid];
 }
-
-struct DevInfo {
-    int cus;
-};
 
 int device_cus() {
     static int cus[128] = {0};
