@@ -6,15 +6,15 @@
 //   * one 512-thread workgroup per CU walks over up to 8 tiles of 32 rows (tile = blockIdx + j * gridDim);
 //   * wave w keeps codebook entries [64w, 64w+64) -- fp16 of -2 sE e_k, all 256 dims -- as the MFMA A operand in
 //     128 VGPRs for the whole kernel (8 waves x 64 entries = the whole codebook, 256 KB of the CU's 512 KB of VGPRs);
-//   * each wave owns 4 rows of every tile: it loads them HBM -> registers two tiles ahead (16 lanes per row, 16 floats
-//     per lane: 256-byte segments, two alternating register sets), converts them to fp16 ONCE (|h(z)|^2, the measured
+//   * each wave owns 4 rows of every tile: it loads them HBM -> registers one tile ahead (16 lanes per row, 16 floats
+//     per lane: 256-byte segments; the registers are refilled as soon as a tile is converted), converts them to fp16 ONCE (|h(z)|^2, the measured
 //     rounding error |z - h(z)|, eps_row) and writes them to a padded fp16 tile in LDS (528-byte rows: conflict-free
 //     ds_read_b128 fragments with one address register and immediate offsets);
 //   * every wave multiplies the tile with its 64 entries: 16 fragment reads feed 32 v_mfma_f32_32x32x16_f16, the
 //     accumulators START at sE |e_k|^2 (read from LDS straight into the accumulator registers), so they END as the
 //     scores sE (|e_k|^2 - 2 z.e_k): no per-score arithmetic beyond id packing and a lane-local top-2 (3 VALU per score);
 //   * the loop is software-pipelined by hand: the 32 MFMA gaps of tile t carry the scores of tile t-1 / t, the merge of
-//     tile t-2, the conversion of tile t+1 and the loads of tile t+3; one s_barrier per tile;
+//     tile t-2, the conversion of tile t+1 and the loads of tile t+2; one s_barrier per tile;
 //   * per tile, 16 (wave, lane-half) slots per row hold (min, second) packed scores; the merge finds the row minimum,
 //     the slots within eps_row of it, and either decides the row or appends (row, entry) pairs to a list;
 //   * after the last tile: the canonical fp32 evaluation d_k = (zz + ee_k) - 2 dot_k (k-ordered fmaf chains, four lanes
@@ -59,8 +59,8 @@ constexpr int EXP_LIMIT = 40;                      // |log2(max codebook magnitu
 
 constexpr int Z16_ROW = 528;                       // padded fp16 row: 512 B + 16 B (shifts consecutive rows by one bank group)
 constexpr int Z16_BUF = TILE * Z16_ROW;            // 16 896
-constexpr int MS_ROW = 136;                        // merge slots of a row: 16 x 8 B + 8 B pad
-constexpr int MS_BUF = TILE * MS_ROW;              // 4 352
+constexpr int MS_ROW = 264;                        // merge slots of a row: 16 (wave, lane half) x 2 (accumulator) x 8 B + 8 B pad
+constexpr int MS_BUF = TILE * MS_ROW;              // 8 448
 constexpr int PAIR_CAP = 2048;
 
 constexpr int L_Z16 = 0;                                   // 2 x fp16 tile
@@ -318,11 +318,13 @@ __device__ __forceinline__ void score(const f32x16& a, int idbase, float& m1, fl
     }
 }
 
+// (min, second) of one accumulator's 16 scores -> slot (wave, lane half, JN) of the lane's row, tile t
+template <int JN>
 __device__ __forceinline__ void write_slot(const Ctx& c, int t, float m1, float m2) {
     f32x2 v;
     v[0] = m1;
     v[1] = m2;
-    ds_wr64<0>(c.lds0 + L_MS + (t & 1) * MS_BUF + (c.lane & 31) * MS_ROW + (2 * c.wave + (c.lane >> 5)) * 8, v);
+    ds_wr64<8 * JN>(c.lds0 + L_MS + (t & 1) * MS_BUF + (c.lane & 31) * MS_ROW + (2 * c.wave + (c.lane >> 5)) * 16, v);
 }
 
 // d = h - x with h the low (HI = 0) or high (HI = 1) fp16 half of `hp`: one v_fma_mix_f32 (exact; the sign does not matter)
@@ -373,39 +375,40 @@ struct Convert {
     }
 };
 
-// merge of a tile in stages (rows 4 wave + g, 16 slots each); same decisions as merge_tile
+// merge of a tile in stages: this wave's rows 4 wave + g, 16 lanes per row, lane i looks at the two slots (accumulator 0 / 1)
+// of (source wave i / 2, lane half i % 2), i.e. at 2 x 16 codebook entries
 struct Merge {
-    f32x2 sl, rs;
-    float m1, m2, rmin;
-    unsigned s1, s2;
-    bool c1, c2;
+    f32x4 sl;                                                           // (min, second) of accumulator 0, (min, second) of accumulator 1
+    f32x2 rs;
+    float rmin;                                                         // row minimum, then the row's threshold
+    unsigned long long bA1, bA2, bB1, bB2;                              // wave ballots (uniform: SGPRs) of "within eps of the row minimum"
     __device__ __forceinline__ void read(const Ctx& c, int tm) {
         const int g = c.lane >> 4, i = c.lane & 15;
         const int r = 4 * c.wave + g;
-        ds_rd64<0>(sl, c.lds0 + L_MS + (tm & 1) * MS_BUF + r * MS_ROW + i * 8);
+        ds_rd128<0>(sl, c.lds0 + L_MS + (tm & 1) * MS_BUF + r * MS_ROW + i * 16);
         ds_rd64<0>(rs, c.lds0 + L_RS + (tm & 3) * (TILE * 8) + r * 8);
     }
     __device__ __forceinline__ void min_a() {                            // after the wait that pins sl, rs
-        m1 = sl[0];
-        m2 = sl[1];
-        rmin = min_nc(m1, dpp_f<0xB1>(m1));
+        rmin = min_nc(sl[0], sl[2]);
+        rmin = min_nc(rmin, dpp_f<0xB1>(rmin));
         rmin = min_nc(rmin, dpp_f<0x4E>(rmin));
     }
     __device__ __forceinline__ void min_b(const Ctx& c) {
-        const int g = c.lane >> 4;
         rmin = min_nc(rmin, dpp_f<0x141>(rmin));
         rmin = min_nc(rmin, dpp_f<0x140>(rmin));
-        const float thr = rmin + rs[0];
-        c1 = m1 <= thr;
-        c2 = m2 <= thr;
-        const unsigned long long b1 = __ballot(c1), b2 = __ballot(c2);
-        s1 = (unsigned)(b1 >> (16 * g)) & 0xffffu;
-        s2 = (unsigned)(b2 >> (16 * g)) & 0xffffu;
+        rmin = rmin + rs[0];
+        bA1 = __ballot(sl[0] <= rmin);
+        bA2 = __ballot(sl[1] <= rmin);
+        bB1 = __ballot(sl[2] <= rmin);
+        bB2 = __ballot(sl[3] <= rmin);
     }
     __device__ __forceinline__ void act(const Ctx& c, int tm) {
         const int g = c.lane >> 4, i = c.lane & 15;
         const int r = 4 * c.wave + g;
-        const int n1 = __popc(s1), n2 = __popc(s2);
+        const unsigned sA1 = (unsigned)(bA1 >> (16 * g)) & 0xffffu, sA2 = (unsigned)(bA2 >> (16 * g)) & 0xffffu;   // this row's 16 lanes
+        const unsigned sB1 = (unsigned)(bB1 >> (16 * g)) & 0xffffu, sB2 = (unsigned)(bB2 >> (16 * g)) & 0xffffu;
+        const bool cA1 = (sA1 >> i) & 1u, cA2 = (sA2 >> i) & 1u, cB1 = (sB1 >> i) & 1u, cB2 = (sB2 >> i) & 1u;
+        const int n1 = __popc(sA1) + __popc(sB1), n2 = __popc(sA2) + __popc(sB2);
         const bool bad = __float_as_uint(rs[1]) != 0u;
         const long grow = (c.tile0 + (long)blockIdx.x + (long)tm * c.G) * TILE + r;
         const bool live = grow < c.M && tm >= 0;                        // (the pipelined loop also merges "tiles" -2, -1)
@@ -414,32 +417,36 @@ struct Merge {
         const bool slow = bad || n1 == 0;
         const bool unique = !slow && n1 == 1 && n2 == 0;
         const bool amb = live && !slow && !unique;
-        if (live && unique && c1) {
-            const unsigned id = __float_as_uint(m1) & 31u;
+        if (live && unique && (cA1 || cB1)) {
+            const unsigned id = __float_as_uint(cA1 ? sl[0] : sl[2]) & 15u;
             f32x2 kv;
-            kv[0] = __uint_as_float((unsigned)entry_of(w_src, id >> 4, id & 15, h_src));
+            kv[0] = __uint_as_float((unsigned)entry_of(w_src, cA1 ? 0 : 1, (int)id, h_src));
             kv[1] = __uint_as_float(0u);
             ds_wr64<0>(c.lds0 + L_RES + rowslot * 8, kv);
         }
         if (__ballot(live && !unique) == 0ull) return;                  // common case: every row of the wave decided
-        // one reservation per ambiguous row (leader lane i == 0): single candidates take one pair, a slot whose second
-        // score is within eps takes all its 32 entries
-        const int need = (n1 - n2) + 32 * n2;
+        // one reservation per ambiguous row (leader lane i == 0): a slot with one score within eps takes one pair, a slot
+        // whose second score is within eps too (it may hide a third) takes all its 16 entries
+        const int need = (n1 - n2) + 16 * n2;
         unsigned pos = 0;
         if (amb && i == 0) pos = ds_add_rtn(c.lds0 + L_CNT, (unsigned)need);
         pos = (unsigned)__builtin_amdgcn_readlane((int)pos, 0) * (g == 0) + (unsigned)__builtin_amdgcn_readlane((int)pos, 16) * (g == 1) +
               (unsigned)__builtin_amdgcn_readlane((int)pos, 32) * (g == 2) + (unsigned)__builtin_amdgcn_readlane((int)pos, 48) * (g == 3);
         const bool fits = pos + (unsigned)need <= (unsigned)PAIR_CAP;
-        if (amb && fits && c1) {
+        if (amb && fits && (cA1 || cB1)) {
             const unsigned lt = (1u << i) - 1u;
-            const unsigned off = pos + (unsigned)__popc(s1 & ~s2 & lt) + 32u * (unsigned)__popc(s2 & lt);
-            if (c2) {
-                for (int e = 0; e < 32; ++e)
-                    ds_wr32(c.lds0 + L_PAIR + (off + e) * 4, (rowslot << 16) | (unsigned)entry_of(w_src, e >> 4, e & 15, h_src));
-            } else {
-                const unsigned id = __float_as_uint(m1) & 31u;
-                ds_wr32(c.lds0 + L_PAIR + off * 4, (rowslot << 16) | (unsigned)entry_of(w_src, id >> 4, id & 15, h_src));
-            }
+            unsigned off = pos + (unsigned)(__popc(sA1 & ~sA2 & lt) + __popc(sB1 & ~sB2 & lt)) + 16u * (unsigned)(__popc(sA2 & lt) + __popc(sB2 & lt));
+            auto push = [&](int jn, bool one, bool all, float best) {
+                if (all) {
+                    for (int e = 0; e < 16; ++e) ds_wr32(c.lds0 + L_PAIR + (off + e) * 4, (rowslot << 16) | (unsigned)entry_of(w_src, jn, e, h_src));
+                    off += 16;
+                } else if (one) {
+                    ds_wr32(c.lds0 + L_PAIR + off * 4, (rowslot << 16) | (unsigned)entry_of(w_src, jn, (int)(__float_as_uint(best) & 15u), h_src));
+                    off += 1;
+                }
+            };
+            push(0, cA1, cA2, sl[0]);
+            push(1, cB1, cB2, sl[2]);
         }
         if (live && i == 0 && (slow || (amb && !fits))) {
             const unsigned sp = ds_add_rtn(c.lds0 + L_CNT + 4, 1u);
@@ -472,37 +479,35 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
     // the values the matrix core multiplies (measured on gfx950: the MFMA keeps fp16 subnormal inputs; this does not rely on it)
     __builtin_amdgcn_s_setreg((2 - 1) << 11 | 6 << 6 | 1, 0);            // hwreg(HW_REG_MODE, offset 6, width 2) <- 0
 
-    // ---- prologue: the first two tiles and the codebook slice on their way, tables into LDS, tile 0 converted
-    f32x4 x0[4], x1[4];                                                // fp32 rows of the even / odd tiles in flight
-    if (!(ABL & 1)) {
-        load_rows(c, 0, x0);
-        if (c.ntl > 1) load_rows(c, 1, x1);
-    }
+    // ---- prologue: header and |e|^2 (small, needed first), the first two tiles, then the codebook slice (needed last)
+    const PackHeader* hdr = reinterpret_cast<const PackHeader*>(packed);
+    c.emax = hdr->emax;
+    c.demax = hdr->demax;
+    c.e_valid = hdr->valid != 0;
+    c.sEf = c.e_valid ? pow2f(hdr->sexp) : 1.0f;
+    const float ee_mine = ee_g[tid];                                   // NT == K
+    f32x4 x[4];                                                        // fp32 rows of the tile in flight (one tile ahead)
+    if (!(ABL & 1)) load_rows(c, 0, x);
     f16x8 af[2][16];
     {
         const f16x8* img = reinterpret_cast<const f16x8*>(packed + PK_OFF_IMG) + (size_t)c.wave * (32 * 64) + c.lane;
 #pragma unroll
         for (int f = 0; f < 32; ++f) af[f >> 4][f & 15] = img[f * 64];
     }
-    const PackHeader* hdr = reinterpret_cast<const PackHeader*>(packed);
-    c.emax = hdr->emax;
-    c.demax = hdr->demax;
-    c.e_valid = hdr->valid != 0;
-    c.sEf = c.e_valid ? pow2f(hdr->sexp) : 1.0f;
     for (int u = tid; u < MAX_TILES * TILE; u += NT) reinterpret_cast<unsigned long long*>(lds + L_RES)[u] = ~0ull;
     for (int u = tid; u < PAIR_CAP; u += NT) reinterpret_cast<unsigned*>(lds + L_PAIR)[u] = ~0u;   // holes of refused reservations stay invalid
     if (tid < 2) reinterpret_cast<unsigned*>(lds + L_CNT)[tid] = 0u;
-    reinterpret_cast<float*>(lds + L_EES)[tid] = ee_g[tid] * c.sEf;                               // NT == K
+    reinterpret_cast<float*>(lds + L_EES)[tid] = ee_mine * c.sEf;
     Convert cv;
     {
         cv.start();
-        cv.cvt<0>(c, 0, x0); const f32x2 p0 = cv.pk; cv.cvt<1>(c, 0, x0); const f32x2 p1 = cv.pk;
-        cv.cvt<2>(c, 0, x0); const f32x2 p2 = cv.pk; cv.cvt<3>(c, 0, x0); const f32x2 p3 = cv.pk;
-        cv.err<0>(p0[0], p0[1], x0); cv.err<1>(p1[0], p1[1], x0); cv.err<2>(p2[0], p2[1], x0); cv.err<3>(p3[0], p3[1], x0);
+        cv.cvt<0>(c, 0, x); const f32x2 p0 = cv.pk; cv.cvt<1>(c, 0, x); const f32x2 p1 = cv.pk;
+        cv.cvt<2>(c, 0, x); const f32x2 p2 = cv.pk; cv.cvt<3>(c, 0, x); const f32x2 p3 = cv.pk;
+        cv.err<0>(p0[0], p0[1], x); cv.err<1>(p1[0], p1[1], x); cv.err<2>(p2[0], p2[1], x); cv.err<3>(p3[0], p3[1], x);
         cv.hh = row16_sum(cv.hh);
         cv.dsq = row16_sum(cv.dsq);
         cv.finish(c, 0);
-        if (c.ntl > 2 && !(ABL & 1)) load_rows(c, 2, x0);
+        if (c.ntl > 1 && !(ABL & 1)) load_rows(c, 1, x);
     }
     __syncthreads();
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
@@ -510,7 +515,7 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
     // ---- tile loop, software-pipelined by hand: 32 MFMA gaps per tile, the vector work of four other tiles in the gaps
     //   G0-3   acc0 <- k-steps 0-3 of tile t (starting from sE|e|^2)   | scores of acc1 (tile t-1), slot write
     //   G4-8   acc1 <- k-steps 0-3, then both accumulators alternate   | merge of tile t-2
-    //   G9-22  k-steps 4-11                                            | tile t+1: fp32 -> fp16, row statistics; loads of tile t+3
+    //   G9-22  k-steps 4-11                                            | tile t+1: fp32 -> fp16, row statistics; loads of tile t+2
     //   G24    barrier (the fp16 image of tile t+1 and the slots of tile t-1 are complete; nobody reads image t any more)
     //   G24-27 acc0 <- k-steps 12-15
     //   G28-31 acc1 <- k-steps 12-15                                   | scores of acc0 (tile t); first reads of tile t+1
@@ -519,7 +524,6 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
     f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
     f16x8 bf[16];
     f32x4 ci0[4], ci1[4];                                               // start values: read into the (just scored, free) accumulator's registers
-    float m1 = INFINITY, m2 = INFINITY;
     const int r_l = c.lane & 31, h_l = c.lane >> 5;
     const unsigned ea = c.lds0 + L_EES + (64 * c.wave + 4 * h_l) * 4;
     const unsigned zbase = c.lds0 + L_Z16 + r_l * Z16_ROW + 16 * h_l;
@@ -537,13 +541,13 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
     // The loop is rotated: front(t) = gaps 0-23 of tile t and the barrier, back(t) = gaps 24-31 (which issue tile t+1's first
     // reads).  Nothing in the body is conditional on t except the row loads: tile "-1" is scored, tiles "-2", "-1" are
     // merged (not live: no effect) and the tile behind the last one is converted (from stale registers, never used).
-    auto front = [&](auto set, const int t) __attribute__((always_inline)) {
-        f32x4 (&x)[4] = decltype(set)::value ? x1 : x0;                   // rows of tile t+1 (its parity picks the set)
-        const bool do_load = !(ABL & 1) && t + 3 < c.ntl;
+    auto front = [&](const int t) __attribute__((always_inline)) {
+        const bool do_load = !(ABL & 1) && t + 2 < c.ntl;
         const unsigned za = zbase + (t & 1) * Z16_BUF;
         DVQ_STAMP(0);
         // G0-3.  LDS reads pending at this point, in issue order: fragments 0, 1, 2, the four start values of acc0, fragment 3
-        if (!(ABL & 8)) { score<0, 6>(acc1, 16, m1, m2); DVQ_PIN2(m1, m2); }
+        float m1 = INFINITY, m2 = INFINITY;                               // (min, second) of acc1 = 16 entries of tile t-1
+        if (!(ABL & 8)) { score<0, 6>(acc1, 0, m1, m2); DVQ_PIN2(m1, m2); }
         asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(ci0[0]), "+v"(ci0[1]), "+v"(ci0[2]), "+v"(ci0[3]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]));
         {
             f32x16 st;
@@ -555,12 +559,12 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
         }
         DVQ_SB();
         DVQ_MF0(1);
-        if (!(ABL & 8)) { score<6, 11>(acc1, 16, m1, m2); DVQ_PIN2(m1, m2); }
+        if (!(ABL & 8)) { score<6, 11>(acc1, 0, m1, m2); DVQ_PIN2(m1, m2); }
         DVQ_SB();
         DVQ_MF0(2);
         if (!(ABL & 8)) {
-            score<11, 16>(acc1, 16, m1, m2);
-            write_slot(c, t - 1, m1, m2);
+            score<11, 16>(acc1, 0, m1, m2);
+            write_slot<1>(c, t - 1, m1, m2);
         }
         ds_rd128<128>(ci1[0], ea); ds_rd128<160>(ci1[1], ea); ds_rd128<192>(ci1[2], ea); ds_rd128<224>(ci1[3], ea);
         DVQ_SB();
@@ -584,11 +588,11 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
         DVQ_MF1(2);
         if (!(ABL & 4)) {
             asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(mg.sl), "+v"(mg.rs));
-            mg.min_a(); DVQ_PIN2(mg.rmin, mg.m1);
+            mg.min_a(); asm volatile("" : "+v"(mg.rmin));
         }
         DVQ_SB();
         DVQ_MF1(3);
-        if (!(ABL & 4)) { mg.min_b(c); DVQ_PIN2(mg.s1, mg.s2); }
+        if (!(ABL & 4)) { mg.min_b(c); asm volatile("" : "+s"(mg.bA1), "+s"(mg.bB1)); }
         DVQ_SB();
         DVQ_STAMP(1);
         // G8-23: k-steps 4-11, both accumulators
@@ -632,7 +636,7 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
         if (!(ABL & 2)) { cv.template err<3>(pk3[0], pk3[1], x); DVQ_PIN2(cv.hh, cv.dsq); }
         DVQ_SB();
         DVQ_MF1(9);
-        if (do_load) load_rows(c, t + 3, x);                            // the set is free: rows of tile t+3 (same parity)
+        if (do_load) load_rows(c, t + 2, x);                            // the registers are free: rows of tile t+2
         if (!(ABL & 2)) { cv.hh = row16_sum(cv.hh); DVQ_PIN2(cv.hh, cv.dsq); }
         DVQ_SB();
         DVQ_RDF(11);
@@ -665,8 +669,7 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
         DVQ_MF0(15);
         DVQ_SB();
         // G28-31: scores of acc0; its registers then take the next tile's start values; first fragments of tile t+1
-        m1 = INFINITY;
-        m2 = INFINITY;
+        float m1 = INFINITY, m2 = INFINITY;                               // (min, second) of acc0 = 16 entries of tile t
         DVQ_RDF(0);
         DVQ_MF1(12);
         if (!(ABL & 8)) { score<0, 6>(acc0, 0, m1, m2); DVQ_PIN2(m1, m2); }
@@ -677,7 +680,7 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
         DVQ_SB();
         DVQ_RDF(2);
         DVQ_MF1(14);
-        if (!(ABL & 8)) { score<11, 16>(acc0, 0, m1, m2); DVQ_PIN2(m1, m2); }
+        if (!(ABL & 8)) { score<11, 16>(acc0, 0, m1, m2); write_slot<0>(c, t, m1, m2); }
         ds_rd128<0>(ci0[0], ea); ds_rd128<32>(ci0[1], ea); ds_rd128<64>(ci0[2], ea); ds_rd128<96>(ci0[3], ea);
         DVQ_SB();
         DVQ_RDF(3);
@@ -685,23 +688,13 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
         DVQ_SB();
         DVQ_STAMP(4);
     };
-    // call sequence F1(0) B(0) F0(1) B(1) F1(2) ... B(ntl-1): F_S(t) converts tile t+1 out of register set S = (t+1) & 1
     {
-        front(std::integral_constant<int, 1>{}, 0);
-        int t = 0;
-        for (; t + 2 < c.ntl; t += 2) {
+        front(0);
+        for (int t = 0; t + 1 < c.ntl; ++t) {
             back(t);
-            front(std::integral_constant<int, 0>{}, t + 1);
-            back(t + 1);
-            front(std::integral_constant<int, 1>{}, t + 2);
+            front(t + 1);
         }
-        if (t + 1 < c.ntl) {
-            back(t);
-            front(std::integral_constant<int, 0>{}, t + 1);
-            back(t + 1);
-        } else {
-            back(t);
-        }
+        back(c.ntl - 1);
         // the last prefetch has no consumer, but its destination registers must stay reserved until the data has landed
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(ci0[0]), "+v"(ci0[1]), "+v"(ci0[2]),
                      "+v"(ci0[3])::"memory");
@@ -714,8 +707,11 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
 #undef DVQ_RDF
 #undef DVQ_STAMP
     // last scores, last merges
-    score<0, 16>(acc1, 16, m1, m2);
-    write_slot(c, c.ntl - 1, m1, m2);
+    {
+        float m1 = INFINITY, m2 = INFINITY;
+        score<0, 16>(acc1, 0, m1, m2);
+        write_slot<1>(c, c.ntl - 1, m1, m2);
+    }
     if (c.ntl >= 2) {
         mg.read(c, c.ntl - 2);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mg.sl), "+v"(mg.rs));

@@ -49,6 +49,11 @@ print("start  min/med/max us:", rel[:, 0].min(), np.median(rel[:, 0]), rel[:, 0]
 print("prologue dur med/max:", np.median(rel[:, 1] - rel[:, 0]), (rel[:, 1] - rel[:, 0]).max())
 print("tile loop dur med/max:", np.median(rel[:, 2] - rel[:, 1]), (rel[:, 2] - rel[:, 1]).max())
 print("refine tail dur med/max:", np.median(rel[:, 3] - rel[:, 2]), (rel[:, 3] - rel[:, 2]).max())
+t2b = (full[:, 6] - t0) * 0.01
+print("   of which pair chains med/max:", np.median(t2b - rel[:, 2]), (t2b - rel[:, 2]).max(), " slow rows + index write med/max:", np.median(rel[:, 3] - t2b), (rel[:, 3] - t2b).max())
+for lo, hi in ((0, 33), (33, 65), (65, 129), (129, 10000)):
+    m = (full[:, 4] >= lo) & (full[:, 4] < hi)
+    if m.any(): print(f"   WGs with {lo}..{hi - 1} pairs: {m.sum():4d}  chains med/max {np.median((t2b - rel[:, 2])[m]):.2f} / {(t2b - rel[:, 2])[m].max():.2f}")
 print("end  min/med/max us:", rel[:, 3].min(), np.median(rel[:, 3]), rel[:, 3].max())
 tot, nov = full[:, 4], full[:, 5]
 print("pairs per WG mean/max:", tot.mean(), tot.max(), " slow rows total:", nov.sum(), " WGs with slow rows:", (nov > 0).sum())
