@@ -64,8 +64,8 @@ constexpr int MS_BUF = TILE * MS_ROW;              // 8 448
 constexpr int PAIR_CAP = 2048;
 
 constexpr int L_Z16 = 0;                                   // 2 x fp16 tile
-constexpr int L_MS = L_Z16 + 2 * Z16_BUF;                  // 2 x merge slots
-constexpr int L_RS = L_MS + 2 * MS_BUF;                    // 4 x [32] {eps sE, flag}
+constexpr int L_MS = L_Z16 + 2 * Z16_BUF;                  // 3 x merge slots (tile % 3)
+constexpr int L_RS = L_MS + 3 * MS_BUF;                    // 4 x [32] {eps sE, flag}
 constexpr int L_EES = L_RS + 4 * TILE * 8;                 // [K] f32: sE |e_k|^2 (accumulator start values)
 constexpr int L_RES = L_EES + K * 4;                       // [MAX_TILES*32] u64 row results (ordered distance bits : entry)
 constexpr int L_PAIR = L_RES + MAX_TILES * TILE * 8;       // [PAIR_CAP] u32 (rowslot << 16 | entry)
@@ -324,7 +324,7 @@ __device__ __forceinline__ void write_slot(const Ctx& c, int t, float m1, float 
     f32x2 v;
     v[0] = m1;
     v[1] = m2;
-    ds_wr64<8 * JN>(c.lds0 + L_MS + (t & 1) * MS_BUF + (c.lane & 31) * MS_ROW + (2 * c.wave + (c.lane >> 5)) * 16, v);
+    ds_wr64<8 * JN>(c.lds0 + L_MS + ((t + 3) % 3) * MS_BUF + (c.lane & 31) * MS_ROW + (2 * c.wave + (c.lane >> 5)) * 16, v);
 }
 
 // d = h - x with h the low (HI = 0) or high (HI = 1) fp16 half of `hp`: one v_fma_mix_f32 (exact; the sign does not matter)
@@ -385,7 +385,7 @@ struct Merge {
     __device__ __forceinline__ void read(const Ctx& c, int tm) {
         const int g = c.lane >> 4, i = c.lane & 15;
         const int r = 4 * c.wave + g;
-        ds_rd128<0>(sl, c.lds0 + L_MS + (tm & 1) * MS_BUF + r * MS_ROW + i * 16);
+        ds_rd128<0>(sl, c.lds0 + L_MS + ((tm + 3) % 3) * MS_BUF + r * MS_ROW + i * 16);
         ds_rd64<0>(rs, c.lds0 + L_RS + (tm & 3) * (TILE * 8) + r * 8);
     }
     __device__ __forceinline__ void min_a() {                            // after the wait that pins sl, rs
@@ -512,43 +512,48 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
     __syncthreads();
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
 
-    // ---- tile loop, software-pipelined by hand: 32 MFMA gaps per tile, the vector work of four other tiles in the gaps
-    //   G0-3   acc0 <- k-steps 0-3 of tile t (starting from sE|e|^2)   | scores of acc1 (tile t-1), slot write
-    //   G4-8   acc1 <- k-steps 0-3, then both accumulators alternate   | merge of tile t-2
-    //   G9-22  k-steps 4-11                                            | tile t+1: fp32 -> fp16, row statistics; loads of tile t+2
-    //   G24    barrier (the fp16 image of tile t+1 and the slots of tile t-1 are complete; nobody reads image t any more)
-    //   G24-27 acc0 <- k-steps 12-15
-    //   G28-31 acc1 <- k-steps 12-15                                   | scores of acc0 (tile t); first reads of tile t+1
-    // LDS waits are by count of the fragment / start-value reads that are ALWAYS issued behind the awaited one; the other
-    // LDS operations in between only make a wait longer than necessary, never shorter.
+    // ---- tile loop, software-pipelined by hand: 32 MFMA gaps per tile, the vector work of four other tiles spread EVENLY
+    // over them (the vector port of a SIMD, shared by its two waves, is the scarce resource: a gap holds 6-9 vector
+    // instructions).  The two accumulators run one behind the other so that each is free for many gaps while it is scored:
+    //   B      barrier: the fp16 image of tile t is complete, nobody reads image t-1 any more
+    //   G0-7   acc0 <- k-steps 0-7 (starting from sE|e|^2)   | 16 scores of acc1 (tile t-1) -> its slots; acc1's start values
+    //   G8-15  acc1 <- k-steps 0-7 (fragments read again)    | merge of tile t-2; conversion of tile t+1 begins
+    //   G16-23 acc0 <- k-steps 8-15                          | conversion of tile t+1, row statistics; loads of tile t+2
+    //   G24-31 acc1 <- k-steps 8-15 (fragments read again)   | 16 scores of acc0 (tile t) -> its slots
+    // The body is generated (tools/gen_vq_tile.py: gap table -> code, with the counted waits derived from the program order of
+    // the reads that are ALWAYS issued; other LDS operations in between only make a wait longer, never shorter).
+    // Nothing is in flight at the end of a tile: the loop header is a control-flow join (rule 1 of the file header).
+    // Nothing is conditional on t except the row loads: tile "-1" is scored, tiles "-2", "-1" are merged (not live: no
+    // effect) and the tile behind the last one is converted (from stale registers, never used).
     f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
     f16x8 bf[16];
     f32x4 ci0[4], ci1[4];                                               // start values: read into the (just scored, free) accumulator's registers
     const int r_l = c.lane & 31, h_l = c.lane >> 5;
     const unsigned ea = c.lds0 + L_EES + (64 * c.wave + 4 * h_l) * 4;
     const unsigned zbase = c.lds0 + L_Z16 + r_l * Z16_ROW + 16 * h_l;
-    ds_rd128<0>(bf[0], zbase); ds_rd128<32>(bf[1], zbase); ds_rd128<64>(bf[2], zbase);
-    ds_rd128<0>(ci0[0], ea); ds_rd128<32>(ci0[1], ea); ds_rd128<64>(ci0[2], ea); ds_rd128<96>(ci0[3], ea);
-    ds_rd128<96>(bf[3], zbase);
     Merge mg;
 #define DVQ_MF0(S) if (!(ABL & 16)) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][S], bf[S], acc0, 0, 0, 0)
 #define DVQ_MF1(S) if (!(ABL & 16)) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][S], bf[S], acc1, 0, 0, 0)
 #define DVQ_SB() __builtin_amdgcn_sched_barrier(0)
 #define DVQ_PIN2(A, B) asm volatile("" : "+v"(A), "+v"(B))
-#define DVQ_WAITF(N, S) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(bf[S]))
 #define DVQ_RDF(S) ds_rd128<32 * (S)>(bf[S], za)
 #define DVQ_STAMP(SLOT) if (DBG) stamp(c, t, SLOT)
-    // The loop is rotated: front(t) = gaps 0-23 of tile t and the barrier, back(t) = gaps 24-31 (which issue tile t+1's first
-    // reads).  Nothing in the body is conditional on t except the row loads: tile "-1" is scored, tiles "-2", "-1" are
-    // merged (not live: no effect) and the tile behind the last one is converted (from stale registers, never used).
-    auto front = [&](const int t) __attribute__((always_inline)) {
+#define DVQ_SCORE(ACC, B, E) if (!(ABL & 8)) { score<B, E>(ACC, 0, m1, m2); DVQ_PIN2(m1, m2); }
+    auto tile = [&](const int t) __attribute__((always_inline)) {
+    // <<< GENERATED by tools/gen_vq_tile.py
         const bool do_load = !(ABL & 1) && t + 2 < c.ntl;
         const unsigned za = zbase + (t & 1) * Z16_BUF;
         DVQ_STAMP(0);
-        // G0-3.  LDS reads pending at this point, in issue order: fragments 0, 1, 2, the four start values of acc0, fragment 3
-        float m1 = INFINITY, m2 = INFINITY;                               // (min, second) of acc1 = 16 entries of tile t-1
-        if (!(ABL & 8)) { score<0, 6>(acc1, 0, m1, m2); DVQ_PIN2(m1, m2); }
-        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(ci0[0]), "+v"(ci0[1]), "+v"(ci0[2]), "+v"(ci0[3]), "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]));
+        if (ABL & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        DVQ_STAMP(1);
+        ds_rd128<0>(ci0[0], ea); ds_rd128<32>(ci0[1], ea); ds_rd128<64>(ci0[2], ea); ds_rd128<96>(ci0[3], ea);
+        DVQ_RDF(0); DVQ_RDF(1); DVQ_RDF(2);
+        float m1 = INFINITY, m2 = INFINITY;                               // (min, second) of one accumulator's 16 scores
+        f32x2 pk0, pk1, pk2, pk3;
+        // gap 0: acc0, k-step 0
+        DVQ_SCORE(acc1, 0, 3)
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ci0[0]), "+v"(ci0[1]), "+v"(ci0[2]), "+v"(ci0[3]), "+v"(bf[0]));
         {
             f32x16 st;
 #pragma unroll
@@ -557,22 +562,52 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
                 for (int e = 0; e < 4; ++e) st[4 * q + e] = ci0[q][e];
             if (!(ABL & 16)) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bf[0], st, 0, 0, 0);
         }
+        DVQ_RDF(3);
         DVQ_SB();
+        // gap 1: acc0, k-step 1
+        DVQ_SCORE(acc1, 3, 6)
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[1]));
         DVQ_MF0(1);
-        if (!(ABL & 8)) { score<6, 11>(acc1, 0, m1, m2); DVQ_PIN2(m1, m2); }
+        DVQ_RDF(4);
         DVQ_SB();
+        // gap 2: acc0, k-step 2
+        DVQ_SCORE(acc1, 6, 9)
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[2]));
         DVQ_MF0(2);
-        if (!(ABL & 8)) {
-            score<11, 16>(acc1, 0, m1, m2);
-            write_slot<1>(c, t - 1, m1, m2);
-        }
+        DVQ_RDF(5);
+        DVQ_SB();
+        // gap 3: acc0, k-step 3
+        DVQ_SCORE(acc1, 9, 12)
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[3]));
+        DVQ_MF0(3);
+        DVQ_RDF(6);
+        DVQ_SB();
+        // gap 4: acc0, k-step 4
+        DVQ_SCORE(acc1, 12, 14)
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[4]));
+        DVQ_MF0(4);
+        DVQ_RDF(7);
+        DVQ_SB();
+        // gap 5: acc0, k-step 5
+        if (!(ABL & 8)) { score<14, 16>(acc1, 0, m1, m2); write_slot<1>(c, t - 1, m1, m2); }
         ds_rd128<128>(ci1[0], ea); ds_rd128<160>(ci1[1], ea); ds_rd128<192>(ci1[2], ea); ds_rd128<224>(ci1[3], ea);
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(bf[5]));
+        DVQ_MF0(5);
+        DVQ_RDF(0);
         DVQ_SB();
-        DVQ_WAITF(4, 3); DVQ_MF0(3);
+        // gap 6: acc0, k-step 6
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(bf[6]));
+        DVQ_MF0(6);
+        DVQ_RDF(1);
         DVQ_SB();
-        // G4-7 (fragments are read two gaps ahead of their first use: an LDS read lands within one MFMA period of the SIMD)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ci1[0]), "+v"(ci1[1]), "+v"(ci1[2]), "+v"(ci1[3]));
-        if (!(ABL & 4)) mg.read(c, t - 2);
+        // gap 7: acc0, k-step 7
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(bf[7]));
+        DVQ_MF0(7);
+        DVQ_RDF(2);
+        DVQ_SB();
+        DVQ_STAMP(2);
+        // gap 8: acc1, k-step 0
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ci1[0]), "+v"(ci1[1]), "+v"(ci1[2]), "+v"(ci1[3]), "+v"(bf[0]));
         {
             f32x16 st;
 #pragma unroll
@@ -581,131 +616,160 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
                 for (int e = 0; e < 4; ++e) st[4 * q + e] = ci1[q][e];
             if (!(ABL & 16)) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][0], bf[0], st, 0, 0, 0);
         }
+        DVQ_RDF(3);
+        if (!(ABL & 4)) mg.read(c, t - 2);
         DVQ_SB();
+        // gap 9: acc1, k-step 1
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[1]));
         DVQ_MF1(1);
-        DVQ_SB();
         DVQ_RDF(4);
-        DVQ_MF1(2);
-        if (!(ABL & 4)) {
-            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(mg.sl), "+v"(mg.rs));
-            mg.min_a(); asm volatile("" : "+v"(mg.rmin));
-        }
         DVQ_SB();
+        // gap 10: acc1, k-step 2
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[2]));
+        DVQ_MF1(2);
+        DVQ_RDF(5);
+        if (!(ABL & 4)) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(mg.sl), "+v"(mg.rs));
+        if (!(ABL & 4)) { mg.min_a(); asm volatile("" : "+v"(mg.rmin)); }
+        DVQ_SB();
+        // gap 11: acc1, k-step 3
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[3]));
         DVQ_MF1(3);
+        DVQ_RDF(6);
         if (!(ABL & 4)) { mg.min_b(c); asm volatile("" : "+s"(mg.bA1), "+s"(mg.bB1)); }
         DVQ_SB();
-        DVQ_STAMP(1);
-        // G8-23: k-steps 4-11, both accumulators
-        DVQ_RDF(5);
-        DVQ_WAITF(1, 4); DVQ_MF0(4);
+        // gap 12: acc1, k-step 4
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[4]));
+        DVQ_MF1(4);
+        DVQ_RDF(7);
         if (!(ABL & 4)) mg.act(c, t - 2);
         DVQ_SB();
-        DVQ_MF1(4);
-        if (!(ABL & 2)) cv.start();
-        DVQ_SB();
-        DVQ_RDF(6);
-        DVQ_WAITF(1, 5); DVQ_MF0(5);
-        DVQ_SB();
+        // gap 13: acc1, k-step 5
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[5]));
         DVQ_MF1(5);
-        f32x2 pk0, pk1, pk2, pk3;
-        if (!(ABL & 2)) { cv.template cvt<0>(c, t + 1, x); pk0 = cv.pk; }
+        DVQ_RDF(8);
+        if (!(ABL & 2)) { cv.start(); cv.template cvt<0>(c, t + 1, x); pk0 = cv.pk; }
         DVQ_SB();
-        DVQ_RDF(7);
-        DVQ_WAITF(1, 6); DVQ_MF0(6);
+        // gap 14: acc1, k-step 6
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[6]));
+        DVQ_MF1(6);
+        DVQ_RDF(9);
         if (!(ABL & 2)) { cv.template err<0>(pk0[0], pk0[1], x); DVQ_PIN2(cv.hh, cv.dsq); }
         DVQ_SB();
-        DVQ_MF1(6);
+        // gap 15: acc1, k-step 7
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[7]));
+        DVQ_MF1(7);
+        DVQ_RDF(10);
         if (!(ABL & 2)) { cv.template cvt<1>(c, t + 1, x); pk1 = cv.pk; }
         DVQ_SB();
-        DVQ_RDF(8);
-        DVQ_WAITF(1, 7); DVQ_MF0(7);
+        DVQ_STAMP(3);
+        // gap 16: acc0, k-step 8
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[8]));
+        DVQ_MF0(8);
+        DVQ_RDF(11);
         if (!(ABL & 2)) { cv.template err<1>(pk1[0], pk1[1], x); DVQ_PIN2(cv.hh, cv.dsq); }
         DVQ_SB();
-        DVQ_MF1(7);
+        // gap 17: acc0, k-step 9
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[9]));
+        DVQ_MF0(9);
+        DVQ_RDF(12);
         if (!(ABL & 2)) { cv.template cvt<2>(c, t + 1, x); pk2 = cv.pk; }
         DVQ_SB();
-        DVQ_RDF(9);
-        DVQ_WAITF(1, 8); DVQ_MF0(8);
+        // gap 18: acc0, k-step 10
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[10]));
+        DVQ_MF0(10);
+        DVQ_RDF(13);
         if (!(ABL & 2)) { cv.template err<2>(pk2[0], pk2[1], x); DVQ_PIN2(cv.hh, cv.dsq); }
         DVQ_SB();
-        DVQ_MF1(8);
+        // gap 19: acc0, k-step 11
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[11]));
+        DVQ_MF0(11);
+        DVQ_RDF(14);
         if (!(ABL & 2)) { cv.template cvt<3>(c, t + 1, x); pk3 = cv.pk; }
         DVQ_SB();
-        DVQ_RDF(10);
-        DVQ_WAITF(1, 9); DVQ_MF0(9);
+        // gap 20: acc0, k-step 12
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[12]));
+        DVQ_MF0(12);
+        DVQ_RDF(15);
         if (!(ABL & 2)) { cv.template err<3>(pk3[0], pk3[1], x); DVQ_PIN2(cv.hh, cv.dsq); }
         DVQ_SB();
-        DVQ_MF1(9);
+        // gap 21: acc0, k-step 13
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[13]));
+        DVQ_MF0(13);
+        DVQ_RDF(8);
         if (do_load) load_rows(c, t + 2, x);                            // the registers are free: rows of tile t+2
         if (!(ABL & 2)) { cv.hh = row16_sum(cv.hh); DVQ_PIN2(cv.hh, cv.dsq); }
         DVQ_SB();
-        DVQ_RDF(11);
-        DVQ_WAITF(1, 10); DVQ_MF0(10);
+        // gap 22: acc0, k-step 14
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[14]));
+        DVQ_MF0(14);
+        DVQ_RDF(9);
         if (!(ABL & 2)) { cv.dsq = row16_sum(cv.dsq); DVQ_PIN2(cv.hh, cv.dsq); }
         DVQ_SB();
-        DVQ_MF1(10);
+        // gap 23: acc0, k-step 15
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[15]));
+        DVQ_MF0(15);
+        DVQ_RDF(10);
         if (!(ABL & 2)) cv.finish(c, t + 1);
         DVQ_SB();
-        DVQ_RDF(12);
-        DVQ_WAITF(1, 11); DVQ_MF0(11);
-        DVQ_SB();
-        DVQ_RDF(13); DVQ_RDF(14); DVQ_RDF(15);
-        DVQ_MF1(11);
-        DVQ_SB();
-        DVQ_STAMP(2);
-        // G24: every LDS operation of this wave complete (fragment reads of this tile included), then the barrier
-        if (ABL & 32) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[12]), "+v"(bf[13]), "+v"(bf[14]), "+v"(bf[15])::"memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(bf[12]), "+v"(bf[13]), "+v"(bf[14]), "+v"(bf[15])::"memory");
-        DVQ_STAMP(3);
-    };
-    auto back = [&](const int t) __attribute__((always_inline)) {
-        const unsigned za = zbase + ((t + 1) & 1) * Z16_BUF;               // the NEXT tile's image
-        DVQ_MF0(12);
-        DVQ_SB();
-        DVQ_MF0(13);
-        DVQ_SB();
-        DVQ_MF0(14);
-        DVQ_SB();
-        DVQ_MF0(15);
-        DVQ_SB();
-        // G28-31: scores of acc0; its registers then take the next tile's start values; first fragments of tile t+1
-        float m1 = INFINITY, m2 = INFINITY;                               // (min, second) of acc0 = 16 entries of tile t
-        DVQ_RDF(0);
-        DVQ_MF1(12);
-        if (!(ABL & 8)) { score<0, 6>(acc0, 0, m1, m2); DVQ_PIN2(m1, m2); }
-        DVQ_SB();
-        DVQ_RDF(1);
-        DVQ_MF1(13);
-        if (!(ABL & 8)) { score<6, 11>(acc0, 0, m1, m2); DVQ_PIN2(m1, m2); }
-        DVQ_SB();
-        DVQ_RDF(2);
-        DVQ_MF1(14);
-        if (!(ABL & 8)) { score<11, 16>(acc0, 0, m1, m2); write_slot<0>(c, t, m1, m2); }
-        ds_rd128<0>(ci0[0], ea); ds_rd128<32>(ci0[1], ea); ds_rd128<64>(ci0[2], ea); ds_rd128<96>(ci0[3], ea);
-        DVQ_SB();
-        DVQ_RDF(3);
-        DVQ_MF1(15);
-        DVQ_SB();
         DVQ_STAMP(4);
+        // gap 24: acc1, k-step 8
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[8]));
+        DVQ_MF1(8);
+        DVQ_RDF(11);
+        m1 = INFINITY;
+        m2 = INFINITY;
+        DVQ_SB();
+        // gap 25: acc1, k-step 9
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[9]));
+        DVQ_MF1(9);
+        DVQ_RDF(12);
+        DVQ_SCORE(acc0, 0, 3)
+        DVQ_SB();
+        // gap 26: acc1, k-step 10
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[10]));
+        DVQ_MF1(10);
+        DVQ_RDF(13);
+        DVQ_SCORE(acc0, 3, 6)
+        DVQ_SB();
+        // gap 27: acc1, k-step 11
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[11]));
+        DVQ_MF1(11);
+        DVQ_RDF(14);
+        DVQ_SCORE(acc0, 6, 8)
+        DVQ_SB();
+        // gap 28: acc1, k-step 12
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[12]));
+        DVQ_MF1(12);
+        DVQ_RDF(15);
+        DVQ_SCORE(acc0, 8, 10)
+        DVQ_SB();
+        // gap 29: acc1, k-step 13
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[13]));
+        DVQ_MF1(13);
+        DVQ_SCORE(acc0, 10, 12)
+        DVQ_SB();
+        // gap 30: acc1, k-step 14
+        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bf[14]));
+        DVQ_MF1(14);
+        DVQ_SCORE(acc0, 12, 14)
+        DVQ_SB();
+        // gap 31: acc1, k-step 15
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[15]));
+        DVQ_MF1(15);
+        if (!(ABL & 8)) { score<14, 16>(acc0, 0, m1, m2); write_slot<0>(c, t, m1, m2); }
+        DVQ_SB();
+        DVQ_STAMP(5);
+    // >>> GENERATED
     };
-    {
-        front(0);
-        for (int t = 0; t + 1 < c.ntl; ++t) {
-            back(t);
-            front(t + 1);
-        }
-        back(c.ntl - 1);
-        // the last prefetch has no consumer, but its destination registers must stay reserved until the data has landed
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bf[0]), "+v"(bf[1]), "+v"(bf[2]), "+v"(bf[3]), "+v"(ci0[0]), "+v"(ci0[1]), "+v"(ci0[2]),
-                     "+v"(ci0[3])::"memory");
-    }
+    for (int t = 0; t < c.ntl; ++t) tile(t);
 #undef DVQ_MF0
 #undef DVQ_MF1
 #undef DVQ_SB
-#undef DVQ_WAITF
 #undef DVQ_PIN2
 #undef DVQ_RDF
 #undef DVQ_STAMP
+#undef DVQ_SCORE
+    wg_barrier();                                                       // every slot of the accumulator-0 lists is written
     // last scores, last merges
     {
         float m1 = INFINITY, m2 = INFINITY;

@@ -57,11 +57,10 @@ for lo, hi in ((0, 33), (33, 65), (65, 129), (129, 10000)):
 print("end  min/med/max us:", rel[:, 3].min(), np.median(rel[:, 3]), rel[:, 3].max())
 tot, nov = full[:, 4], full[:, 5]
 print("pairs per WG mean/max:", tot.mean(), tot.max(), " slow rows total:", nov.sum(), " WGs with slow rows:", (nov > 0).sum())
-# in-loop stamps (shader clock, 32-bit) of the pipelined iteration: 0 start, 1 after gap 7, 2 in front of the barrier (gap 24),
-# 3 behind it, 4 end of the iteration
+# in-loop stamps (shader clock, 32-bit) of one tile: 0 start, 1 behind the barrier, 2 after gap 7, 3 after gap 15, 4 after gap 23, 5 end
 def d(a, b, tile):
     v = ((st[:, :, tile, b] - st[:, :, tile, a]) & 0xffffffff).reshape(-1)
     return f"{np.median(v):7.0f} /{np.percentile(v, 90):7.0f}"
 for tile, name in ((0, "t=2"), (1, "t=5")):
-    print(f"-- iteration {name}: median / p90 shader cycles:  gaps 0-7", d(0, 1, tile), " gaps 8-23", d(1, 2, tile), " barrier", d(2, 3, tile),
-          " gaps 24-31", d(3, 4, tile), " total", d(0, 4, tile))
+    print(f"-- tile {name}: median / p90 shader cycles:  barrier", d(0, 1, tile), " gaps 0-7", d(1, 2, tile), " gaps 8-15", d(2, 3, tile),
+          " gaps 16-23", d(3, 4, tile), " gaps 24-31", d(4, 5, tile), " total", d(0, 5, tile))
