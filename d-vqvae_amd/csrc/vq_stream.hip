@@ -21,8 +21,8 @@
 //     per chain) of the listed pairs, ds_min_u64 of (ordered distance bits, entry) per row = torch.argmin's order
 //     (first minimum, NaN first).  Rows with NaN/Inf, fp16 overflow or an overflowing list: all K entries canonically.
 //
-// Error bound (filter keeps the exact winner).  No per-row scaling: h(.) = round to fp16 with subnormals flushed (MODE
-// register: the conversion instruction flushes, so what the matrix core sees is what the error was measured on).
+// Error bound (filter keeps the exact winner).  No per-row scaling: h(.) = round to nearest fp16, subnormals kept (by the
+// conversion and, measured on gfx950, by the matrix core: tests/test_gpu_parity.py::test_mfma_keeps_f16_subnormals).
 // With dz_j = z_j - h(z_j), de_kj = e_kj - h(-2 sE e_kj)/(-2 sE) (exact in fp32), products h.h exact in the MFMA's fp32,
 // T_k = sE (true_k - |z|^2), gamma_n = n 2^-24 (gamma'_n = n 2^-23 allows a truncating accumulator):
 //   |S_k - T_k|         <= sE [2 (|dz||e_k| + |z||de_k| + |dz||de_k|) + gamma'_259 (|e_k|^2 + 2|z||e_k|)]          (filter)
@@ -30,7 +30,8 @@
 //   |packed(S_k) - S_k| <= 2^-18 |S_k| <= 2^-18 sE (|z| + |e_k|)^2                                 (5-bit id in the mantissa)
 // so for the canonical winner k* and every k:  packed(S_k*) <= packed(S_k) + sE eps_row,
 //   eps_row = 4 (|dz| Emax + |z| dEmax + |dz| dEmax) + (2 gamma'_259 + 2^-17 + 2 gamma_260 = 9.97e-5) (|z| + Emax)^2,
-// |dz| measured by the kernel's own conversion, |z| <= |h(z)| + |dz|, dEmax by dvq_vq_pack, norms rounded up.  A slot whose
+// |dz| measured by the kernel's own conversion (-DDVQ_MEASURE_DZ=0: half-ulp bound 2^-11 |h(z)| + 2^-21), |z| <= |h(z)| + |dz|, dEmax measured by
+// dvq_vq_pack, norms rounded up.  A slot whose
 // SECOND score is within eps may hide a third: all 32 entries of that slot are listed, so the list always contains k*.
 // Algorithmic HBM bytes per row: D*4 (z) + 8 (int64 index); the codebook (K*D*4) is read once.
 //
@@ -134,13 +135,11 @@ __global__ void vq_pack_norm_kernel(const float* __restrict__ E, float* __restri
     }
 }
 
-// image: fp16 of -2 sE e in fragment order; subnormal results are stored as zero (the matrix core may flush them)
+// image: fp16 of -2 sE e in fragment order
 __global__ void vq_pack_img_kernel(const float* __restrict__ E, const PackHeader* __restrict__ hdr, _Float16* __restrict__ img) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= K * D) return;
-    _Float16 hv = (_Float16)(-2.0f * pow2f(hdr->sexp) * E[gid]);
-    if (fabsf((float)hv) < 6.103515625e-05f) hv = (_Float16)0.f;
-    img[img_pos(gid / D, gid % D)] = hv;
+    img[img_pos(gid / D, gid % D)] = (_Float16)(-2.0f * pow2f(hdr->sexp) * E[gid]);   // (subnormals kept; the error kernel measures what is stored)
 }
 
 // measured rounding error of the image, per entry, as a 2-norm in codebook units; its maximum goes into the header
@@ -337,6 +336,9 @@ __device__ __forceinline__ float mix_diff(float hp, float x) {
 }
 
 // fp32 -> fp16 conversion of the wave's 4 rows of a tile in pieces (the pipelined loop puts one piece into each MFMA gap)
+#ifndef DVQ_MEASURE_DZ
+#define DVQ_MEASURE_DZ 1   // 1: |z - h(z)| measured element by element (31 vector instructions per wave and tile; eps_row 0.65x, 0.65x the pairs in the refine tail: measured 36.0 vs 37.3 us per call); 0: half-ulp bound
+#endif
 struct Convert {
     float hh, dsq;                                                     // sum h(z)^2, sum (z - h(z))^2
     f32x2 pk;
@@ -355,14 +357,20 @@ struct Convert {
     }
     template <int Q>
     __device__ __forceinline__ void err(float lo_hi0, float lo_hi1, const f32x4 (&x)[4]) {   // rounding error of quad Q (pk of that quad)
-        const float d0 = mix_diff<0>(lo_hi0, x[Q][0]), d1 = mix_diff<1>(lo_hi0, x[Q][1]);
-        const float d2 = mix_diff<0>(lo_hi1, x[Q][2]), d3 = mix_diff<1>(lo_hi1, x[Q][3]);
-        dsq = fmaf(d0, d0, dsq); dsq = fmaf(d1, d1, dsq); dsq = fmaf(d2, d2, dsq); dsq = fmaf(d3, d3, dsq);
+        if (DVQ_MEASURE_DZ) {
+            const float d0 = mix_diff<0>(lo_hi0, x[Q][0]), d1 = mix_diff<1>(lo_hi0, x[Q][1]);
+            const float d2 = mix_diff<0>(lo_hi1, x[Q][2]), d3 = mix_diff<1>(lo_hi1, x[Q][3]);
+            dsq = fmaf(d0, d0, dsq); dsq = fmaf(d1, d1, dsq); dsq = fmaf(d2, d2, dsq); dsq = fmaf(d3, d3, dsq);
+        }
     }
     __device__ __forceinline__ void finish(const Ctx& c, int j) {        // hh, dsq already reduced over the row's 16 lanes
         const int g = c.lane >> 4, i = c.lane & 15;
-        const float dzn = __builtin_amdgcn_sqrtf(dsq) * 1.0001f;
-        const float zn = (__builtin_amdgcn_sqrtf(hh) + dzn) * 1.0001f;  // |z| <= |h(z)| + |z - h(z)|
+        const float hn = __builtin_amdgcn_sqrtf(hh);
+        // |z - h(z)|: measured, or a priori: half an ulp of a normal fp16 is at most 2^-11 |h|, of a subnormal one 2^-25
+        // (16 * 2^-25 over a row); fp16 subnormals are KEPT by the conversion (MODE) and by the matrix core (measured on gfx950:
+        // tools/microbench/f16_denorm_probe.hip, asserted by tests/test_gpu_parity.py::test_mfma_keeps_f16_subnormals)
+        const float dzn = DVQ_MEASURE_DZ ? __builtin_amdgcn_sqrtf(dsq) * 1.0001f : hn * 4.8877e-4f + 4.8e-7f;
+        const float zn = (hn + dzn) * 1.0001f;                          // |z| <= |h(z)| + |z - h(z)|
         const float eps = 4.004f * (dzn * c.emax + zn * c.demax + dzn * c.demax) + 1.01e-4f * (zn + c.emax) * (zn + c.emax);
         const float epsS = eps * c.sEf;
         const bool bad = !c.e_valid || !(hh <= 3.0e38f) || !(dsq <= 3.0e38f) || !(epsS <= 3.0e38f);   // NaN/Inf, fp16 overflow
@@ -475,9 +483,8 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
     c.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     c.lds0 = lds_addr(lds);
     const float* ee_g = reinterpret_cast<const float*>(packed + PK_OFF_EE);
-    // fp16 subnormals flush to zero in conversions (MODE.FP_DENORM[3:2] = 0): the rounding error is measured on exactly
-    // the values the matrix core multiplies (measured on gfx950: the MFMA keeps fp16 subnormal inputs; this does not rely on it)
-    __builtin_amdgcn_s_setreg((2 - 1) << 11 | 6 << 6 | 1, 0);            // hwreg(HW_REG_MODE, offset 6, width 2) <- 0
+    // fp16 subnormals are kept by conversions (MODE.FP_DENORM[3:2] = 3, stated explicitly) as they are by the matrix core
+    __builtin_amdgcn_s_setreg((2 - 1) << 11 | 6 << 6 | 1, 3);            // hwreg(HW_REG_MODE, offset 6, width 2) <- 3
 
     // ---- prologue: header and |e|^2 (small, needed first), the first two tiles, then the codebook slice (needed last)
     const PackHeader* hdr = reinterpret_cast<const PackHeader*>(packed);
