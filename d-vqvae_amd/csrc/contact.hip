@@ -101,9 +101,11 @@ extern "C" int dvq_nn_points(const float* src, int64_t src_batch_stride, int64_t
     DVQ_REQUIRE(B <= 65535LL * 65535LL, "nn_points: B too large");
     hipStream_t st = (hipStream_t)stream;
     static DvqOncePerDevice attr_once;
-    if (attr_once.first()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nn_points_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, NN_MAX_TRG * 12);
+    {
+        const hipError_t e = attr_once.run([] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&nn_points_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       NN_MAX_TRG * 12);
+        });
         if (e != hipSuccess) {
             dvq_set_error("nn_points: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return DVQ_ELAUNCH;

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
+#include <mutex>
 #include "../../include/dvq.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -19,16 +21,26 @@ void dvq_set_error(const char* fmt, ...);
         }                                           \
     } while (0)
 
-// Function attributes (dynamic LDS limit) are per device: one process may drive several GPUs.
+// Function attributes (dynamic LDS limit) are per device: one process may drive several GPUs, from several threads.
+// run(fn) calls fn() once per device; concurrent first calls are serialised, and a FAILED attempt is not remembered
+// (the next launch on that device tries again and reports again).
 struct DvqOncePerDevice {
-    unsigned long long mask[2] = {0, 0};
-    bool first() {
+    std::atomic<unsigned char> done[128];
+    std::mutex lock;
+    DvqOncePerDevice() {
+        for (auto& d : done) d.store(0, std::memory_order_relaxed);
+    }
+    template <class F>
+    hipError_t run(F&& fn) {
         int d = 0;
         (void)hipGetDevice(&d);
         d &= 127;
-        const bool f = !((mask[d >> 6] >> (d & 63)) & 1ull);
-        mask[d >> 6] |= 1ull << (d & 63);
-        return f;
+        if (done[d].load(std::memory_order_acquire)) return hipSuccess;
+        std::lock_guard<std::mutex> g(lock);
+        if (done[d].load(std::memory_order_relaxed)) return hipSuccess;
+        const hipError_t e = fn();
+        if (e == hipSuccess) done[d].store(1, std::memory_order_release);
+        return e;
     }
 };
 

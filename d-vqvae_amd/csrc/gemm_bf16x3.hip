@@ -441,9 +441,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(const GemmParam
 template <int EPI>
 int launch_dma(const GemmParams& p, hipStream_t stream) {
     static DvqOncePerDevice attr_once;
-    if (attr_once.first()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_dma_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_SMEM);
+    {
+        const hipError_t e = attr_once.run([] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_dma_kernel<EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)D_SMEM);
+        });
         if (e != hipSuccess) {
             dvq_set_error("gemm_bf16x3: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return DVQ_ELAUNCH;
@@ -508,9 +510,11 @@ __global__ void split_bf16x3_kernel(const float* __restrict__ w, long n, uint16_
 template <int EPI, bool WPLANES>
 int launch(const GemmParams& p, hipStream_t stream) {
     static DvqOncePerDevice attr_once;
-    if (attr_once.first()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_kernel<EPI, WPLANES>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BYTES);
+    {
+        const hipError_t e = attr_once.run([] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_kernel<EPI, WPLANES>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BYTES);
+        });
         if (e != hipSuccess) {
             dvq_set_error("gemm_bf16x3: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return DVQ_ELAUNCH;

@@ -130,9 +130,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmParams p) {
 template <int EPI>
 int launch(const GemmParams& p, hipStream_t stream) {
     static DvqOncePerDevice attr_once;
-    if (attr_once.first()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM_BYTES);
+    {
+        const hipError_t e = attr_once.run([] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)SMEM_BYTES);
+        });
         if (e != hipSuccess) {
             dvq_set_error("gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return DVQ_ELAUNCH;

@@ -12,7 +12,7 @@ void dvq_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* dvq_last_error(void) { return g_err; }
-extern "C" int dvq_abi_version(void) { return 2; }
+extern "C" int dvq_abi_version(void) { return 3; }
 extern "C" int dvq_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return -1;
@@ -29,6 +29,7 @@ struct ProfRec { int kind; hipEvent_t a, b; double flops, bytes; };
 std::vector<ProfRec> g_recs;
 std::vector<std::string> g_kinds;
 std::vector<hipEvent_t> g_pool;
+std::mutex g_prof_lock;                 // launches may come from several threads (one stream each)
 int kind_id(const char* name) {
     for (size_t i = 0; i < g_kinds.size(); ++i) if (g_kinds[i] == name) return (int)i;
     g_kinds.emplace_back(name);
@@ -44,22 +45,27 @@ hipEvent_t get_event() {
 
 DvqProfScope::DvqProfScope(const char* kind, double flops, double bytes, hipStream_t st) : slot(-1), stream(st) {
     if (!g_dvq_prof_on) return;
+    std::lock_guard<std::mutex> g(g_prof_lock);
     ProfRec r{kind_id(kind), get_event(), get_event(), flops, bytes};
     (void)hipEventRecord(r.a, st);
     g_recs.push_back(r);
     slot = (int)g_recs.size() - 1;
 }
 DvqProfScope::~DvqProfScope() {
-    if (slot >= 0) (void)hipEventRecord(g_recs[slot].b, stream);
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> g(g_prof_lock);
+    if (slot < (int)g_recs.size()) (void)hipEventRecord(g_recs[slot].b, stream);
 }
 
 extern "C" int dvq_prof_enable(int on) { g_dvq_prof_on = on != 0; return DVQ_OK; }
 extern "C" int dvq_prof_reset(void) {
+    std::lock_guard<std::mutex> g(g_prof_lock);
     for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
     g_recs.clear();
     return DVQ_OK;
 }
 extern "C" int dvq_prof_read(dvq_prof_entry* out, int max_entries) {
+    std::lock_guard<std::mutex> g(g_prof_lock);
     std::vector<dvq_prof_entry> acc(g_kinds.size());
     for (size_t i = 0; i < g_kinds.size(); ++i) {
         memset(&acc[i], 0, sizeof(dvq_prof_entry));
@@ -157,6 +163,53 @@ __global__ void transform_cloud_kernel(const float* __restrict__ pc, long pc_bst
     for (int c = 3; c < C; ++c) dst[c * N + n] = src[c * N + n];
 }
 
+// Philox4x32-10 (Salmon et al., SC'11), counter = (column quad, row low, row high, stream), key = seed
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+// out[r, 4q..4q+3] = -log(u), u = (24 random bits + 0.5) 2^-24 in (0, 1): Exp(1) variates that depend only on
+// (seed, stream, GLOBAL row row0 + r, column), not on how the rows are split into calls, batches or ranks
+__global__ void exp1_noise_kernel(unsigned long long seed, unsigned stream_id, long row0, long rows, int cols, float* __restrict__ out) {
+    const int quads = cols / 4;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long r = gid / quads;
+    const int q = (int)(gid % quads);
+    if (r >= rows) return;
+    const unsigned long long grow = (unsigned long long)(row0 + r);
+    unsigned c[4] = {(unsigned)q, (unsigned)grow, (unsigned)(grow >> 32), stream_id};
+    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = -logf(((float)(c[i] >> 8) + 0.5f) * 5.9604644775390625e-08f);
+    *reinterpret_cast<f32x4*>(out + r * cols + 4 * q) = v;
+}
+
+// does the matrix core keep fp16 subnormal inputs?  out[0] = sum over k of a_k b_k with a_0 = a_8 = 16 * 2^-24 (subnormal),
+// b = 1024: 2 * 2^-10 when kept, 0 when flushed; out[1] = the same product by scalar fp32 arithmetic
+typedef _Float16 probe_f16x8 __attribute__((ext_vector_type(8)));
+__global__ void probe_f16_subnormal_kernel(float* out) {
+    probe_f16x8 a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)0.f; b[i] = (_Float16)0.f; }
+    const unsigned short bits = 0x0010;
+    a[0] = __builtin_bit_cast(_Float16, bits);
+    b[0] = (_Float16)1024.f;
+    f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    if (threadIdx.x == 0) {
+        out[0] = c[0];
+        out[1] = 2.0f * (16.0f * 5.9604644775390625e-08f) * 1024.0f;
+    }
+}
+
 }  // namespace
 
 int dvq_launch_gather_rows(const float* table, const int64_t* idx, long idx_stride, long M, int K, int D, float* out,
@@ -223,5 +276,27 @@ extern "C" int dvq_transform_cloud(const float* pc, int64_t pc_batch_stride, con
     DVQ_LAUNCH(transform_cloud_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        pc, (long)pc_batch_stride, R, t, (long)B, C, N, out);
     DVQ_CHECK_LAUNCH("transform_cloud");
+    return DVQ_OK;
+}
+
+extern "C" int dvq_exp1_noise(uint64_t seed, uint32_t stream_id, int64_t row0, int64_t rows, int cols, float* out, dvq_stream_t stream) {
+    DVQ_REQUIRE(rows >= 0 && cols > 0 && cols % 4 == 0 && row0 >= 0, "exp1_noise: bad shape rows=%ld cols=%d row0=%ld", (long)rows, cols, (long)row0);
+    if (rows == 0) return DVQ_OK;
+    DVQ_REQUIRE(out && dvq_aligned16(out), "exp1_noise: null/unaligned output");
+    const long total = rows * (cols / 4);
+    DVQ_REQUIRE(total < (1L << 31) * 256, "exp1_noise: too many elements");
+    {
+        DVQ_PROF("exp1_noise", 0, (double)rows * cols * 4, (hipStream_t)stream);
+        DVQ_LAUNCH(exp1_noise_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                   (unsigned long long)seed, (unsigned)stream_id, (long)row0, (long)rows, cols, out);
+    }
+    DVQ_CHECK_LAUNCH("exp1_noise");
+    return DVQ_OK;
+}
+
+extern "C" int dvq_probe_f16_subnormal(float* out, dvq_stream_t stream) {
+    DVQ_REQUIRE(out, "probe_f16_subnormal: null pointer");
+    DVQ_LAUNCH(probe_f16_subnormal_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out);
+    DVQ_CHECK_LAUNCH("probe_f16_subnormal");
     return DVQ_OK;
 }

@@ -1,7 +1,11 @@
 // PointNet encoder (PointNetEncoder.forward, network/pointnet_encoder.py:140-169; STN3d.forward :27-45).
-// Layer 1 (C -> 64, K = 3/4) is a VALU kernel that also applies the 3x3 input transform; layers 2/3
-// run on the fp32 MFMA GEMM, the 128 -> 1024 layer with the per-sample max fused into its epilogue so
-// the [N,1024] activation is never written.  BatchNorm (eval) is folded into the weights by the packer.
+// Default path: ONE fused trunk kernel per encoder pass (pn_trunk_kernel, below): conv1 (C -> 64, vector ALU, with the 3x3
+// input transform xyz @ trans) -> conv2 (64 -> 128) -> conv3 (128 -> 1024) -> max over the points, on the split-bf16
+// (bf16x3) matrix-core arithmetic; no per-point activation ever leaves the CU, the kernel writes one row of column maxima
+// per 128 points and colmax_reduce_kernel finishes the max.  The STN's FC layers (1024 -> 512 -> 256 -> 9) use the GEMM.
+// With DVQ_GEMM=fp32 (exercised by tests/test_gpu_parity.py::test_fp32_gemm_branch_matches_goldens) the trunk runs
+// unfused instead: pn_layer1_kernel (vector ALU) + two fp32-MFMA GEMMs, the second with the column-max epilogue.
+// BatchNorm (eval) is folded into the weights by the packer (packing.py, fp64 fold, rounded once).
 #include "dvq_internal.h"
 
 int dvq_launch_pn_trunk(const float* pc, int C, int N, long B, const float* trans, const float* W1, const float* b1,
@@ -363,9 +367,18 @@ int dvq_launch_pn_trunk(const float* pc, int C, int N, long B, const float* tran
                         hipStream_t st) {
     const int tiles = (N + 127) / 128;
     static DvqOncePerDevice attr_once;
-    if (attr_once.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_trunk_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_trunk_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+    {
+        const hipError_t e = attr_once.run([] {
+            const hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_trunk_kernel<3>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+            const hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_trunk_kernel<4>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+            return e3 != hipSuccess ? e3 : e4;
+        });
+        if (e != hipSuccess) {
+            dvq_set_error("pointnet: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return DVQ_ELAUNCH;
+        }
     }
     const long grid = B * tiles;
     DVQ_REQUIRE(grid < (1L << 31), "pointnet: grid too large");

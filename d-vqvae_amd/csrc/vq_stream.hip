@@ -71,7 +71,7 @@ constexpr int L_EES = L_RS + 4 * TILE * 8;                 // [K] f32: sE |e_k|^
 constexpr int L_RES = L_EES + K * 4;                       // [MAX_TILES*32] u64 row results (ordered distance bits : entry)
 constexpr int L_PAIR = L_RES + MAX_TILES * TILE * 8;       // [PAIR_CAP] u32 (rowslot << 16 | entry)
 constexpr int L_SLOW = L_PAIR + PAIR_CAP * 4;              // [MAX_TILES*32] u16 rowslots for the all-entries path
-constexpr int L_CNT = L_SLOW + MAX_TILES * TILE * 2;       // [0] pairs, [1] slow rows
+constexpr int L_CNT = L_SLOW + MAX_TILES * TILE * 2;       // [0] pairs, [1] rows for the all-entries path, [2] rows with >= 32 pairs
 constexpr int L_DBG = L_CNT + 64;                          // [8 waves][32] u32 phase stamps (DVQ_VQ_DBG only)
 constexpr int LDS_BYTES = L_DBG + NWV * 32 * 4;
 constexpr int DBG_WG_BYTES = 64 + NWV * 32 * 4;            // per-workgroup debug record in the workspace
@@ -441,6 +441,7 @@ struct Merge {
         pos = (unsigned)__builtin_amdgcn_readlane((int)pos, 0) * (g == 0) + (unsigned)__builtin_amdgcn_readlane((int)pos, 16) * (g == 1) +
               (unsigned)__builtin_amdgcn_readlane((int)pos, 32) * (g == 2) + (unsigned)__builtin_amdgcn_readlane((int)pos, 48) * (g == 3);
         const bool fits = pos + (unsigned)need <= (unsigned)PAIR_CAP;
+        if (amb && i == 0 && fits && need >= 32) asm volatile("ds_add_u32 %0, %1" ::"v"(c.lds0 + L_CNT + 8), "v"(1u) : "memory");   // heavily ambiguous row
         if (amb && fits && (cA1 || cB1)) {
             const unsigned lt = (1u << i) - 1u;
             unsigned off = pos + (unsigned)(__popc(sA1 & ~sA2 & lt) + __popc(sB1 & ~sB2 & lt)) + 16u * (unsigned)(__popc(sA2 & lt) + __popc(sB2 & lt));
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
     }
     for (int u = tid; u < MAX_TILES * TILE; u += NT) reinterpret_cast<unsigned long long*>(lds + L_RES)[u] = ~0ull;
     for (int u = tid; u < PAIR_CAP; u += NT) reinterpret_cast<unsigned*>(lds + L_PAIR)[u] = ~0u;   // holes of refused reservations stay invalid
-    if (tid < 2) reinterpret_cast<unsigned*>(lds + L_CNT)[tid] = 0u;
+    if (tid < 3) reinterpret_cast<unsigned*>(lds + L_CNT)[tid] = 0u;
     reinterpret_cast<float*>(lds + L_EES)[tid] = ee_mine * c.sEf;
     Convert cv;
     {
@@ -828,7 +829,9 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
         const float tsum = zz2 + ee_g[tid];
         atomicMin(&s_res[rowslot], order_key(tsum - 2.0f * dot2, tid));
     }
-    if (slow_rows && n_slow > 0 && tid == 0) atomicAdd(slow_rows, (unsigned long long)n_slow);
+    // rows that cost far more than a filtered row: the all-entries path and rows with two or more expanded slots (callers watch
+    // this count to fall back to the exact kernel on ill-conditioned input, see dvq.h)
+    if (slow_rows && tid == 0 && n_slow + (int)s_cnt[2] > 0) atomicAdd(slow_rows, (unsigned long long)(n_slow + (int)s_cnt[2]));
     __syncthreads();
     if (tid < c.ntl * TILE) {
         const long gr = grow_of(tid);
@@ -905,16 +908,19 @@ extern "C" int dvq_vq_argmin_fast(const float* z, const float* E, const void* pa
     }
     hipStream_t st = (hipStream_t)stream;
     static DvqOncePerDevice attr_once;
-    if (attr_once.first()) {
-        hipError_t e = hipSuccess;
-        for (const void* fn : {(const void*)&vq_stream_kernel<0, false>, (const void*)&vq_stream_kernel<0, true>,
+    {
+        const hipError_t e = attr_once.run([] {
+            hipError_t e = hipSuccess;
+            for (const void* fn : {(const void*)&vq_stream_kernel<0, false>, (const void*)&vq_stream_kernel<0, true>,
                                (const void*)&vq_stream_kernel<1, true>, (const void*)&vq_stream_kernel<2, true>,
                                (const void*)&vq_stream_kernel<4, true>, (const void*)&vq_stream_kernel<8, true>,
                                (const void*)&vq_stream_kernel<16, true>, (const void*)&vq_stream_kernel<32, true>,
                                (const void*)&vq_stream_kernel<15, true>, (const void*)&vq_stream_kernel<47, true>}) {
-            const hipError_t e1 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-            if (e1 != hipSuccess) e = e1;
-        }
+                const hipError_t e1 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+                if (e1 != hipSuccess) e = e1;
+            }
+            return e;
+        });
         if (e != hipSuccess) {
             dvq_set_error("vq_argmin_fast: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return DVQ_ELAUNCH;

@@ -48,11 +48,22 @@ def all_gather_rows(local: torch.Tensor, total_rows: Optional[int] = None) -> to
     local = local.contiguous()
     if local.is_cuda and dist.get_backend() == "gloo":       # gloo gathers host tensors only (one-GPU plumbing tests)
         return all_gather_rows(local.cpu(), total_rows).to(local.device)
-    if total_rows is None or total_rows % world == 0:
-        out = torch.empty((local.shape[0] * world,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if total_rows is not None and total_rows % world == 0 and local.shape[0] * world == total_rows:
+        out = torch.empty((total_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local)
         return out
-    sizes = [shard_range(total_rows, r, world) for r in range(world)]
+    if total_rows is None:                                   # shard sizes unknown: exchange them first (one tiny all-gather)
+        counts = torch.empty(world, dtype=torch.int64, device=local.device)
+        dist.all_gather_into_tensor(counts, torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device))
+        counts = [int(v) for v in counts.tolist()]
+        sizes, lo = [], 0
+        for n in counts:
+            sizes.append((lo, lo + n))
+            lo += n
+    else:
+        sizes = [shard_range(total_rows, r, world) for r in range(world)]
+        if sizes[rank][1] - sizes[rank][0] != local.shape[0]:
+            raise RuntimeError(f"all_gather_rows: rank {rank} holds {local.shape[0]} rows, shard_range says {sizes[rank][1] - sizes[rank][0]}")
     pad = max(hi - lo for lo, hi in sizes)
     buf = torch.zeros((pad,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     buf[: local.shape[0]] = local

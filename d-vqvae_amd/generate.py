@@ -103,8 +103,11 @@ def load_model(args, device) -> GenNet:
 
 @torch.no_grad()
 def generate_for_object(net: GenNet, obj4n: torch.Tensor, num_grasp: int, rotate: bool, rng: np.random.Generator,
-                        noise: Optional[torch.Tensor] = None, proxies: bool = False) -> Dict[str, object]:
+                        noise: Optional[torch.Tensor] = None, proxies: bool = False, seed: Optional[int] = None,
+                        object_index: Optional[int] = None, row0: int = 0) -> Dict[str, object]:
     """num_grasp grasps for one object in ONE batched call.  Returns the reference's JSON fields plus tensors.
+    ``seed`` / ``object_index`` / ``row0`` key the prior's device noise (seed, stream = object, global grasp row), so the
+    grasps of an object do not depend on which rank generates it or on how its grasps are split into calls.
     ``proxies``: also the per-grasp penetration / contact proxies (contact.grasp_proxies) of the posed hands against
     the (rotated) object clouds -- the cheap on-device stand-in for the scripts' trimesh / pybullet metrics."""
     dev = next(net.parameters()).device
@@ -119,7 +122,7 @@ def generate_for_object(net: GenNet, obj4n: torch.Tensor, num_grasp: int, rotate
         t = np.zeros(3)
     batch = ops.transform_cloud(obj4n.to(dev).contiguous(), torch.as_tensor(R, dtype=torch.float32, device=dev),
                                 torch.as_tensor(t, dtype=torch.float32, device=dev))
-    recon, pos = net.gen(batch, noise=noise)
+    recon, pos = net.gen(batch, noise=noise, seed=seed, row0=row0, stream_id=object_index)
     params = ops.assemble61(recon, pos)                                            # obman.py:243-247
     final = net.rh_mano(betas=params[:, :10], global_orient=params[:, 10:13], hand_pose=params[:, 13:58],
                         transl=params[:, 58:61])                                   # obman.py:252-253
@@ -147,8 +150,7 @@ def main(dataset: str, argv: Optional[Sequence[str]] = None) -> List[str]:
         raise RuntimeError("the HIP path needs a GPU: there is no CPU fallback (use the reference on CPU)")
     device = torch.device(args.device) if args.device else torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-    torch.manual_seed(args.seed + rank)
-    rng = np.random.default_rng(args.seed)
+    torch.manual_seed(args.seed)
     net = load_model(args, device)
     if args.objects:
         objs = [(os.path.splitext(os.path.basename(p))[0], object_tensor(np.load(p).astype(np.float64))) for p in args.objects]
@@ -159,10 +161,11 @@ def main(dataset: str, argv: Optional[Sequence[str]] = None) -> List[str]:
     written = []
     lo, hi = dist.shard_range(len(objs), rank, world)                              # objects are independent: shard them
     total_t, total_g = 0.0, 0
-    for name, obj in objs[lo:hi]:
+    for gi, (name, obj) in enumerate(objs[lo:hi], start=lo):
         torch.cuda.synchronize(device)
         t0 = time.time()
-        out = generate_for_object(net, obj, args.num_grasp, DATASETS[dataset]["rotate"], rng)
+        rng = np.random.default_rng([args.seed, gi])                                # per OBJECT: rotations independent of the sharding
+        out = generate_for_object(net, obj, args.num_grasp, DATASETS[dataset]["rotate"], rng, seed=args.seed, object_index=gi)
         torch.cuda.synchronize(device)                                             # the reference times without a sync
         dt = time.time() - t0
         total_t += dt

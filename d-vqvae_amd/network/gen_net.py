@@ -27,6 +27,14 @@ class GenNet(nn.Module):
         self.recon_encoder = PointNetEncoder(global_feat=True, feature_transform=False, channel=3)
         self.pos_decoder = Decoder(layer_sizes=[1024, 128, 6], latent_size=2048)
         self.GatedPixelCNN = GatedPixelCNN(prior_tokens, prior_dim, prior_layers, prior_classes)
+        self.noise_seed = 0          # key of the device Philox generator that replaces multinomial's draws (set_noise_seed)
+        self._noise_stream = 0       # one Philox stream per gen() call unless the caller names it
+
+    def set_noise_seed(self, seed, first_stream=0):
+        """Seed of the prior's sampling noise; every gen() call without explicit ``noise`` / ``stream_id`` uses the next stream."""
+        self.noise_seed = int(seed)
+        self._noise_stream = int(first_stream)
+        return self
 
     def set_rh_mano(self, Rh_mano):
         Rh_mano.eval()
@@ -55,9 +63,11 @@ class GenNet(nn.Module):
         return self.decoder(z_out).view(B, 55)
 
     @torch.no_grad()
-    def gen(self, obj, noise=None, return_aux=False):
+    def gen(self, obj, noise=None, return_aux=False, seed=None, row0=0, stream_id=None):
         """obj [B,4,N] f32 on the GPU -> (recon [B,55], recon_pos [B,6]).
-        ``noise`` [B,9,prior_tokens] ~ Exp(1) fixes the prior's draws (parity runs); sampled on device if None."""
+        ``noise`` [B,9,prior_tokens] ~ Exp(1) fixes the prior's draws (parity runs).  Without it the draws come from the
+        device Philox generator keyed by (seed, stream_id, row0 + b): a batch sharded over ranks (``row0`` = first global
+        row of the shard, same ``seed`` / ``stream_id``) generates exactly what the unsharded call generates."""
         if obj.dim() != 3:
             raise RuntimeError(f"gen: expected obj [B,4,N], got {tuple(obj.shape)}")
         B, dev = obj.shape[0], obj.device
@@ -72,7 +82,10 @@ class GenNet(nn.Module):
         err = ops.new_err_flag(dev)
         pk = self.GatedPixelCNN.packed()
         if noise is None:
-            noise = torch.empty(B, 9, pk.n_in, device=dev, dtype=torch.float32).exponential_(1.0)
+            if stream_id is None:
+                stream_id = self._noise_stream
+                self._noise_stream += 1
+            noise = ops.exp1_noise(B, 9 * pk.n_in, self.noise_seed if seed is None else seed, row0, stream_id, device=dev).view(B, 9, pk.n_in)
         codes = ops.pixelcnn_sample(pk, label, noise.contiguous(), err=err)   # :92
         recon = self._decode(codes, {"z_out": z_out}, None, err)           # :95-113
         verts = self._hand_vertices(recon)                                 # :116-118

@@ -44,10 +44,11 @@ class GatedPixelCNN(PackedModule):
         """x [B,3,3] int64, label [B] -> logits [B,input_dim,3,3]"""
         return ops.pixelcnn_forward(self.packed(), x, label)
 
-    def generate(self, x_start, label, shape=(3, 3), batch_size=64, noise=None, return_logits=False):
+    def generate(self, x_start, label, shape=(3, 3), batch_size=64, noise=None, return_logits=False, seed=0, row0=0, stream_id=0):
         """Raster-order sampling of the 3x3 grid -> int64 [B,3,3].  ``x_start`` is ignored (as in the
         reference, models.py:186).  ``noise`` [B,9,input_dim] ~ Exp(1) makes the draw reproducible
-        (argmax softmax/noise == multinomial(1)); drawn on the device when omitted."""
+        (argmax softmax/noise == multinomial(1)); drawn by the device Philox generator keyed by (seed, stream_id,
+        row0 + b) when omitted (ops.exp1_noise)."""
         if tuple(shape) != (3, 3):
             raise NotImplementedError("the grasp path samples a 3x3 latent grid (gen_net.py:92)")
         label = label.reshape(-1).contiguous()
@@ -55,5 +56,5 @@ class GatedPixelCNN(PackedModule):
             raise RuntimeError(f"generate: {label.shape[0]} labels for batch_size={batch_size}")
         pk = self.packed()
         if noise is None:
-            noise = torch.empty(batch_size, 9, pk.n_in, device=label.device, dtype=torch.float32).exponential_(1.0)
+            noise = ops.exp1_noise(batch_size, 9 * pk.n_in, seed, row0, stream_id, device=label.device).view(batch_size, 9, pk.n_in)
         return ops.pixelcnn_sample(pk, label, noise.contiguous(), return_logits=return_logits)

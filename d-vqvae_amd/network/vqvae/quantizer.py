@@ -54,9 +54,11 @@ class VectorQuantizer(nn.Module):
                 st["prefer_exact"] = True
             st["slow_seen"], st["rows_seen"], st["event"] = slow, st["rows_at_copy"], None
         if st["event"] is None and st["calls"] % self.PROBE_EVERY == 0:
-            st["host"].copy_(st["counter"], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
+            dev = st["counter"].device                       # copy and event on the stream the kernels of THIS device run on
+            with torch.cuda.device(dev):
+                st["host"].copy_(st["counter"], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
             st["event"], st["rows_at_copy"] = ev, st["rows"]
         st["calls"] += 1
 

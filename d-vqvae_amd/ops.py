@@ -55,19 +55,22 @@ def _stream(dev: torch.device) -> int:
 
 
 _ws: Dict[Tuple[int, int, str], Tensor] = {}
+_WS_MAX = 16        # (device, stream) scratch buffers kept; the least recently used one goes when a 17th stream shows up
 
 
 def workspace(nbytes: int, dev: torch.device, tag: str = "main") -> Tensor:
     """Grow-only scratch per (device, current stream): reuse is ordered by the stream the ops are enqueued on, so two
-    streams driving the library concurrently never share a buffer."""
+    streams driving the library concurrently never share a buffer.  At most ``_WS_MAX`` buffers are kept (LRU; an evicted
+    buffer stays alive until the work already enqueued on it has run: the caching allocator frees by stream order)."""
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     key = (idx, int(torch.cuda.current_stream(idx).cuda_stream), tag)
-    buf = _ws.get(key)
+    buf = _ws.pop(key, None)
     if buf is None or buf.numel() < nbytes:
-        _ws.pop(key, None)
         buf = None
         buf = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=dev)
-        _ws[key] = buf
+    _ws[key] = buf                                           # (re)inserted last = most recently used
+    while len(_ws) > _WS_MAX:
+        _ws.pop(next(iter(_ws)))
     return buf
 
 
@@ -208,6 +211,37 @@ def vq_lookup(E: Tensor, idx: Tensor, out: Optional[Tensor] = None, err: Optiona
     if own_err and int(err.item()) != 0:
         raise RuntimeError(f"index out of bounds for codebook with {K} rows")
     return out
+
+
+# ------------------------------------------------------------------------------------------ sampling noise
+def exp1_noise(rows: int, cols: int, seed: int, row0: int = 0, stream_id: int = 0, device=None, out: Optional[Tensor] = None) -> Tensor:
+    """[rows, cols] Exp(1) variates from the device Philox generator, keyed by (seed, stream_id, GLOBAL row row0 + r, column):
+    a shard of a batch (row0 = its first row) draws exactly the rows the whole batch would draw (dvq_exp1_noise)."""
+    lib = _lib.load()
+    if out is None:
+        if device is None:
+            raise RuntimeError("exp1_noise: pass `device` or `out`")
+        out = torch.empty(rows, cols, dtype=torch.float32, device=device)
+    dev = _require_gpu(out)
+    if tuple(out.shape) != (rows, cols) or not out.is_contiguous() or out.dtype != torch.float32:
+        raise RuntimeError("exp1_noise: `out` must be a contiguous float32 [rows, cols] tensor")
+    if cols % 4 != 0:
+        raise RuntimeError("exp1_noise: cols must be a multiple of 4")
+    with torch.cuda.device(dev):
+        check(lib.dvq_exp1_noise(int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_id) & 0xFFFFFFFF, int(row0), rows, cols, out.data_ptr(),
+                                 _stream(dev)), "dvq_exp1_noise")
+    return out
+
+
+def probe_f16_subnormal(device) -> Tuple[float, float]:
+    """(fp16 MFMA product with a subnormal input, its exact value): equal when the matrix core keeps fp16 subnormals."""
+    lib = _lib.load()
+    out = torch.zeros(2, dtype=torch.float32, device=device)
+    dev = _require_gpu(out)
+    with torch.cuda.device(dev):
+        check(lib.dvq_probe_f16_subnormal(out.data_ptr(), _stream(dev)), "dvq_probe_f16_subnormal")
+    a, b = out.cpu().tolist()
+    return a, b
 
 
 # ------------------------------------------------------------------------------------------ PointNet

@@ -82,13 +82,16 @@ int dvq_vq_argmin(const float* z, int64_t ldz, const float* E, int64_t M, int K,
                   dvq_stream_t stream);
 
 /* Fast path for the headline shape (K = 512, D = 256, dense z): returns the SAME indices as dvq_vq_argmin,
- * bit for bit.  One kernel: an fp16-MFMA filter with a proven error bound keeps every row's candidate entries (the
+ * bit for bit.  One persistent kernel (one workgroup per CU, the fp16 codebook image held in registers): z is read from
+ * HBM once and streamed under an fp16-MFMA filter with a proven error bound that keeps every row's candidate entries (the
  * exact fp32 argmin is always among them); rows with one candidate are decided, the rest are re-evaluated in the
  * canonical fp32 order inside the same workgroup (DESIGN.md "vq_argmin").  `packed` is the codebook image built once
- * per codebook by dvq_vq_pack (fp16 image of -2 sE E, canonical |e_k|^2, max |e_k|, measured rounding error).
- * `slow_rows` (device, may be NULL, never reset by the library): the kernel adds the number of rows that could not
- * be decided from their candidate list (second-level filter or all-entries scan, 10-20 us each).  A caller that sees
- * a large fraction there (ill-conditioned input: |z| >> codebook spread) should use dvq_vq_argmin instead. */
+ * per codebook by dvq_vq_pack (fp16 image of -2 sE E in MFMA-fragment order, canonical |e_k|^2, max |e_k|, measured
+ * rounding error).  Rows are not rescaled: fp16 overflow (|z_j| > 65504), NaN/Inf rows and codebooks with magnitudes
+ * outside 2^+-40 take the all-entries path.
+ * `slow_rows` (device, may be NULL, never reset by the library): the kernel adds the number of rows that cost far more
+ * than a filtered row: all-entries scans and rows with 32 or more candidate pairs.  A caller that sees a large fraction
+ * there (ill-conditioned input: |z| >> codebook spread) should use dvq_vq_argmin instead. */
 int dvq_vq_fast_supported(int K, int D);
 size_t dvq_vq_pack_bytes(int K, int D);
 int dvq_vq_pack(const float* E, int K, int D, void* packed, size_t packed_bytes, dvq_stream_t stream);
@@ -206,6 +209,18 @@ int dvq_assemble61(const float* recon /* [B,55] */, const float* recon_pos /* [B
 int dvq_transform_cloud(const float* pc /* [C,N] or [B,C,N] */, int64_t pc_batch_stride, const float* R /* [B,3,3] */,
                         const float* t /* [3] */, int64_t B, int C, int N, float* out /* [B,C,N] */,
                         dvq_stream_t stream);
+
+/* ------------------------------------------------------------------ sampling noise of the prior
+ * GatedPixelCNN.generate draws with probs.multinomial(1) (network/pixelcnn/models.py:190-197), i.e. argmax_k p_k / q_k with
+ * q ~ Exp(1).  out[r, c] = -log(u) from Philox4x32-10 keyed by `seed`, counter (c / 4, row0 + r, stream_id): the noise of a
+ * grasp depends on its GLOBAL row only, so a batch sharded over ranks (row0 = first row of the shard) draws exactly what the
+ * unsharded batch draws.  `stream_id` separates independent uses (objects, calls).  cols % 4 == 0. */
+int dvq_exp1_noise(uint64_t seed, uint32_t stream_id, int64_t row0, int64_t rows, int cols, float* out /* [rows,cols] */,
+                   dvq_stream_t stream);
+
+/* Self-test: out[0] (device) = an fp16 MFMA product with a SUBNORMAL input, out[1] = its exact value.  The fast VQ kernel's
+ * error bound assumes the matrix core keeps fp16 subnormals (measured so on gfx950); tests assert out[0] == out[1]. */
+int dvq_probe_f16_subnormal(float* out /* device [2] */, dvq_stream_t stream);
 
 /* ------------------------------------------------------------------ contact / penetration proxies (after the path)
  * utils/utils_loss.py:7-24 get_NN (pytorch3d knn_points, K=1): nearest target point of every source point of the same

@@ -203,18 +203,24 @@ def sample_from_logits(logits: Tensor, q: Tensor) -> Tensor:
     return torch.argmax(p / q, dim=-1)
 
 
-def pixelcnn_generate(sd: SD, pre: str, label: Tensor, q: Tensor, shape=(3, 3)) -> Tensor:
+def pixelcnn_generate(sd: SD, pre: str, label: Tensor, q: Tensor, shape=(3, 3), return_race_gap: bool = False):
     """GatedPixelCNN.generate, models.py:176-198, naive form: one full forward per grid position.
     label [B] int64, q [B, H*W, n_out] Exp(1) noise -> x [B,H,W] int64.  (x_start is ignored by the
-    reference: the copy at :186 is commented out.)"""
+    reference: the copy at :186 is commented out.)  ``return_race_gap``: also, per sample, the smallest relative margin
+    by which a draw won its exponential race, 1 - (second largest p/q) / (largest p/q), evaluated in float64 (tests use it
+    to set aside samples whose draw an fp32 rounding difference of the logits could flip)."""
     B = label.shape[0]
     H, W = shape
     x = torch.zeros(B, H, W, dtype=torch.int64)
+    gap = torch.ones(B, dtype=torch.float64)
     for i in range(H):
         for j in range(W):
             logits = pixelcnn_forward(sd, pre, x, label)
             x[:, i, j] = sample_from_logits(logits[:, :, i, j], q[:, i * W + j])
-    return x
+            if return_race_gap:
+                r = torch.topk(F.softmax(logits[:, :, i, j].double(), -1) / q[:, i * W + j].double(), 2, dim=-1)[0]
+                gap = torch.minimum(gap, 1.0 - r[:, 1] / r[:, 0])
+    return (x, gap.float()) if return_race_gap else x
 
 
 # --------------------------------------------------------------------------- GenNet.gen
@@ -233,7 +239,7 @@ def gen(sd: SD, obj: Tensor, q: Tensor, mano, return_aux: bool = False):
     n_cls = sd["GatedPixelCNN.layers.0.class_cond_embedding.weight"].shape[0]
     if int(label.max()) >= n_cls:
         raise RuntimeError("label out of range for the prior's class embedding")
-    codes = pixelcnn_generate(sd, "GatedPixelCNN.", label, q)                    # :92
+    codes, race_gap = pixelcnn_generate(sd, "GatedPixelCNN.", label, q, return_race_gap=True)   # :92
     embs = [vq_lookup(sd[f"vqvae{k}.vector_quantization.embedding.weight"], codes[:, i, j])
             for k, (i, j) in enumerate(CODE_SLOTS)]                              # :95-106
     z_out = torch.cat(embs + [feat_type], dim=1)                                 # :109 raw feature, not obj_emb
@@ -243,8 +249,12 @@ def gen(sd: SD, obj: Tensor, q: Tensor, mano, return_aux: bool = False):
     z_pos = torch.cat([hand_feat, feat_pos], dim=1)                              # :121
     recon_pos = mlp_decoder(sd, "pos_decoder.", z_pos).view(B, 6)                # :122-123
     if return_aux:
+        E6 = sd["vqvae6.vector_quantization.embedding.weight"].double()
+        d64 = (feat_type.double() ** 2).sum(1, keepdim=True) + (E6 ** 2).sum(1) - 2 * feat_type.double() @ E6.t()
+        top2 = torch.topk(d64, 2, dim=1, largest=False)[0]
         return recon, recon_pos, dict(feat_type=feat_type, feat_pos=feat_pos, idx6=idx6, codes=codes,
-                                      verts=verts, hand_feat=hand_feat)
+                                      verts=verts, hand_feat=hand_feat, race_gap=race_gap,
+                                      idx6_gap=(top2[:, 1] - top2[:, 0]).float())
     return recon, recon_pos
 
 

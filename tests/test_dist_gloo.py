@@ -13,6 +13,17 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _params(total):
+    """[total, 61] MANO parameter rows as the path produces them: the reference's own outputs for 8 objects (fixture G7:
+    recon [8,55], recon_pos [8,6]) through the oracle's 61-parameter assembly, repeated with a per-row offset."""
+    import numpy as np
+    from oracle import dvq_oracle as O
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g7_gen.npz"))
+    p8 = O.assemble61(torch.from_numpy(g["recon"]), torch.from_numpy(g["recon_pos"]))
+    reps = (total + 7) // 8
+    return (p8.repeat(reps, 1) + torch.arange(reps * 8, dtype=torch.float32)[:, None] * 1e-3)[:total].contiguous()
+
+
 def _worker(rank, world, port, total, ret):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
@@ -20,9 +31,12 @@ def _worker(rank, world, port, total, ret):
     r, lr, w = dist.init(backend="gloo")
     assert (r, w) == (rank, world)
     lo, hi = dist.shard_range(total, rank, world)
-    full = torch.arange(total * 61, dtype=torch.float32).view(total, 61)
+    full = _params(total)
     gathered = dist.all_gather_rows(full[lo:hi].clone(), total_rows=total)
     ok = torch.equal(gathered, full)
+    ok = ok and torch.equal(dist.all_gather_rows(full[lo:hi].clone()), full)         # shard sizes exchanged first
+    uneven = full[: total // 3] if rank == 0 else full[total // 3:]                 # shards shard_range would not produce
+    ok = ok and torch.equal(dist.all_gather_rows(uneven.clone()), full)
     mx = dist.max_over_ranks(float(rank + 1), "cpu")
     dist.barrier()
     ret[rank] = (ok, mx)
@@ -44,3 +58,12 @@ def test_all_gather_even_shards():
 
 def test_all_gather_ragged_shards():
     _run(37)
+
+
+def test_shard_ranges_cover_the_batch_in_rank_major_order():
+    from dvqvae_amd import dist
+    for total, world in ((65536, 8), (65536, 4), (37, 8), (5, 8), (0, 2)):
+        spans = [dist.shard_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1

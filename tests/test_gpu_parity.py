@@ -304,9 +304,9 @@ def test_gen_end_to_end_golden(golden):
     assert np.array_equal(idx6[safe], g["idx6"][safe])
     codes = aux["codes"].cpu().numpy()
     same = (idx6 == g["idx6"]) & np.all(codes.reshape(8, 9) == g["codes"].reshape(8, 9), axis=1)
-    print(f"idx6 match {np.mean(idx6 == g['idx6']):.3f}; code match {np.mean(codes == g['codes']):.3f}; "
-          f"samples with all codes equal: {same.sum()}/8")
-    assert same.sum() >= 7
+    print(f"idx6 match {np.mean(idx6 == g['idx6']):.3f}; code match {np.mean(codes == g['codes']):.3f}; samples with all codes "
+          f"equal: {same.sum()}/8; set aside by the gap check (fp64 top-2 distance gap of the object code <= 0.05): {(~safe).sum()}")
+    assert same[safe].all(), "every grasp whose object code is well separated must reproduce the reference's codes"
     s = torch.from_numpy(same)
     assert_close(recon.cpu()[s], g["recon"][same], atol=TOL, what="MANO pose/shape vs reference")
     assert_close(pos.cpu()[s], g["recon_pos"][same], atol=TOL, what="wrist params vs reference")
@@ -603,7 +603,127 @@ def test_entry_point_writes_reference_json(tmp_path):
     from dvqvae_amd import diversity, generate
     out_dir = str(tmp_path / "ho3d")
     paths = generate.main("ho3d", ["--num_grasp", "5", "--num_objects", "2", "--points", "300", "--out_dir", out_dir,
-                                   "--checkpoint", "/nonexistent", "--mano_model", "/nonexistent"])
+                                            "--checkpoint", "/nonexistent", "--mano_model", "/nonexistent"])
     assert len(paths) == 2
     params = diversity.load_params(paths)
     assert params.shape == (10, 61) and np.isfinite(params).all()
+
+
+# ------------------------------------------------------------------------------------------ round-2 additions
+def test_mfma_keeps_f16_subnormals():
+    """The fast VQ kernel's error bound counts on the matrix core multiplying fp16 SUBNORMAL inputs exactly (it measures /
+    bounds the rounding error of the conversion, not of a flush inside the MFMA)."""
+    got, want = ops.probe_f16_subnormal(DEV)
+    assert got == want and want > 0.0, f"fp16 MFMA with a subnormal input gave {got}, exact value {want}"
+
+
+def test_vqvae_train_forward_golden(golden):
+    """VQVAE.forward (train mode: loss, straight-through z_q, perplexity), network/VQVAE.py:29-42 and
+    vqvae/quantizer.py:56-64, against the values the reference produced (G3)."""
+    from dvqvae_amd.network.VQVAE import VQVAE
+    g = golden("g2_vq")
+    vq = VQVAE(128, 32, 2, 128, 256, 0.25, a=1).to(DEV)
+    with torch.no_grad():
+        vq.vector_quantization.embedding.weight.copy_(torch.from_numpy(g["crafted_E"]))
+    vq.train()
+    zt = gpu(synth.synthetic_normal((64, 256), SEED, "vq/z/train"))
+    loss, zq, perp = vq(zt)
+    assert_close(loss, g["train_loss"], atol=1e-6)
+    assert_close(perp, g["train_perplexity"], atol=1e-4)
+    assert_close(zq.double().sum(1).float(), g["train_zq_rowsum"], atol=1e-4)
+    o_loss, o_zq, o_perp, o_onehot, o_idx = O.vq_train_forward(torch.from_numpy(g["crafted_E"]), zt.cpu(), beta=0.25, al=1)
+    l5, z5, p5, onehot, idx = vq.vector_quantization(zt, True)
+    assert torch.equal(idx.cpu(), o_idx) and torch.equal(onehot.cpu(), o_onehot)
+    assert_close(z5, o_zq, atol=1e-6)
+    # straight-through estimator: the gradient of z_q w.r.t. z is the identity, the codebook gets the commitment term
+    zr = zt.clone().requires_grad_(True)
+    loss_r, zq_r, _ = vq(zr)
+    (zq_r.sum() + loss_r).backward()
+    assert zr.grad is not None and vq.vector_quantization.embedding.weight.grad is not None
+    assert_close(zr.grad, 1.0 + 2.0 * (zr.detach() - zq_r.detach()) / zr.numel(), atol=1e-6)
+
+
+def test_gen_bench_config_vs_oracle():
+    """The benchmark's network (K = 512 codebooks, 512 prior classes, N = 1024 points, synthetic weights) against the CPU
+    oracle on 256 grasps: object codes and sampled codes exact, MANO pose/shape and wrist parameters within 1e-5.  Grasps
+    whose decision an fp32 rounding difference could flip are set aside by stated margins and counted."""
+    from dvqvae_amd.network.gen_net import GenNet
+    B, N, K = 256, 1024, 512
+    net = GenNet(n_embeddings=K, prior_tokens=K, prior_classes=K)
+    sd = synth.synthetic_state_dict(net.state_dict(), 1234)
+    net.load_state_dict(sd)
+    net.eval().to(DEV)
+    arrays = dmano.synthetic_mano_arrays()
+    net.set_rh_mano(dmano.ManoLayer(arrays).to(DEV))
+    obj = synth.synthetic_clouds(B, N, seed=4242)
+    q = synth.exp1_noise(B, 9, K, seed=4243)
+    recon, pos, aux = net.gen(gpu(obj), noise=gpu(q), return_aux=True)
+    with torch.no_grad():
+        o_recon, o_pos, o_aux = O.gen({k: v.cpu() for k, v in sd.items()}, obj, q, mano_oracle.ManoOracle(arrays), return_aux=True)
+    zz = float((o_aux["feat_type"].double() ** 2).sum(1).max())
+    safe_idx = o_aux["idx6_gap"].numpy() > 1e-5 * zz          # fp32 distances carry ~1e-7 (|z|^2 + |e|^2) of noise
+    safe_race = o_aux["race_gap"].numpy() > 1e-4             # fp32 logits differ by ~1e-6 relative between the two paths
+    safe = safe_idx & safe_race
+    idx_ok = (aux["idx6"].cpu() == o_aux["idx6"]).reshape(B, -1).all(1).numpy()
+    code_ok = (aux["codes"].cpu() == o_aux["codes"]).reshape(B, -1).all(1).numpy()
+    print(f"bench-config parity on {B} grasps: object code match {idx_ok.mean():.4f}, sampled codes match {code_ok.mean():.4f}; "
+          f"set aside: {(~safe_idx).sum()} by the object-code gap, {(safe_idx & ~safe_race).sum()} by the race margin")
+    assert safe.sum() >= 0.9 * B
+    assert idx_ok[safe_idx].all() and code_ok[safe].all()
+    both = torch.from_numpy(idx_ok & code_ok)
+    assert_close(recon.cpu()[both], o_recon[both], atol=TOL, what="MANO pose/shape")
+    assert_close(pos.cpu()[both], o_pos[both], atol=TOL, what="wrist parameters")
+
+
+def test_gen_sharded_equals_unsharded_with_device_noise():
+    """with the device noise keyed by (seed, stream, global row), R contiguous shards of a batch -- each a
+    separate gen() call with row0 = its first global row, as R ranks would make them -- reproduce the unsharded call bit for
+    bit, in rank-major order (R = 2, 4, 8, ragged shards included)."""
+    net, _ = _gennet()
+    B = 52
+    obj = gpu(synth.synthetic_clouds(B, 384, seed=505))
+    r0, p0, a0 = net.gen(obj, seed=77, row0=1000, stream_id=5, return_aux=True)
+    r1, p1 = net.gen(obj, seed=77, row0=1000, stream_id=5)
+    assert torch.equal(r0, r1) and torch.equal(p0, p1)                      # same key, same draws
+    r2, _, a2 = net.gen(obj, seed=77, row0=1000, stream_id=6, return_aux=True)
+    assert not torch.equal(a0["codes"], a2["codes"])                        # another stream, other draws
+    from dvqvae_amd import dist
+    for R in (2, 4, 8):
+        parts = []
+        for rank in range(R):
+            lo, hi = dist.shard_range(B, rank, R)
+            rr, pp = net.gen(obj[lo:hi], seed=77, row0=1000 + lo, stream_id=5)
+            parts.append(ops.assemble61(rr, pp))
+        assert torch.equal(torch.cat(parts), ops.assemble61(r0, p0)), f"R={R}"
+
+
+def test_fp32_gemm_branch_matches_goldens(tmp_path):
+    """DVQ_GEMM=fp32 (v_mfma_f32_32x32x2_f32 GEMMs, unfused PointNet trunk) is chosen when the library loads: a fresh process
+    runs the GEMM, PointNet, PixelCNN and end-to-end golden tests of this file on that branch."""
+    import os, subprocess, sys
+    env = dict(os.environ, DVQ_GEMM="fp32")
+    sel = "test_linear or test_pointnet_golden or test_pixelcnn_small_golden or test_decoders_golden or test_gen_end_to_end_golden"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", sel,
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("dataset", ["obman", "grab", "FHAB"])
+def test_other_entry_points_write_reference_json(tmp_path, dataset):
+    """gen_diverse_grasp_{obman,grab,FHAB}.py end to end on two synthetic objects (the ho3d one is covered above): the shims'
+    own `main` with the reference's default grasp counts, the reference's JSON layout
+    (gen_diverse_grasp_grab.py:302-311)."""
+    import importlib, json
+    mod = importlib.import_module(f"dvqvae_amd.gen_diverse_grasp_{dataset}")
+    out_dir = str(tmp_path / dataset)
+    n = {"obman": 1, "grab": 20, "FHAB": 49}[dataset]
+    written = mod.main(dataset, ["--num_objects", "2", "--points", "256", "--out_dir", out_dir, "--seed", "3",
+                                 "--checkpoint", "/nonexistent", "--mano_model", "/nonexistent"])
+    assert len(written) == 2
+    for path in written:
+        d = json.load(open(path))
+        assert set(d) == {"recon_params", "R_list", "trans_list", "r_list"}
+        assert len(d["recon_params"]) == n and len(d["recon_params"][0]) == 1 and len(d["recon_params"][0][0]) == 61
+        assert np.asarray(d["R_list"]).shape == (n, 3, 4) and len(d["trans_list"]) == n and len(d["r_list"]) == n
+        assert np.isfinite(np.asarray(d["recon_params"])).all()

@@ -156,7 +156,8 @@ def test_gen_end_to_end_vs_reference(golden):
     safe = g["idx6_gap"] > 0.05
     assert np.array_equal(aux["idx6"][:, 0].numpy()[safe], g["idx6"][safe])
     same = np.all(aux["codes"].numpy().reshape(8, 9) == g["codes"].reshape(8, 9), axis=1) & (aux["idx6"][:, 0].numpy() == g["idx6"])
-    assert same.sum() >= 7
+    print(f"set aside by the gap check (fp64 top-2 distance gap of the object code <= 0.05): {(~safe).sum()} of 8")
+    assert same[safe].all()
     close(recon[torch.from_numpy(same)], g["recon"][same])
     close(pos[torch.from_numpy(same)], g["recon_pos"][same])
     j = golden("g7_gen_juice")
