@@ -49,7 +49,7 @@ class PixelcnnWeights(C.Structure):
 
 
 class ManoModel(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("v_template", "shapedirs", "posedirs", "j_template", "j_shapedirs",
+    _fields_ = [(n, C.c_void_p) for n in ("v_template", "blend_w", "blend_w_planes", "j_template", "j_shapedirs",
                                           "weights", "comps", "pose_mean")] + [("parents", C.c_int32 * 16)]
 
 
@@ -83,8 +83,9 @@ SIGNATURES = {
                                       C.c_void_p, C.c_size_t, c_stream]),
     "dvq_pixelcnn_forward": (C.c_int, [C.POINTER(PixelcnnWeights), c_i64p, c_i64p, C.c_int64, c_f32p, c_i32p, C.c_void_p,
                                        C.c_size_t, c_stream]),
+    "dvq_mano_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "dvq_mano_forward": (C.c_int, [C.POINTER(ManoModel), c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p,
-                                   C.c_int64, C.c_int64, c_f32p, C.c_int, c_f32p, c_stream]),
+                                   C.c_int64, C.c_int64, c_f32p, C.c_int, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
     "dvq_copy_cols": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int, c_f32p, C.c_int64, c_stream]),
     "dvq_assemble61": (C.c_int, [c_f32p, c_f32p, C.c_int64, c_f32p, c_stream]),
     "dvq_prof_enable": (C.c_int, [C.c_int]),

@@ -339,10 +339,13 @@ def mano_forward(packed, betas: Tensor, hand_pose: Tensor, global_orient: Option
         pt, ldt = _rows(_f32(transl, "transl"), "transl")
     verts = torch.empty((B, 3, 778) if channel_major else (B, 778, 3), dtype=torch.float32, device=dev)
     joints = torch.empty(B, 16, 3, dtype=torch.float32, device=dev) if want_joints else None
+    nws = lib.dvq_mano_workspace_bytes(B)
+    ws = workspace(nws, dev)
     with torch.cuda.device(dev):
         check(lib.dvq_mano_forward(C.byref(packed.cstruct), pb, ldb, pp, ldp, pg or None, ldg, pt or None, ldt, B,
                                    verts.data_ptr(), 1 if channel_major else 0,
-                                   joints.data_ptr() if want_joints else None, _stream(dev)), "dvq_mano_forward")
+                                   joints.data_ptr() if want_joints else None, ws.data_ptr(), ws.numel(), _stream(dev)),
+              "dvq_mano_forward")
     return (verts, joints) if want_joints else verts
 
 

@@ -203,8 +203,10 @@ class PackedMano(_Packed):
         t = self.tensors
         tt = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
         t["v_template"] = tt(vt)
-        t["shapedirs"] = tt(sh.reshape(778 * 3, 10).T)
-        t["posedirs"] = tt(po.reshape(778 * 3, 135).T)
+        blend = np.zeros((778 * 3, 160))                  # row e = [shapedirs[e, :10] | posedirs[e, :135] | 0]: V = X @ blend^T
+        blend[:, :10] = sh.reshape(778 * 3, 10)
+        blend[:, 10:145] = po.reshape(778 * 3, 135)
+        t["blend_w"] = tt(blend)
         t["j_template"] = tt(jr @ vt)
         t["j_shapedirs"] = tt(np.einsum("jv,vkl->ljk", jr, sh).reshape(10, 48))
         t["weights"] = tt(f64("weights"))
@@ -215,10 +217,15 @@ class PackedMano(_Packed):
         self.parents[0] = -1
         self.faces = np.asarray(arrays.get("faces", np.zeros((0, 3), dtype=np.int64)))
 
+    PLANES = ("blend_w",)
+
     def _bind(self):
         s = _lib.ManoModel()
         for name, _ in _lib.ManoModel._fields_[:-1]:
-            setattr(s, name, self.tensors[name].data_ptr())
+            if name == "blend_w_planes":
+                s.blend_w_planes = self.planes_ptr("blend_w")
+            else:
+                setattr(s, name, self.tensors[name].data_ptr())
         for j, p in enumerate(self.parents):
             s.parents[j] = p
         self.cstruct = s

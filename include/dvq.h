@@ -178,9 +178,9 @@ int dvq_pixelcnn_forward(const dvq_pixelcnn_weights* w_host, const int64_t* x, c
  * package at network/gen_net.py:116-118 and gen_diverse_grasp_obman.py:252-253; restated, unpinned)
  * use_pca=True, 45 comps, flat_hand_mean folded into pose_mean by the packer. */
 typedef struct {
-    const float* v_template;  /* [778,3] */
-    const float* shapedirs;   /* [10][2334]  (beta-major) */
-    const float* posedirs;    /* [135][2334] */
+    const float* v_template;  /* [778,3] = the blendshape GEMM's bias [2334] */
+    const float* blend_w;     /* [2334][160]: row e = [shapedirs[.,e] (10) | posedirs[.,e] (135) | 0 (15)]: V = X . blend_w^T */
+    const uint16_t* blend_w_planes;   /* optional split-bf16 planes of blend_w (dvq_split_bf16x3), [3][2334][160] */
     const float* j_template;  /* [16,3]   J_regressor @ v_template */
     const float* j_shapedirs; /* [10][48] J_regressor @ shapedirs */
     const float* weights;     /* [778,16] */
@@ -190,11 +190,14 @@ typedef struct {
 } dvq_mano_model;
 
 /* betas [B,10] (row stride ldb), pose [B,45] (ldp), optional global_orient [B,3] (ldg) and transl
- * [B,3] (ldt) -> verts; layout 0: [B,778,3] (the mano layer's), 1: [B,3,778] (PointNet input). */
+ * [B,3] (ldt) -> verts; layout 0: [B,778,3] (the mano layer's), 1: [B,3,778] (PointNet input).
+ * Three launches per 16 384 samples: pose/chain kernel, blendshape GEMM [B,160] x [160,2334], skinning kernel.
+ * workspace: dvq_mano_workspace_bytes(B). */
+size_t dvq_mano_workspace_bytes(int64_t B);
 int dvq_mano_forward(const dvq_mano_model* m_host, const float* betas, int64_t ldb, const float* pose,
                      int64_t ldp, const float* global_orient, int64_t ldg, const float* transl,
                      int64_t ldt, int64_t B, float* verts, int layout, float* joints /* optional [B,16,3] */,
-                     dvq_stream_t stream);
+                     void* workspace, size_t workspace_bytes, dvq_stream_t stream);
 
 /* ------------------------------------------------------------------ small data movement
  * out[m, col0:col0+W] = src[m, 0:W]  (concatenations of gen_net.py:109,121) */
