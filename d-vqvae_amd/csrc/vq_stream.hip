@@ -507,7 +507,9 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
     if (tid < 3) reinterpret_cast<unsigned*>(lds + L_CNT)[tid] = 0u;
     reinterpret_cast<float*>(lds + L_EES)[tid] = ee_mine * c.sEf;
     Convert cv;
+    unsigned long long t0a = 0, t0b = 0;
     {
+        if (DBG) { asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3])); t0a = __builtin_amdgcn_s_memrealtime(); }
         cv.start();
         cv.cvt<0>(c, 0, x); const f32x2 p0 = cv.pk; cv.cvt<1>(c, 0, x); const f32x2 p1 = cv.pk;
         cv.cvt<2>(c, 0, x); const f32x2 p2 = cv.pk; cv.cvt<3>(c, 0, x); const f32x2 p3 = cv.pk;
@@ -516,8 +518,9 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
         cv.dsq = row16_sum(cv.dsq);
         cv.finish(c, 0);
         if (c.ntl > 1 && !(ABL & 1)) load_rows(c, 1, x);
+        if (DBG) t0b = __builtin_amdgcn_s_memrealtime();
     }
-    __syncthreads();
+    wg_barrier();          // (not __syncthreads: its fence would wait for the codebook slice and the rows of tile 1 as well)
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
 
     // ---- tile loop, software-pipelined by hand: 32 MFMA gaps per tile, the vector work of four other tiles spread EVENLY
@@ -844,7 +847,7 @@ __global__ __launch_bounds__(NT, 2) void vq_stream_kernel(const float* __restric
             o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3;
             o[4] = (unsigned long long)total; o[5] = (unsigned long long)n_slow;
             o[6] = t2b;
-            o[7] = (unsigned long long)__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));  // XCC_ID
+            o[7] = ((t0a - t0) << 32) | ((t0b - t0) & 0xffffffffull);   // prologue: rows of tile 0 arrived, tile 0 converted
         }
         if (tid < NWV * 32)
             reinterpret_cast<unsigned*>(reinterpret_cast<char*>(dbg) + (size_t)blockIdx.x * DBG_WG_BYTES + 64)[tid] =

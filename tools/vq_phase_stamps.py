@@ -47,6 +47,8 @@ t0 = dbg[:, 0].min()
 rel = (dbg - t0) * 0.01   # us (100 MHz)
 print("start  min/med/max us:", rel[:, 0].min(), np.median(rel[:, 0]), rel[:, 0].max())
 print("prologue dur med/max:", np.median(rel[:, 1] - rel[:, 0]), (rel[:, 1] - rel[:, 0]).max())
+pa, pb = (full[:, 7] >> 32) * 0.01, (full[:, 7] & 0xffffffff) * 0.01
+print("   of which: until the rows of tile 0 have arrived med/max:", np.median(pa), pa.max(), " until tile 0 is converted:", np.median(pb), pb.max())
 print("tile loop dur med/max:", np.median(rel[:, 2] - rel[:, 1]), (rel[:, 2] - rel[:, 1]).max())
 print("refine tail dur med/max:", np.median(rel[:, 3] - rel[:, 2]), (rel[:, 3] - rel[:, 2]).max())
 t2b = (full[:, 6] - t0) * 0.01
