@@ -34,7 +34,8 @@ class PointnetWeights(C.Structure):
     _fields_ = [("C", C.c_int32), ("_pad", C.c_int32)] + [
         (n, C.c_void_p) for n in (
             "s_w1", "s_b1", "s_w2", "s_b2", "s_w3", "s_b3", "s_f1", "s_c1", "s_f2", "s_c2", "s_f3", "s_c3",
-            "w1", "b1", "w2", "b2", "w3", "b3", "s_w2p", "s_w3p", "s_f1p", "s_f2p", "s_f3p", "w2p", "w3p")]
+            "w1", "b1", "w2", "b2", "w3", "b3", "s_w2p", "s_w3p", "s_f1p", "s_f2p", "s_f3p", "w2p", "w3p",
+            "s_w3f", "w3f")]
 
 
 class PixelcnnLayer(C.Structure):
@@ -76,6 +77,8 @@ SIGNATURES = {
                                      C.c_void_p, C.c_size_t, c_stream]),
     "dvq_vq_lookup": (C.c_int, [c_f32p, c_i64p, C.c_int64, C.c_int64, C.c_int, C.c_int, c_f32p, C.c_int64, c_i32p, c_stream]),
     "dvq_pointnet_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "dvq_pointnet_filter_bytes": (C.c_size_t, []),
+    "dvq_pointnet_pack_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dvq_pointnet_encode": (C.c_int, [C.POINTER(PointnetWeights), c_f32p, C.c_int64, C.c_int, c_f32p, C.c_int64, c_f32p,
                                       C.c_void_p, C.c_size_t, c_stream]),
     "dvq_pixelcnn_workspace_bytes": (C.c_size_t, [C.POINTER(PixelcnnWeights), C.c_int64]),

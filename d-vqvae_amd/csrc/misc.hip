@@ -12,7 +12,7 @@ void dvq_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* dvq_last_error(void) { return g_err; }
-extern "C" int dvq_abi_version(void) { return 3; }
+extern "C" int dvq_abi_version(void) { return 4; }
 extern "C" int dvq_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return -1;

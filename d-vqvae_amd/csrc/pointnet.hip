@@ -11,6 +11,13 @@
 int dvq_launch_pn_trunk(const float* pc, int C, int N, long B, const float* trans, const float* W1, const float* b1,
                         const uint16_t* W2p, const float* b2, const uint16_t* W3p, const float* b3, float* partial,
                         hipStream_t st);
+// pointnet_filter.hip
+size_t dvq_pn_filter_image_bytes();
+int dvq_launch_pn_filter_pack(const float* w3, void* image, hipStream_t st);
+int dvq_launch_pn_trunk_filter(const float* pc, int C, int N, int Npad, long B, const float* trans, const float* W1, const float* b1,
+                               const float* W2, const uint16_t* W2p, const float* b2, const void* w3f, const float* w3, const float* b3,
+                               int relu, float* h2buf, void* part, unsigned* tstat, float* cbuf, float* feat, long ld_feat,
+                               unsigned long long* stats, hipStream_t st);
 
 namespace {
 
@@ -51,6 +58,9 @@ __global__ void pn_layer1_kernel(const float* __restrict__ pc, int C, int N, int
 
 struct PnScratch {
     float *h1, *h2, *part, *f0, *f1, *f2, *tr;
+    unsigned* tstat;
+    float* cbuf;
+    unsigned long long* stats;
     long chunk;
     int Npad;
     size_t bytes;
@@ -58,8 +68,9 @@ struct PnScratch {
 
 PnScratch plan(int64_t B, int N, void* ws) {
     PnScratch s;
-    s.Npad = (N + 127) / 128 * 128;
-    const size_t per_sample = (size_t)s.Npad * (64 + 128) * 4 + (size_t)(s.Npad / 128) * 1024 * 4 + (1024 + 512 + 256 + 16) * 4;
+    s.Npad = (N + 255) / 256 * 256;                       // tiles of 128 (fused / unfused trunk) and of 256 (filtered trunk)
+    const size_t per_sample = (size_t)s.Npad * (64 + 128) * 4 + (size_t)s.Npad * 64 + (size_t)(s.Npad / 256) * 16 + 512 +
+                              (1024 + 512 + 256 + 16 + 1) * 4;
     const size_t budget = (size_t)6 << 30;
     long chunk = (long)(budget / per_sample);
     if (chunk < 1) chunk = 1;
@@ -70,7 +81,10 @@ PnScratch plan(int64_t B, int N, void* ws) {
     auto take = [&](size_t n) { char* q = p; p += dvq_round_up(n, 256); return (float*)q; };
     s.h1 = take((size_t)chunk * s.Npad * 64 * 4);
     s.h2 = take((size_t)chunk * s.Npad * 128 * 4);
-    s.part = take((size_t)chunk * (s.Npad / 128) * 1024 * 4);
+    s.part = take((size_t)chunk * s.Npad * 64);           // [tiles128][1024] floats or [tiles256][1024] float4
+    s.tstat = (unsigned*)take((size_t)chunk * (s.Npad / 256) * 16);
+    s.cbuf = take((size_t)chunk * 128 * 4);
+    s.stats = (unsigned long long*)take(64);
     s.f0 = take((size_t)chunk * 1024 * 4);
     s.f1 = take((size_t)chunk * 512 * 4);
     s.f2 = take((size_t)chunk * 256 * 4);
@@ -93,12 +107,20 @@ int dense(const float* x, long ldx, int K, const float* w, const uint16_t* wp, c
     return dvq_launch_gemm(p, EPI_BIAS, st);
 }
 
+bool filter_enabled() {
+    const char* e = getenv("DVQ_PN_FILTER");
+    return !(e && e[0] == '0');
+}
+
 int trunk(const float* pc, int C, int N, long Bc, const float* trans, const float* w1, const float* b1, const float* w2,
-          const uint16_t* w2p, const float* b2, const float* w3, const uint16_t* w3p, const float* b3, int relu3, const PnScratch& s, float* feat, long ld_feat,
-          hipStream_t st) {
+          const uint16_t* w2p, const float* b2, const float* w3, const uint16_t* w3p, const void* w3f, const float* b3, int relu3,
+          const PnScratch& s, float* feat, long ld_feat, hipStream_t st) {
+    if (w2p && w3f && dvq_gemm_mode() == 1 && filter_enabled() && N <= 16384)     // filtered trunk (pointnet_filter.hip)
+        return dvq_launch_pn_trunk_filter(pc, C, N, s.Npad, Bc, trans, w1, b1, w2, w2p, b2, w3f, w3, b3, relu3, s.h2, s.part, s.tstat,
+                                          s.cbuf, feat, ld_feat, getenv("DVQ_PN_STATS") ? s.stats : nullptr, st);
     if (w2p && w3p && dvq_gemm_mode() == 1) {       // fused trunk; w3p is the k-permuted plane image (see pn_trunk_kernel)
         DVQ_PROPAGATE(dvq_launch_pn_trunk(pc, C, N, Bc, trans, w1, b1, w2p, b2, w3p, b3, s.part, st));
-        return dvq_launch_colmax_reduce(s.part, Bc, s.Npad / 128, 1024, relu3, feat, ld_feat, st);
+        return dvq_launch_colmax_reduce(s.part, Bc, (N + 127) / 128, 1024, relu3, feat, ld_feat, st);   // the kernel's own tiling
     }
     w3p = nullptr;                                  // the unfused GEMM path takes natural-order planes only: split on the fly
     const long rows = Bc * s.Npad;
@@ -150,17 +172,24 @@ extern "C" int dvq_pointnet_encode(const dvq_pointnet_weights* w, const float* p
         const long Bc = (long)((B - b0 < s.chunk) ? (B - b0) : s.chunk);
         const float* pcb = pc + b0 * (long)w->C * N;
         // STN3d: trunk with ReLU on the last layer, then fc1/fc2 (BN folded, ReLU) and fc3 (+identity)
-        DVQ_PROPAGATE(trunk(pcb, w->C, N, Bc, nullptr, w->s_w1, w->s_b1, w->s_w2, w->s_w2p, w->s_b2, w->s_w3, w->s_w3p, w->s_b3,
+        DVQ_PROPAGATE(trunk(pcb, w->C, N, Bc, nullptr, w->s_w1, w->s_b1, w->s_w2, w->s_w2p, w->s_b2, w->s_w3, w->s_w3p, w->s_w3f, w->s_b3,
                             1, s, s.f0, 1024, st));
         DVQ_PROPAGATE(dense(s.f0, 1024, 1024, w->s_f1, w->s_f1p, w->s_c1, Bc, 512, 1, s.f1, 512, st));
         DVQ_PROPAGATE(dense(s.f1, 512, 512, w->s_f2, w->s_f2p, w->s_c2, Bc, 256, 1, s.f2, 256, st));
         float* tr = trans_out ? trans_out + b0 * 9 : s.tr;
         DVQ_PROPAGATE(dense(s.f2, 256, 256, w->s_f3, w->s_f3p, w->s_c3, Bc, 9, 0, tr, 9, st));
         // main trunk on the transformed cloud; no ReLU after the last BN (pointnet_encoder.py:162)
-        DVQ_PROPAGATE(trunk(pcb, w->C, N, Bc, tr, w->w1, w->b1, w->w2, w->w2p, w->b2, w->w3, w->w3p, w->b3, 0, s,
+        DVQ_PROPAGATE(trunk(pcb, w->C, N, Bc, tr, w->w1, w->b1, w->w2, w->w2p, w->b2, w->w3, w->w3p, w->w3f, w->b3, 0, s,
                             feat + b0 * ld_feat, ld_feat, st));
     }
     return DVQ_OK;
+}
+
+extern "C" size_t dvq_pointnet_filter_bytes(void) { return dvq_pn_filter_image_bytes(); }
+
+extern "C" int dvq_pointnet_pack_filter(const float* w3, void* image, dvq_stream_t stream) {
+    DVQ_REQUIRE(w3 && image && dvq_aligned16(image), "pointnet_pack_filter: null/unaligned pointer");
+    return dvq_launch_pn_filter_pack(w3, image, (hipStream_t)stream);
 }
 
 // =====================================================================================================================

@@ -1,0 +1,829 @@
+// PointNet trunk, filtered: conv1 -> conv2 -> [conv3 -> max over the points] with conv3 evaluated TWICE at very different
+// cost (PointNetEncoder.forward, network/pointnet_encoder.py:147-164; STN3d.forward :30-35):
+//
+//   1. pn_trunk_filter_kernel: conv1 (vector ALU) and conv2 (split-bf16, six matrix-core products, fp32-accurate) as in
+//      pn_trunk_kernel; the fp32 h2 rows [point][128] go to HBM.  conv3 (94 % of the trunk's FLOPs) is then evaluated as ONE
+//      fp16 product per term on CENTRED rows: d_p = h2_p - c (c = pn_center_kernel's mean of four rows of the sample; the
+//      argmax over the points does not depend on it), d scaled by a per-wave power of two, W3 by a per-channel power of
+//      two, both rounded to fp16.  Per (sample, 256-point tile, channel) the kernel emits the three largest approximate
+//      scores that carry the id of their point in the low mantissa bits, and one flag per wave (64 points) that holds
+//      further points in range whose ids were not kept.
+//   2. pn_exact_kernel: per (sample, channel) the estimate of a point's score is  approx + exact_dot(w_n, c)  with
+//      |estimate - exact_dot(w_n, h2_p)| <= E_t = |r_n| max_p |d_p| + |w_n| max_p |rd_p| + C_ID |w_n| max_p |d_p|
+//      + 2 DELTA |w_n| max_p |h2_p|, maxima over the tile; r_n = w_n - fp16 image (norm measured by the packer), rd_p =
+//      d_p - fp16 image (norm measured by the trunk kernel), C_ID: id bits + matrix-core accumulation, DELTA: rounding of
+//      one exact_dot.  Every tracked
+//      point whose upper bound reaches the best lower bound is re-evaluated in fp32 (exact_dot: a fixed-order fp32 FMA dot
+//      of W3[n,:] and the stored h2 row) and the maximum of THOSE values + bias is the feature -- bit-identical to the
+//      maximum of exact_dot over ALL points (tests: DVQ_PN_EXHAUSTIVE=1 evaluates exactly that).  The 64 points of a flagged
+//      wave are all evaluated.
+//
+// Matrix-core cost per (32 points x 32 channels x K=128): 8 x v_mfma_f32_32x32x16_f16 instead of 48 bf16 MFMAs; the
+// kernel is co-bound by the vector port (4 instructions per score: id, max, two med3) -- see DESIGN.md 3.3.
+#include "dvq_internal.h"
+
+namespace {
+
+typedef __bf16 qbf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 qf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 qf16x2 __attribute__((ext_vector_type(2)));
+
+// beyond the two measured rounding residuals: 2^-15 from the 8 id bits, 2^-19 from the matrix core's fp32 accumulation of
+// 128 exact products, the product of the two residuals (2^-22); rounded up
+constexpr float C_ID = 3.6e-5f;
+// |exact_dot(w, h) - w.h| <= DELTA |w| |h|: 8 chained FMAs + 4 butterfly adds = 12 roundings (7.2e-7), + the fp32 add of
+// the centre term
+constexpr float DELTA = 1.0e-6f;
+constexpr float NEG_BIG = -3.0e38f;
+constexpr int MAX_TILES = 64;                             // filtered trunk: N <= 16384 points
+
+constexpr int F_STAGE2 = 3 * 64 * 128;                    // conv2: one half of W2's planes (3 x 64 rows x 128 B)
+constexpr int F_STAGE3 = 64 * 256;                        // conv3: 64 channels x 128 k fp16
+constexpr int F_OFF_TB = 2 * F_STAGE2;                    // [2 parities][4 waves][64 channels] float4
+constexpr int F_OFF_W1 = F_OFF_TB + 2 * 4 * 64 * 16;      // [64][4] fp32
+constexpr int F_OFF_B1 = F_OFF_W1 + 64 * 4 * 4;           // [64]
+constexpr int F_OFF_B2 = F_OFF_B1 + 64 * 4;               // [128]
+constexpr int F_OFF_SC = F_OFF_B2 + 128 * 4;              // [4] 1 / (wave scale)
+constexpr int F_OFF_TI = F_OFF_SC + 64;                   // [1024] 1 / (channel scale)
+constexpr int F_OFF_CS = F_OFF_TI + 4096;                 // [128] centre of the sample
+constexpr int F_OFF_WS = F_OFF_CS + 512;                  // [3][4] per-wave |h|max, |d|max, |rd|max
+constexpr int F_LDS = F_OFF_WS + 64;                      // 63 872 B -> 2 workgroups per CU
+static_assert(2 * F_STAGE3 <= 2 * F_STAGE2, "conv3 stages reuse the W2 region");
+
+__device__ __forceinline__ float max_nc(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, 3.0e38f); }
+__device__ __forceinline__ float min_nc(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, NEG_BIG); }
+
+__device__ __forceinline__ void q_split_pair(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+    const unsigned a0 = __float_as_uint(x0) & 0xffff0000u, a1 = __float_as_uint(x1) & 0xffff0000u;
+    const float r0 = x0 - __uint_as_float(a0), r1 = x1 - __uint_as_float(a1);
+    const unsigned b0 = __float_as_uint(r0) & 0xffff0000u, b1 = __float_as_uint(r1) & 0xffff0000u;
+    const float s0 = r0 - __uint_as_float(b0), s1 = r1 - __uint_as_float(b1);
+    p1 = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+    p2 = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+    p3 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+__device__ __forceinline__ void q_split8(const float (&v)[8], qbf16x8 (&out)[3]) {
+    unsigned p[3][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) q_split_pair(v[2 * q], v[2 * q + 1], p[0][q], p[1][q], p[2][q]);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) out[pl] = __builtin_bit_cast(qbf16x8, uint4{p[pl][0], p[pl][1], p[pl][2], p[pl][3]});
+}
+
+// W2 planes: same image and DMA pattern as pn_trunk_kernel (rows of 128 B, chunk c of row r at c ^ ((r >> 1) & 7))
+__device__ __forceinline__ void w2_issue(const uint16_t* __restrict__ planes, int row0, char* stage, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int id = wave * 6 + i;
+        const int pl = id >> 3, rb = id & 7;
+        const int row = rb * 8 + (lane >> 3);
+        const uint16_t* src = planes + pl * (128L * 64) + (long)(row0 + row) * 64 + 8 * ((lane & 7) ^ ((row >> 1) & 7));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(stage + (pl * 64 + rb * 8) * 128), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ qbf16x8 w2_frag(const char* stage, int pl, int row, int chunk) {
+    return *reinterpret_cast<const qbf16x8*>(stage + (pl * 64 + row) * 128 + 16 * (chunk ^ ((row >> 1) & 7)));
+}
+
+// W3 filter image: [1024][128] fp16, rows of 256 B = 16 chunks; in LDS chunk c of row r sits at chunk c ^ (r & 15).
+// One 64-channel chunk = 16 KiB: every lane moves 4 x 16 B through registers (global loads at the top of a chunk, LDS writes
+// at its end -- an LDS-DMA piece costs the issuing wave ~150 cycles, a load + a write a few).
+struct W3Regs { uint4 a, b, c, d; };
+__device__ __forceinline__ const uint4* w3_src(const char* __restrict__ w3h, int ch0, int wave, int lane, int i) {
+    const int row = (wave * 4 + i) * 4 + (lane >> 4);
+    return reinterpret_cast<const uint4*>(w3h + (long)(ch0 + row) * 256 + 16 * (lane & 15));
+}
+__device__ __forceinline__ W3Regs w3_load(const char* __restrict__ w3h, int ch0, int wave, int lane) {
+    W3Regs v;
+    v.a = *w3_src(w3h, ch0, wave, lane, 0);
+    v.b = *w3_src(w3h, ch0, wave, lane, 1);
+    v.c = *w3_src(w3h, ch0, wave, lane, 2);
+    v.d = *w3_src(w3h, ch0, wave, lane, 3);
+    return v;
+}
+__device__ __forceinline__ uint4* w3_dst(char* stage, int wave, int lane, int i) {
+    const int row = (wave * 4 + i) * 4 + (lane >> 4);
+    return reinterpret_cast<uint4*>(stage + row * 256 + 16 * ((lane & 15) ^ (row & 15)));
+}
+__device__ __forceinline__ void w3_store(char* stage, int wave, int lane, const W3Regs& v) {
+    *w3_dst(stage, wave, lane, 0) = v.a;
+    *w3_dst(stage, wave, lane, 1) = v.b;
+    *w3_dst(stage, wave, lane, 2) = v.c;
+    *w3_dst(stage, wave, lane, 3) = v.d;
+}
+__device__ __forceinline__ qf16x8 w3_frag(const char* stage, int row, int chunk) {
+    return *reinterpret_cast<const qf16x8*>(stage + row * 256 + 16 * (chunk ^ (row & 15)));
+}
+
+#define Q_MFMA6(ACC, X, Y)                                                            \
+    do {                                                                              \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[2], Y[0], ACC, 0, 0, 0);      \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[0], Y[2], ACC, 0, 0, 0);      \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[1], Y[1], ACC, 0, 0, 0);      \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[1], Y[0], ACC, 0, 0, 0);      \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[0], Y[1], ACC, 0, 0, 0);      \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[0], Y[0], ACC, 0, 0, 0);      \
+    } while (0)
+
+// top three of the union of two descending triples
+__device__ __forceinline__ void merge3(float& a1, float& a2, float& a3, float b1, float b2, float b3) {
+    const float x = min_nc(a1, b1), y = max_nc(a2, b2), z = min_nc(a2, b2), w = max_nc(a3, b3);
+    a1 = max_nc(a1, b1);
+    a2 = max_nc(x, y);
+    a3 = max_nc(min_nc(x, y), max_nc(z, w));
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// Points are dealt to the tiles round robin and to the 256 slots of a tile (wave, block, lane) through a multiplicative
+// permutation: neighbours in the cloud's order -- often neighbours in space, i.e. near ties -- land in different waves.
+__device__ __forceinline__ int point_of_slot(int tile, int slot, int tiles) { return ((slot * 67) & 255) * tiles + tile; }
+// id bits of a tracked score: [3:0] accumulator register, [4] point block, [5] lane half, [7:6] wave -> slot inside the tile
+__device__ __forceinline__ int slot_of_id(unsigned id) {
+    const int e = id & 15, pb = (id >> 4) & 1, h = (id >> 5) & 1, w = (id >> 6) & 3;
+    return w * 64 + pb * 32 + 8 * (e >> 2) + 4 * h + (e & 3);
+}
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __restrict__ pc, const float* __restrict__ trans,
+                                                                 int N, int Npad, int tiles, const float* __restrict__ W1,
+                                                                 const float* __restrict__ b1, const uint16_t* __restrict__ W2p,
+                                                                 const float* __restrict__ b2, const char* __restrict__ w3f,
+                                                                 float* __restrict__ h2buf, f32x4* __restrict__ part,
+                                                                 unsigned* __restrict__ tstat, const float* __restrict__ cbuf,
+                                                                 int abl /* timing diagnostics only (DVQ_PN_ABL) */) {
+    extern __shared__ __attribute__((aligned(16))) char fl[];
+    f32x4* tb = reinterpret_cast<f32x4*>(fl + F_OFF_TB);
+    float* w1s = reinterpret_cast<float*>(fl + F_OFF_W1);
+    float* b1s = reinterpret_cast<float*>(fl + F_OFF_B1);
+    float* b2s = reinterpret_cast<float*>(fl + F_OFF_B2);
+    float* scs = reinterpret_cast<float*>(fl + F_OFF_SC);
+    float* tis = reinterpret_cast<float*>(fl + F_OFF_TI);
+    float* cs = reinterpret_cast<float*>(fl + F_OFF_CS);
+    float* wst = reinterpret_cast<float*>(fl + F_OFF_WS);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const long b = blockIdx.x / tiles;
+    const int tile = blockIdx.x % tiles;
+
+    w2_issue(W2p, 0, fl, wave, lane);
+    w2_issue(W2p, 64, fl + F_STAGE2, wave, lane);
+    w1s[tid] = W1[tid];
+    if (tid < 64) b1s[tid] = b1[tid];
+    if (tid < 128) b2s[tid] = b2[tid];
+    *reinterpret_cast<f32x4*>(tis + 4 * tid) = *reinterpret_cast<const f32x4*>(w3f + 1024 * 256 + 16 * tid);
+    if (tid < 128) cs[tid] = cbuf[b * 128 + tid];
+
+    float xin[2][4];
+    int pidx[2];
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+        int p = point_of_slot(tile, wave * 64 + pb * 32 + r, tiles);
+        pidx[pb] = p;
+        if (p >= N) p = N - 1;                            // padding slots load the last point (their conv3 rows are zeroed below)
+        const float* src = pc + b * (long)C * N + p;
+        float x0 = src[0], x1 = src[N], x2 = src[2L * N];
+        const float x3 = (C > 3) ? src[3L * N] : 0.f;
+        if (trans) {                                      // xyz @ trans[b]  (pointnet_encoder.py:146)
+            const float* t = trans + b * 9;
+            const float n0 = fmaf(x2, t[6], fmaf(x1, t[3], x0 * t[0]));
+            const float n1 = fmaf(x2, t[7], fmaf(x1, t[4], x0 * t[1]));
+            const float n2 = fmaf(x2, t[8], fmaf(x1, t[5], x0 * t[2]));
+            x0 = n0; x1 = n1; x2 = n2;
+        }
+        xin[pb][0] = x0; xin[pb][1] = x1; xin[pb][2] = x2; xin[pb][3] = x3;
+    }
+    __syncthreads();                                      // W1/b1/b2 visible, W2 planes landed
+
+    // ---- conv1 + conv2 (six-product split-bf16), h2 = relu(conv2 + b2) kept in fp32: hv[pb][16 t4 + e]
+    float hv[2][64];
+    float nrm2 = 0.f;
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+        qbf16x8 h1f[4][3];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * s + 8 * h + j;
+                const f32x4 w = *reinterpret_cast<const f32x4*>(w1s + 4 * k);
+                float a = xin[pb][0] * w[0];
+                a = fmaf(xin[pb][1], w[1], a);
+                a = fmaf(xin[pb][2], w[2], a);
+                a = fmaf(xin[pb][3], w[3], a);
+                v[j] = fmaxf(a + b1s[k], 0.f);
+            }
+            q_split8(v, h1f[s]);
+        }
+        float sq = 0.f;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const char* st = fl + (t4 >> 1) * F_STAGE2;
+            const int row = 32 * (t4 & 1) + r;
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                qbf16x8 wf[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) wf[pl] = w2_frag(st, pl, row, 2 * s + h);
+                Q_MFMA6(acc, wf, h1f[s]);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ch = 32 * t4 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const float v = fmaxf(acc[e] + b2s[ch], 0.f);
+                hv[pb][16 * t4 + e] = v;
+                sq = fmaf(v, v, sq);
+            }
+            if (pidx[pb] < N && !(abl & 1)) {             // natural channel order: 4 consecutive channels per 16-byte store
+                float* dst = h2buf + ((b * Npad + pidx[pb]) * 128 + 32 * t4 + 4 * h);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(dst + 8 * g) =
+                        f32x4{hv[pb][16 * t4 + 4 * g], hv[pb][16 * t4 + 4 * g + 1], hv[pb][16 * t4 + 4 * g + 2], hv[pb][16 * t4 + 4 * g + 3]};
+            }
+        }
+        sq += __shfl_xor(sq, 32);                         // the two lane halves hold the two halves of a point's channels
+        nrm2 = fmaxf(nrm2, sq);
+    }
+    // ---- centre the rows on the sample's centre (pn_center_kernel)
+    float amax = 0.f, dn2 = 0.f;
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 c4 = *reinterpret_cast<const f32x4*>(cs + 32 * t4 + 8 * g + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                hv[0][16 * t4 + 4 * g + i] -= c4[i];
+                hv[1][16 * t4 + 4 * g + i] -= c4[i];
+            }
+        }
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            amax = fmaxf(amax, fabsf(hv[pb][i]));
+            sq = fmaf(hv[pb][i], hv[pb][i], sq);
+        }
+        sq += __shfl_xor(sq, 32);
+        dn2 = fmaxf(dn2, sq);
+    }
+    amax = wave_max(amax);
+    nrm2 = wave_max(nrm2);
+    dn2 = wave_max(dn2);
+    // per-wave power-of-two scale: amax * s in [2^14, 2^15)
+    float s_w = 1.f;
+    {
+        const int ex = (int)((__float_as_uint(amax) >> 23) & 255u);              // amax in [2^(ex-127), 2^(ex-126))
+        if (ex > 20 && ex < 235) s_w = __uint_as_float((unsigned)(127 + 15 - (ex - 126)) << 23);
+    }
+    // conv3's A operand, one fp16 plane: step = 2 t4 + q, k order inside a step as conv2's accumulator delivers it;
+    // rn2 = largest squared norm of a row's rounding residual (scaled units)
+    qf16x8 a3[2][8];
+    float rn2 = 0.f;
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+        float sq = 0.f;
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            qf16x8 f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                // a padding slot plays the sample's centre (score w.c = mean of four real scores <= the maximum), not a
+                // copy of the last point: copies would tie with each other and flag their waves
+                const float v = pidx[pb] < N ? hv[pb][8 * st + j] * s_w : 0.f;
+                f[j] = (_Float16)v;
+                const float res = v - (float)f[j];
+                sq = fmaf(res, res, sq);
+            }
+            a3[pb][st] = f;
+        }
+        sq += __shfl_xor(sq, 32);
+        rn2 = fmaxf(rn2, sq);
+    }
+    rn2 = wave_max(rn2);
+    if (lane == 0) {              // per-tile maxima; non-negative floats (and NaN, above all of them) order as integers
+        const float hm = sqrtf(nrm2), dmx = sqrtf(dn2), rdm = sqrtf(rn2) / s_w;
+        scs[wave] = 1.0f / s_w;
+        wst[wave] = hm; wst[4 + wave] = dmx; wst[8 + wave] = rdm;
+        atomicMax(tstat + 4 * blockIdx.x + 0, __float_as_uint(hm));
+        atomicMax(tstat + 4 * blockIdx.x + 1, __float_as_uint(dmx));
+        atomicMax(tstat + 4 * blockIdx.x + 2, __float_as_uint(rdm));
+    }
+    __syncthreads();                                      // everybody is done with W2 in the stages; scs visible
+
+    // ---- conv3, filtered: 16 chunks of 64 channels, one fp16 product, top three scores per channel
+    const char* w3h = w3f;
+    W3Regs wreg = w3_load(w3h, 0, wave, lane);
+    w3_store(fl, wave, lane, wreg);
+    const float* wnorm_g = reinterpret_cast<const float*>(w3f + 1024 * 256 + 4096);
+    const float* rnorm_g = reinterpret_cast<const float*>(w3f + 1024 * 256 + 8192);
+    float pub_wn = 0.f, pub_rn = 0.f;    // norms of the channel this lane publishes next (loaded one barrier ahead)
+    // wave (c & 3): per channel of chunk c the three largest id-carrying scores of the tile (real units) and, per wave, a
+    // flag "holds a point within 2 E of the tile's largest score that is not among the three"
+    auto publish = [&](int c) {
+        const f32x4* src = tb + (c & 1) * 256;
+        const float ti = tis[64 * c + lane];
+        const float hm = fmaxf(fmaxf(wst[0], wst[1]), fmaxf(wst[2], wst[3])) * 1.00001f;
+        const float dmx = fmaxf(fmaxf(wst[4], wst[5]), fmaxf(wst[6], wst[7])) * 1.00001f;
+        const float rdm = fmaxf(fmaxf(wst[8], wst[9]), fmaxf(wst[10], wst[11])) * 1.00001f;
+        const float e2 = 2.0f * fmaf(pub_rn, dmx, fmaf(pub_wn, rdm, fmaf(C_ID * pub_wn, dmx, 2.0f * DELTA * pub_wn * hm)));
+        float v1[4], v2[4], v3[4];
+        float c1 = NEG_BIG, c2 = NEG_BIG, c3 = NEG_BIG;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const f32x4 q = src[w * 64 + lane];
+            const float f = scs[w] * ti;
+            v1[w] = __uint_as_float((__float_as_uint(q[0] * f) & ~0xC0u) | (unsigned)(w << 6));
+            v2[w] = __uint_as_float((__float_as_uint(q[1] * f) & ~0xC0u) | (unsigned)(w << 6));
+            v3[w] = q[2] * f;
+            c3 = __builtin_amdgcn_fmed3f(c2, c3, v1[w]); c2 = __builtin_amdgcn_fmed3f(c1, c2, v1[w]); c1 = max_nc(c1, v1[w]);
+            c3 = __builtin_amdgcn_fmed3f(c2, c3, v2[w]); c2 = __builtin_amdgcn_fmed3f(c1, c2, v2[w]); c1 = max_nc(c1, v2[w]);
+        }
+        const float thr = c1 - e2;                         // NaN -> no flag here; pn_exact_kernel sees the non-finite bound
+        unsigned flags = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const bool f = (v3[w] >= thr) || (v2[w] >= thr && v2[w] < c3) || (v1[w] >= thr && v1[w] < c3);
+            flags |= f ? (1u << w) : 0u;
+        }
+        part[((long)blockIdx.x) * 1024 + 64 * c + lane] = f32x4{c1, c2, c3, __uint_as_float(flags)};
+    };
+    // one 32-point x 32-channel block: 8 MFMAs; its 32 scores per lane go through the top-three chain (4 vector
+    // instructions per score) while the NEXT block's MFMAs run: 1 MFMA (32 cycles of the matrix pipe) per 8 chain instructions
+#define F_MFMA_BLOCK(ACC, PB, WF)                                                                              \
+    do {                                                                                                       \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) ACC[e] = 0.f;                                           \
+        _Pragma("unroll") for (int s = 0; s < 8; ++s)                                                          \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3[PB][s], WF[s], ACC, 0, 0, 0);                      \
+    } while (0)
+#define F_CHAIN_BLOCK(ACC, PB, M1, M2, M3)                                                                     \
+    do {                                                                                                       \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                       \
+            const float x = __uint_as_float((__float_as_uint(ACC[e]) & ~31u) | (unsigned)(16 * (PB) + e));     \
+            M3 = __builtin_amdgcn_fmed3f(M2, M3, x);                                                           \
+            M2 = __builtin_amdgcn_fmed3f(M1, M2, x);                                                           \
+            M1 = max_nc(M1, x);                                                                                \
+        }                                                                                                      \
+    } while (0)
+#define F_INTERLEAVE()                                                                                         \
+    do {                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 \
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                                                 \
+        }                                                                                                      \
+    } while (0)
+    // the other lane half holds the same channel for the other 32 points: merge, lanes 0..31 hand the triple over
+    auto finish = [&](int c, int jn, float m1, float m2, float m3) {
+        m1 = __uint_as_float((__float_as_uint(m1) & ~32u) | (unsigned)(h << 5));
+        m2 = __uint_as_float((__float_as_uint(m2) & ~32u) | (unsigned)(h << 5));
+        const float o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32), o3 = __shfl_xor(m3, 32);
+        merge3(m1, m2, m3, o1, o2, o3);
+        if (h == 0) tb[(c & 1) * 256 + wave * 64 + 32 * jn + r] = f32x4{m1, m2, m3, 0.f};
+    };
+    int stage = 0;
+    for (int c = 0; c < ((abl & 2) ? 0 : 16); ++c) {
+        __syncthreads();                                  // chunk c is in its stage; the other stage and tb parity are free
+        if (c + 1 < 16) wreg = w3_load(w3h, 64 * (c + 1), wave, lane);
+        if (c > 0 && wave == ((c - 1) & 3)) publish(c - 1);
+        const char* st = fl + stage * F_STAGE3;
+        qf16x8 wf0[8], wf1[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) wf0[s] = w3_frag(st, r, 2 * s + h);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) wf1[s] = w3_frag(st, 32 + r, 2 * s + h);
+        f32x16 accA, accB;
+        float a1 = NEG_BIG, a2 = NEG_BIG, a3m = NEG_BIG, b1m = NEG_BIG, b2m = NEG_BIG, b3m = NEG_BIG;
+        F_MFMA_BLOCK(accA, 0, wf0);
+        F_MFMA_BLOCK(accB, 1, wf0);
+        F_CHAIN_BLOCK(accA, 0, a1, a2, a3m);
+        F_INTERLEAVE();
+        F_MFMA_BLOCK(accA, 0, wf1);
+        F_CHAIN_BLOCK(accB, 1, a1, a2, a3m);
+        F_INTERLEAVE();
+        F_MFMA_BLOCK(accB, 1, wf1);
+        F_CHAIN_BLOCK(accA, 0, b1m, b2m, b3m);
+        F_INTERLEAVE();
+        F_CHAIN_BLOCK(accB, 1, b1m, b2m, b3m);
+        finish(c, 0, a1, a2, a3m);
+        finish(c, 1, b1m, b2m, b3m);
+        if (wave == (c & 3)) {                             // consumed after the next barrier (its vmcnt(0) covers the loads)
+            pub_wn = wnorm_g[64 * c + lane];
+            pub_rn = rnorm_g[64 * c + lane];
+        }
+        if (c + 1 < 16) w3_store(fl + (stage ^ 1) * F_STAGE3, wave, lane, wreg);
+        stage ^= 1;
+    }
+#undef F_MFMA_BLOCK
+#undef F_CHAIN_BLOCK
+#undef F_INTERLEAVE
+    __syncthreads();
+    if (wave == 3) publish(15);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// exact_dot: THE definition of a conv3 score on this path.  16 lanes per dot, lane j owns k = 8j .. 8j+7 (fixed FMA
+// order), then a 16-lane butterfly (every lane gets the same bits).
+template <int CTRL>
+__device__ __forceinline__ float q_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float exact_dot_regs(const f32x4& w0, const f32x4& w1, const f32x4& a, const f32x4& c) {
+    float s = w0[0] * a[0];
+    s = fmaf(w0[1], a[1], s);
+    s = fmaf(w0[2], a[2], s);
+    s = fmaf(w0[3], a[3], s);
+    s = fmaf(w1[0], c[0], s);
+    s = fmaf(w1[1], c[1], s);
+    s = fmaf(w1[2], c[2], s);
+    s = fmaf(w1[3], c[3], s);
+    s += q_dpp<0xB1>(s);
+    s += q_dpp<0x4E>(s);
+    s += q_dpp<0x141>(s);
+    s += q_dpp<0x140>(s);
+    return s;
+}
+__device__ __forceinline__ float exact_dot(const f32x4& w0, const f32x4& w1, const float* __restrict__ hrow, int j) {
+    return exact_dot_regs(w0, w1, *reinterpret_cast<const f32x4*>(hrow + 8 * j), *reinterpret_cast<const f32x4*>(hrow + 8 * j + 4));
+}
+// torch.max semantics: a NaN wins
+__device__ __forceinline__ float max_nan(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b); }
+
+// order-preserving map float -> unsigned (for atomicMax on LDS)
+__device__ __forceinline__ unsigned f2key(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// One workgroup per sample, 16 groups of 16 lanes.
+//   phase A (one thread per channel): best lower bound over the tiles; every kept score whose upper bound reaches it
+//           becomes a candidate point of the channel (table of 4 per channel, the rest in a list); flagged waves of tiles in
+//           contention become (channel, tile, wave) entries;
+//   phase B (one group per channel): the weight row once, its candidates' rows together, exact_dot, maximum;
+//   phase C (one wave per entry, no barrier): the 64 points of a flagged wave; then, whole workgroup per channel, every
+//           point for the channels on the "everything" list (DVQ_PN_EXHAUSTIVE / non-finite inputs).
+// stats (optional): channels with one candidate, with another count, wave entries, candidates.
+constexpr int PAIR_CAP = 1024;
+constexpr int FB_CAP = 2048;
+__global__ __launch_bounds__(256) void pn_exact_kernel(const f32x4* __restrict__ part, int tiles, const float* __restrict__ h2buf,
+                                                       int N, int Npad, const float* __restrict__ w3, const float* __restrict__ b3,
+                                                       const float* __restrict__ wnorm, const float* __restrict__ rnorm,
+                                                       const unsigned* __restrict__ tstat, int relu, int exhaustive,
+                                                       int pair_cap, int fb_cap, float* __restrict__ feat, long ld_feat,
+                                                       unsigned long long* __restrict__ stats) {
+    __shared__ unsigned short cand[1024][4];
+    __shared__ unsigned char cand_n[1024];
+    __shared__ int pair_list[PAIR_CAP];
+    __shared__ int fb_list[FB_CAP];
+    __shared__ short all_list[1024];
+    __shared__ int pair_count, fb_count, all_count;
+    __shared__ float fb_part[16];
+    __shared__ float hm[MAX_TILES], dm[MAX_TILES], rd[MAX_TILES];
+    __shared__ unsigned best_k[1024];
+    const int tid = threadIdx.x, g = tid >> 4, j = tid & 15;
+    const long b = blockIdx.x;
+    if (tid == 0) { pair_count = 0; fb_count = 0; all_count = 0; }
+    if (tid < tiles) {
+        const unsigned* ts = tstat + 4 * (b * tiles + tid);
+        hm[tid] = __uint_as_float(ts[0]) * 1.00001f;
+        dm[tid] = __uint_as_float(ts[1]) * 1.00001f;
+        rd[tid] = __uint_as_float(ts[2]) * 1.00001f;
+    }
+    __syncthreads();
+    const float* h2 = h2buf + b * (long)Npad * 128;
+    const f32x4* pt = part + b * (long)tiles * 1024;
+    // ---- phase A
+    unsigned n_single = 0, n_multi = 0, n_cand = 0, n_wave = 0;
+    for (int n = tid; n < 1024; n += 256) {
+        best_k[n] = f2key(NEG_BIG);
+        const float wn = wnorm[n], rn = rnorm[n];
+        float lb = NEG_BIG, e_all = 0.f;
+        for (int t = 0; t < tiles; ++t) {
+            const float et = fmaf(rn, dm[t], fmaf(wn, rd[t], fmaf(C_ID * wn, dm[t], 2.0f * DELTA * wn * hm[t])));
+            e_all = fmaxf(e_all, et);
+            lb = fmaxf(lb, pt[t * 1024 + n][0] - et);
+        }
+        int cands = 0;
+        const bool all = exhaustive || !(e_all < 3.0e38f) || !(lb > NEG_BIG) || !(lb < 3.0e38f);   // non-finite inputs: evaluate everything
+        if (all) {
+            all_list[atomicAdd(&all_count, 1)] = (short)n;
+            cand_n[n] = 0;
+            continue;
+        }
+        for (int t = 0; t < tiles; ++t) {
+            const f32x4 q = pt[t * 1024 + n];
+            const float et = fmaf(rn, dm[t], fmaf(wn, rd[t], fmaf(C_ID * wn, dm[t], 2.0f * DELTA * wn * hm[t])));
+            if (!(q[0] + et >= lb)) continue;               // the tile's largest score is out of range: so is the rest of it
+            unsigned flags = __float_as_uint(q[3]) & 15u;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (q[k] + et >= lb) {
+                    int p = point_of_slot(t, slot_of_id(__float_as_uint(q[k]) & 255u), tiles);
+                    if (p >= N) p = N - 1;
+                    if (cands < 4) cand[n][cands] = (unsigned short)p;
+                    else {
+                        const int slot = atomicAdd(&pair_count, 1);
+                        if (slot < pair_cap) pair_list[slot] = n | (p << 10);
+                        else flags |= 1u << ((__float_as_uint(q[k]) >> 6) & 3u);   // list full (never seen): evaluate its wave instead
+                    }
+                    ++cands;
+                }
+            while (flags) {
+                const int w = __ffs(flags) - 1;
+                flags &= flags - 1;
+                const int slot = atomicAdd(&fb_count, 1);
+                if (slot < fb_cap) fb_list[slot] = n | (t << 10) | (w << 20);
+                else {                                       // list full (never seen): this thread walks the wave's points itself
+                    for (int sl = 64 * w; sl < 64 * w + 64; ++sl) {
+                        int p = point_of_slot(t, sl, tiles);
+                        if (p >= N) p = N - 1;
+                        float sacc[16];
+                        // same arithmetic as exact_dot, one thread playing the sixteen lanes
+                        for (int l = 0; l < 16; ++l) {
+                            const float* wr = w3 + n * 128 + 8 * l;
+                            const float* hr = h2 + (long)p * 128 + 8 * l;
+                            float a = wr[0] * hr[0];
+                            for (int k = 1; k < 8; ++k) a = fmaf(wr[k], hr[k], a);
+                            sacc[l] = a;
+                        }
+                        for (int l = 0; l < 16; l += 2) sacc[l] = sacc[l] + sacc[l + 1];       // xor 1
+                        for (int l = 0; l < 16; l += 4) sacc[l] = sacc[l] + sacc[l + 2];       // xor 2
+                        const float lo = sacc[0] + sacc[4], hi = sacc[8] + sacc[12];           // half mirror, mirror
+                        atomicMax(&best_k[n], f2key(lo + hi));
+                    }
+                }
+                ++n_wave;
+            }
+        }
+        cand_n[n] = (unsigned char)min(cands, 4);
+        n_single += cands == 1;
+        n_multi += cands != 1;
+        n_cand += cands;
+    }
+    __syncthreads();
+    // ---- phase B: table
+    for (int n = g; n < 1024; n += 16) {
+        const int cn = cand_n[n];
+        if (cn == 0) continue;
+        const float* wr = w3 + n * 128 + 8 * j;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr), w1 = *reinterpret_cast<const f32x4*>(wr + 4);
+        f32x4 ha[4], hb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u < cn) {                                  // all loads first, then the arithmetic
+                const float* hr = h2 + (long)cand[n][u] * 128 + 8 * j;
+                ha[u] = *reinterpret_cast<const f32x4*>(hr);
+                hb[u] = *reinterpret_cast<const f32x4*>(hr + 4);
+            }
+        float best = exact_dot_regs(w0, w1, ha[0], hb[0]);
+#pragma unroll
+        for (int u = 1; u < 4; ++u)
+            if (u < cn) best = fmaxf(best, exact_dot_regs(w0, w1, ha[u], hb[u]));
+        if (j == 0) atomicMax(&best_k[n], f2key(best));
+    }
+    // ---- phase B: overflow list
+    const int npairs = min(pair_count, pair_cap);
+    for (int i = g; i < npairs; i += 16) {
+        const int code = pair_list[i];
+        const int n = code & 1023;
+        const float* wr = w3 + n * 128 + 8 * j;
+        const float v = exact_dot(*reinterpret_cast<const f32x4*>(wr), *reinterpret_cast<const f32x4*>(wr + 4), h2 + (long)(code >> 10) * 128, j);
+        if (j == 0) atomicMax(&best_k[n], f2key(v));
+    }
+    // ---- phase C: flagged waves, one wave of the workgroup per entry, its four groups take 16 points each
+    const int nfb = min(fb_count, fb_cap);
+    for (int i = tid >> 6; i < nfb; i += 4) {
+        const int code = fb_list[i];
+        const int n = code & 1023, t = (code >> 10) & 1023, w = (code >> 20) & 3;
+        const float* wr = w3 + n * 128 + 8 * j;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr), w1 = *reinterpret_cast<const f32x4*>(wr + 4);
+        float best = NEG_BIG;
+        for (int q0 = 0; q0 < 16; q0 += 4) {
+            f32x4 ha[4], hb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int p = point_of_slot(t, 64 * w + 16 * (g & 3) + q0 + u, tiles);
+                if (p >= N) p = N - 1;
+                const float* hr = h2 + (long)p * 128 + 8 * j;
+                ha[u] = *reinterpret_cast<const f32x4*>(hr);
+                hb[u] = *reinterpret_cast<const f32x4*>(hr + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) best = fmaxf(best, exact_dot_regs(w0, w1, ha[u], hb[u]));
+        }
+        if (j == 0) atomicMax(&best_k[n], f2key(best));
+    }
+    __syncthreads();
+    // ---- phase C: everything (NaN-propagating maximum, torch.max semantics)
+    const int nall = all_count;
+    for (int i = 0; i < nall; ++i) {
+        const int n = all_list[i];
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(w3 + n * 128 + 8 * j);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(w3 + n * 128 + 8 * j + 4);
+        float best = NEG_BIG;
+        for (int p = g; p < N; p += 16) best = max_nan(best, exact_dot(w0, w1, h2 + (long)p * 128, j));
+        if (j == 0) fb_part[g] = best;
+        __syncthreads();
+        if (tid == 0) {
+            float v = fb_part[0];
+            for (int k = 1; k < 16; ++k) v = max_nan(v, fb_part[k]);
+            best_k[n] = (v != v) ? 0xffffffffu : f2key(v);       // NaN: the largest key, decoded below
+        }
+        __syncthreads();
+    }
+    for (int n = tid; n < 1024; n += 256) {
+        const unsigned k = best_k[n];
+        const float v = (k == 0xffffffffu ? __builtin_nanf("") : key2f(k)) + b3[n];
+        feat[b * ld_feat + n] = relu ? (v != v ? v : fmaxf(v, 0.f)) : v;
+    }
+    if (stats) {
+        if (n_single) atomicAdd(stats + 0, (unsigned long long)n_single);
+        if (n_multi) atomicAdd(stats + 1, (unsigned long long)n_multi);
+        if (n_wave) atomicAdd(stats + 2, (unsigned long long)n_wave);
+        if (n_cand) atomicAdd(stats + 3, (unsigned long long)n_cand);
+    }
+}
+
+// Centre of a sample: mean of the conv2 rows of the points 0, N/4, N/2, 3N/4, plain fp32 (any vector would do -- it shifts
+// every score of a channel by the same w.c -- but one close to the rows makes the fp16 residuals, hence the bounds, small).
+template <int C>
+__global__ __launch_bounds__(256) void pn_center_kernel(const float* __restrict__ pc, const float* __restrict__ trans, int N,
+                                                        const float* __restrict__ W1, const float* __restrict__ b1,
+                                                        const float* __restrict__ W2, const float* __restrict__ b2,
+                                                        float* __restrict__ cbuf) {
+    __shared__ float h1c[4][64];
+    __shared__ float h2c[4][128];
+    const int tid = threadIdx.x, q = tid >> 6, k = tid & 63;
+    const long b = blockIdx.x;
+    {
+        const int p = (int)(((long)q * N) / 4);
+        const float* src = pc + b * (long)C * N + p;
+        float x0 = src[0], x1 = src[N], x2 = src[2L * N];
+        const float x3 = (C > 3) ? src[3L * N] : 0.f;
+        if (trans) {
+            const float* t = trans + b * 9;
+            const float n0 = fmaf(x2, t[6], fmaf(x1, t[3], x0 * t[0]));
+            const float n1 = fmaf(x2, t[7], fmaf(x1, t[4], x0 * t[1]));
+            const float n2 = fmaf(x2, t[8], fmaf(x1, t[5], x0 * t[2]));
+            x0 = n0; x1 = n1; x2 = n2;
+        }
+        const float* w = W1 + 4 * k;
+        float a = x0 * w[0];
+        a = fmaf(x1, w[1], a);
+        a = fmaf(x2, w[2], a);
+        a = fmaf(x3, w[3], a);
+        h1c[q][k] = fmaxf(a + b1[k], 0.f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int ch = k + 64 * half;
+        const float* w = W2 + ch * 64;
+        float a = 0.f;
+        for (int i = 0; i < 64; ++i) a = fmaf(w[i], h1c[q][i], a);
+        h2c[q][ch] = fmaxf(a + b2[ch], 0.f);
+    }
+    __syncthreads();
+    if (tid < 128) cbuf[b * 128 + tid] = 0.25f * ((h2c[0][tid] + h2c[1][tid]) + (h2c[2][tid] + h2c[3][tid]));
+}
+
+// One wave per conv3 output channel: fp16 image (k permuted to conv2's accumulator order, scaled by a power of two so that
+// the row maximum lies in [2^14, 2^15)), 1 / scale, |w| rounded up.
+__global__ __launch_bounds__(256) void pn_filter_pack_kernel(const float* __restrict__ w3, _Float16* __restrict__ wh,
+                                                             float* __restrict__ tinv, float* __restrict__ wnorm,
+                                                             float* __restrict__ rnorm) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const float a = w3[n * 128 + lane], c = w3[n * 128 + 64 + lane];
+    const float amax = wave_max(fmaxf(fabsf(a), fabsf(c)));
+    float sq = fmaf(a, a, c * c);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sq += __shfl_xor(sq, o);
+    float t = 1.f;
+    const int ex = (int)((__float_as_uint(amax) >> 23) & 255u);
+    if (ex > 20 && ex < 235) t = __uint_as_float((unsigned)(127 + 15 - (ex - 126)) << 23);
+    // image position pos = 16 blk + q holds channel 16 blk + perm(q), perm = (0 1 2 3 8 9 10 11 4 5 6 7 12 13 14 15)
+    float rs = 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int pos = 64 * half + lane;
+        const int q = pos & 15;
+        const int k = (pos & ~15) + ((q & 3) | ((q & 4) << 1) | ((q & 8) >> 1));
+        const float v = w3[n * 128 + k] * t;
+        const _Float16 hv = (_Float16)v;
+        wh[n * 128 + pos] = hv;
+        const float res = v - (float)hv;
+        rs = fmaf(res, res, rs);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) rs += __shfl_xor(rs, o);
+    if (lane == 0) {
+        tinv[n] = 1.0f / t;
+        wnorm[n] = sqrtf(sq) * 1.00001f;
+        rnorm[n] = sqrtf(rs) / t * 1.00001f;
+    }
+}
+
+}  // namespace
+
+size_t dvq_pn_filter_image_bytes() { return (size_t)1024 * 256 + 3 * 1024 * 4; }
+
+int dvq_launch_pn_filter_pack(const float* w3, void* image, hipStream_t st) {
+    char* im = (char*)image;
+    DVQ_LAUNCH(pn_filter_pack_kernel, dim3(256), dim3(256), 0, st, w3, reinterpret_cast<_Float16*>(im),
+               reinterpret_cast<float*>(im + 1024 * 256), reinterpret_cast<float*>(im + 1024 * 256 + 4096),
+               reinterpret_cast<float*>(im + 1024 * 256 + 8192));
+    DVQ_CHECK_LAUNCH("pn_filter_pack");
+    return DVQ_OK;
+}
+
+// tiles of 256 points; h2buf [B][Npad][128] fp32, part [B][tiles][1024] float4, hmax [B] (zeroed here)
+int dvq_launch_pn_trunk_filter(const float* pc, int C, int N, int Npad, long B, const float* trans, const float* W1, const float* b1,
+                               const float* W2, const uint16_t* W2p, const float* b2, const void* w3f, const float* w3, const float* b3,
+                               int relu, float* h2buf, void* part, unsigned* tstat, float* cbuf, float* feat, long ld_feat,
+                               unsigned long long* stats, hipStream_t st) {
+    const int tiles = (N + 255) / 256;
+    DVQ_REQUIRE(tiles <= MAX_TILES, "pointnet: the filtered trunk takes at most %d points", MAX_TILES * 256);
+    static DvqOncePerDevice attr_once;
+    {
+        const hipError_t e = attr_once.run([] {
+            const hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_trunk_filter_kernel<3>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+            const hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_trunk_filter_kernel<4>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+            return e3 != hipSuccess ? e3 : e4;
+        });
+        if (e != hipSuccess) {
+            dvq_set_error("pointnet: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return DVQ_ELAUNCH;
+        }
+    }
+    const long grid = B * tiles;
+    DVQ_REQUIRE(grid < (1L << 31), "pointnet: grid too large");
+    DVQ_REQUIRE(Npad >= N, "pointnet: bad padded row count");
+    if (hipMemsetAsync(tstat, 0, (size_t)grid * 16, st) != hipSuccess ||
+        (stats && hipMemsetAsync(stats, 0, 64, st) != hipSuccess)) {
+        dvq_set_error("pointnet: hipMemsetAsync failed");
+        return DVQ_ELAUNCH;
+    }
+    {
+        DVQ_PROF("pn_center", 2.0 * (double)B * 4 * (4.0 * 64 + 64.0 * 128), (double)B * (64 + 512), st);
+        if (C == 3) DVQ_LAUNCH(pn_center_kernel<3>, dim3((unsigned)B), dim3(256), 0, st, pc, trans, N, W1, b1, W2, b2, cbuf);
+        else DVQ_LAUNCH(pn_center_kernel<4>, dim3((unsigned)B), dim3(256), 0, st, pc, trans, N, W1, b1, W2, b2, cbuf);
+    }
+    DVQ_CHECK_LAUNCH("pn_center");
+    const double pts = (double)B * tiles * 256;
+    const char* abl_e = getenv("DVQ_PN_ABL");
+    const int abl = abl_e ? atoi(abl_e) : 0;
+    {
+        DVQ_PROF("pn_trunk", 2.0 * pts * (4.0 * 64 + 64.0 * 128 + 128.0 * 1024), pts * (16 + 512) + (double)grid * 16384, st);
+        if (C == 3)
+            DVQ_LAUNCH(pn_trunk_filter_kernel<3>, dim3((unsigned)grid), dim3(256), F_LDS, st, pc, trans, N, Npad, tiles, W1, b1, W2p,
+                       b2, (const char*)w3f, h2buf, (f32x4*)part, tstat, cbuf, abl);
+        else
+            DVQ_LAUNCH(pn_trunk_filter_kernel<4>, dim3((unsigned)grid), dim3(256), F_LDS, st, pc, trans, N, Npad, tiles, W1, b1, W2p,
+                       b2, (const char*)w3f, h2buf, (f32x4*)part, tstat, cbuf, abl);
+    }
+    DVQ_CHECK_LAUNCH("pn_trunk_filter");
+    static const bool exhaustive_default = false;
+    const char* ex = getenv("DVQ_PN_EXHAUSTIVE");
+    const int exhaustive = (ex && ex[0] == '1') ? 1 : (int)exhaustive_default;
+    int pair_cap = PAIR_CAP, fb_cap = FB_CAP;              // tests shrink the lists to reach the overflow paths
+    if (const char* e = getenv("DVQ_PN_CAPS")) {
+        int a = 0, c = 0;
+        if (sscanf(e, "%d,%d", &a, &c) == 2) {
+            pair_cap = a < 0 ? 0 : (a > PAIR_CAP ? PAIR_CAP : a);
+            fb_cap = c < 0 ? 0 : (c > FB_CAP ? FB_CAP : c);
+        }
+    }
+    {
+        DVQ_PROF("pn_exact", 2.0 * (double)B * 1024 * 128, (double)B * (tiles * 16384.0 + 1024.0 * 512 + 4096), st);
+        DVQ_LAUNCH(pn_exact_kernel, dim3((unsigned)B), dim3(256), 0, st, (const f32x4*)part, tiles, h2buf, N, Npad, w3, b3,
+                   reinterpret_cast<const float*>((const char*)w3f + 1024 * 256 + 4096),
+                   reinterpret_cast<const float*>((const char*)w3f + 1024 * 256 + 8192), tstat, relu, exhaustive, pair_cap, fb_cap,
+                   feat, ld_feat, stats);
+    }
+    DVQ_CHECK_LAUNCH("pn_exact");
+    if (stats) {                                          // diagnostics (DVQ_PN_STATS=1): synchronises
+        unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h, stats, sizeof h, hipMemcpyDeviceToHost);
+        (void)hipMemset(stats, 0, sizeof h);
+        const double tot = (double)B * 1024;
+        fprintf(stderr, "[dvq pn] B=%ld N=%d: one candidate %.4f, other counts %.4f of the channels, flagged waves %.5f per channel; %.3f candidate dots per channel\n",
+                B, N, h[0] / tot, h[1] / tot, h[2] / tot, h[3] / tot);
+    }
+    return DVQ_OK;
+}

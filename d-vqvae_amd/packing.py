@@ -47,6 +47,19 @@ def split_bf16x3(w: Tensor) -> Tensor:
     return out
 
 
+def pointnet_filter_image(w3: Tensor) -> Tensor:
+    """uint8 image of a conv3 weight matrix [1024,128] for the filtered PointNet trunk (dvq_pointnet_pack_filter)."""
+    lib = _lib.load()
+    w3 = w3.contiguous()
+    if tuple(w3.shape) != (1024, 128):
+        raise RuntimeError(f"pointnet filter image: conv3 weight must be [1024,128], got {tuple(w3.shape)}")
+    out = torch.empty(lib.dvq_pointnet_filter_bytes(), dtype=torch.uint8, device=w3.device)
+    with torch.cuda.device(w3.device):
+        _lib.check(lib.dvq_pointnet_pack_filter(w3.data_ptr(), out.data_ptr(),
+                                                torch.cuda.current_stream(w3.device).cuda_stream), "dvq_pointnet_pack_filter")
+    return out
+
+
 class _Packed:
     """Holds device tensors + the ctypes struct that points at them; re-homed lazily with .to(device)."""
 
@@ -62,7 +75,7 @@ class _Packed:
         if self.device == device:
             return self
         self.tensors = {k: (v.to(device) if v.dtype == torch.int16 else _dev(v, device)) for k, v in self.tensors.items()
-                        if not k.endswith("__planes")}
+                        if not k.endswith(("__planes", "__filter"))}
         self.device = device
         for name in self.PLANES:                        # split-bf16 images of the GEMM weights, built on the device
             for key in [k for k in self.tensors if k == name or (k.startswith(name) and k[len(name):].isdigit())]:
@@ -108,8 +121,12 @@ class PackedPointNet(_Packed):
     def _bind(self):
         s = _lib.PointnetWeights()
         s.C = self.C
+        for key in ("w3", "s_w3"):                      # conv3 filter images (fp16 rows + scales + norms), built on the device
+            self.tensors[key + "__filter"] = pointnet_filter_image(self.tensors[key])
         for name, _ in _lib.PointnetWeights._fields_[2:]:
-            if name.endswith("p"):
+            if name.endswith("f"):
+                setattr(s, name, self.tensors[name[:-1] + "__filter"].data_ptr())
+            elif name.endswith("p"):
                 setattr(s, name, self.planes_ptr(name[:-1]))
             else:
                 setattr(s, name, self.tensors[name].data_ptr())

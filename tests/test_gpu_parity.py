@@ -195,6 +195,67 @@ def test_pointnet_batched_equals_loop_and_strided_output():
     assert torch.all(out[:, :1024] == 0)
 
 
+def _with_env(key, val, fn):
+    import os
+    old = os.environ.get(key)
+    os.environ[key] = val
+    try:
+        return fn()
+    finally:
+        if old is None:
+            del os.environ[key]
+        else:
+            os.environ[key] = old
+
+
+@pytest.mark.parametrize("C,N,B", [(4, 1024, 6), (3, 778, 5), (4, 100, 3), (4, 3000, 2), (3, 257, 3), (4, 1, 2)])
+def test_pointnet_filter_equals_exhaustive_exact_evaluation(C, N, B):
+    """The fp16 matrix-core filter of conv3 + max never changes the result: the feature is bit-identical to the maximum of
+    the exact fp32 score over ALL points (DVQ_PN_EXHAUSTIVE=1 makes pn_exact_kernel evaluate exactly that), and within the
+    path's tolerance of the six-product trunk kernel (DVQ_PN_FILTER=0)."""
+    net, _ = _pointnet(C, SEED + 10 * C)
+    x = gpu(synth.synthetic_clouds(B, N, seed=300 + N, channels=C))
+    feat, trans, _ = net(x)
+    feat_all, trans_all, _ = _with_env("DVQ_PN_EXHAUSTIVE", "1", lambda: net(x))
+    assert torch.equal(trans, trans_all), "STN trunk: filtered != exhaustive"
+    assert torch.equal(feat, feat_all), "main trunk: filtered != exhaustive"
+    feat6, trans6, _ = _with_env("DVQ_PN_FILTER", "0", lambda: net(x))
+    assert_close(trans, trans6, atol=TOL, what="filtered trunk vs six-product trunk (trans)")
+    assert_close(feat, feat6, atol=TOL, what="filtered trunk vs six-product trunk (feat)")
+
+
+def test_pointnet_filter_list_overflow_paths():
+    """pn_exact_kernel's candidate lists are finite; with the capacities shrunk (DVQ_PN_CAPS) the overflow paths -- a wave
+    evaluated instead of a dropped pair, a thread walking a wave by itself -- must give the same bits."""
+    net, _ = _pointnet(4, SEED + 5)
+    x = gpu(synth.synthetic_clouds(3, 1500, seed=11, channels=4))
+    feat, trans, _ = net(x)
+    for caps in ("7,2048", "4096,3", "0,0", "100,1"):
+        f2, t2, _ = _with_env("DVQ_PN_CAPS", caps, lambda: net(x))
+        assert torch.equal(trans, t2) and torch.equal(feat, f2), f"caps {caps}"
+
+
+def test_pointnet_filter_ties_scales_and_degenerate_clouds():
+    """Duplicate points (exact ties: all three tracked scores equal -> whole-cloud evaluation), clouds scaled by 1e-4 and
+    1e4 (per-wave power-of-two scaling), an all-zero cloud, one huge outlier point."""
+    net, _ = _pointnet(4, SEED + 77)
+    base = synth.synthetic_clouds(4, 700, seed=5, channels=4)
+    cases = {"dup": base[:, :, torch.randint(0, 40, (700,), generator=torch.Generator().manual_seed(1))],
+             "tiny": base * 1e-4, "huge": base * 1e4, "zero": torch.zeros_like(base)}
+    out = base.clone()
+    out[:, :3, 13] = 5e3
+    cases["outlier"] = out
+    for name, x in cases.items():
+        x = gpu(x.contiguous())
+        feat, trans, _ = net(x)
+        feat_all, trans_all, _ = _with_env("DVQ_PN_EXHAUSTIVE", "1", lambda: net(x))
+        assert torch.isfinite(feat).all(), name
+        assert torch.equal(trans, trans_all) and torch.equal(feat, feat_all), f"{name}: filtered != exhaustive"
+        feat6, _, _ = _with_env("DVQ_PN_FILTER", "0", lambda: net(x))
+        scale = float(feat6.abs().max()) + 1.0
+        assert_close(feat / scale, feat6 / scale, atol=TOL, what=f"{name}: filtered vs six-product trunk")
+
+
 def test_pointnet_needs_eval_and_supported_config():
     from dvqvae_amd.network.pointnet_encoder import PointNetEncoder
     net = PointNetEncoder(channel=4).to(DEV).train()
