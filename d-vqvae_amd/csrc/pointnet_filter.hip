@@ -39,8 +39,8 @@ constexpr int MAX_TILES = 64;                             // filtered trunk: N <
 
 constexpr int F_STAGE2 = 3 * 64 * 128;                    // conv2: one half of W2's planes (3 x 64 rows x 128 B)
 constexpr int F_STAGE3 = 64 * 256;                        // conv3: 64 channels x 128 k fp16
-constexpr int F_OFF_TB = 2 * F_STAGE2;                    // [2 parities][4 waves][64 channels] float4
-constexpr int F_OFF_W1 = F_OFF_TB + 2 * 4 * 64 * 16;      // [64][4] fp32
+constexpr int F_OFF_TB = 2 * F_STAGE3;                    // conv3 phase: [8 chunks][4 waves][3][64] fp32 behind the two W3 stages
+constexpr int F_OFF_W1 = F_OFF_TB + 8 * 4 * 3 * 64 * 4;   // [64][4] fp32
 constexpr int F_OFF_B1 = F_OFF_W1 + 64 * 4 * 4;           // [64]
 constexpr int F_OFF_B2 = F_OFF_B1 + 64 * 4;               // [128]
 constexpr int F_OFF_SC = F_OFF_B2 + 128 * 4;              // [4] 1 / (wave scale)
@@ -48,7 +48,7 @@ constexpr int F_OFF_TI = F_OFF_SC + 64;                   // [1024] 1 / (channel
 constexpr int F_OFF_CS = F_OFF_TI + 4096;                 // [128] centre of the sample
 constexpr int F_OFF_WS = F_OFF_CS + 512;                  // [3][4] per-wave |h|max, |d|max, |rd|max
 constexpr int F_LDS = F_OFF_WS + 64;                      // 63 872 B -> 2 workgroups per CU
-static_assert(2 * F_STAGE3 <= 2 * F_STAGE2, "conv3 stages reuse the W2 region");
+static_assert(F_OFF_W1 >= 2 * F_STAGE2, "the conv3 stages and the triple buffer cover the W2 region");
 
 __device__ __forceinline__ float max_nc(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, 3.0e38f); }
 __device__ __forceinline__ float min_nc(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, NEG_BIG); }
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
                                                                  unsigned* __restrict__ tstat, const float* __restrict__ cbuf,
                                                                  int abl /* timing diagnostics only (DVQ_PN_ABL) */) {
     extern __shared__ __attribute__((aligned(16))) char fl[];
-    f32x4* tb = reinterpret_cast<f32x4*>(fl + F_OFF_TB);
+    float* tb = reinterpret_cast<float*>(fl + F_OFF_TB);
     float* w1s = reinterpret_cast<float*>(fl + F_OFF_W1);
     float* b1s = reinterpret_cast<float*>(fl + F_OFF_B1);
     float* b2s = reinterpret_cast<float*>(fl + F_OFF_B2);
@@ -329,12 +329,13 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     w3_store(fl, wave, lane, wreg);
     const float* wnorm_g = reinterpret_cast<const float*>(w3f + 1024 * 256 + 4096);
     const float* rnorm_g = reinterpret_cast<const float*>(w3f + 1024 * 256 + 8192);
-    float pub_wn = 0.f, pub_rn = 0.f;    // norms of the channel this lane publishes next (loaded one barrier ahead)
-    // wave (c & 3): per channel of chunk c the three largest id-carrying scores of the tile (real units) and, per wave, a
-    // flag "holds a point within 2 E of the tile's largest score that is not among the three"
+    // per channel of chunk c the three largest id-carrying scores of the tile (real units) and, per wave, a flag "holds a
+    // point within 2 E of the tile's largest score that is not among the three".  Every wave publishes two chunks after
+    // chunk 7 and after chunk 15 (all four busy at the same time: no wave waits for a publisher at the chunk barriers).
     auto publish = [&](int c) {
-        const f32x4* src = tb + (c & 1) * 256;
+        const float* src = tb + (c & 7) * 768;
         const float ti = tis[64 * c + lane];
+        const float pub_wn = wnorm_g[64 * c + lane], pub_rn = rnorm_g[64 * c + lane];
         const float hm = fmaxf(fmaxf(wst[0], wst[1]), fmaxf(wst[2], wst[3])) * 1.00001f;
         const float dmx = fmaxf(fmaxf(wst[4], wst[5]), fmaxf(wst[6], wst[7])) * 1.00001f;
         const float rdm = fmaxf(fmaxf(wst[8], wst[9]), fmaxf(wst[10], wst[11])) * 1.00001f;
@@ -343,11 +344,11 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         float c1 = NEG_BIG, c2 = NEG_BIG, c3 = NEG_BIG;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const f32x4 q = src[w * 64 + lane];
+            const float q0 = src[w * 192 + lane], q1 = src[w * 192 + 64 + lane], q2 = src[w * 192 + 128 + lane];
             const float f = scs[w] * ti;
-            v1[w] = __uint_as_float((__float_as_uint(q[0] * f) & ~0xC0u) | (unsigned)(w << 6));
-            v2[w] = __uint_as_float((__float_as_uint(q[1] * f) & ~0xC0u) | (unsigned)(w << 6));
-            v3[w] = q[2] * f;
+            v1[w] = __uint_as_float((__float_as_uint(q0 * f) & ~0xC0u) | (unsigned)(w << 6));
+            v2[w] = __uint_as_float((__float_as_uint(q1 * f) & ~0xC0u) | (unsigned)(w << 6));
+            v3[w] = q2 * f;
             c3 = __builtin_amdgcn_fmed3f(c2, c3, v1[w]); c2 = __builtin_amdgcn_fmed3f(c1, c2, v1[w]); c1 = max_nc(c1, v1[w]);
             c3 = __builtin_amdgcn_fmed3f(c2, c3, v2[w]); c2 = __builtin_amdgcn_fmed3f(c1, c2, v2[w]); c1 = max_nc(c1, v2[w]);
         }
@@ -388,15 +389,25 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     auto finish = [&](int c, int jn, float m1, float m2, float m3) {
         m1 = __uint_as_float((__float_as_uint(m1) & ~32u) | (unsigned)(h << 5));
         m2 = __uint_as_float((__float_as_uint(m2) & ~32u) | (unsigned)(h << 5));
-        const float o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32), o3 = __shfl_xor(m3, 32);
+        // v_permlane32_swap: element 1 of the result holds the upper half's values in both halves -- what lanes 0..31 need
+        const float o1 = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(m1), __float_as_uint(m1), false, false)[1]);
+        const float o2 = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(m2), __float_as_uint(m2), false, false)[1]);
+        const float o3 = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(m3), __float_as_uint(m3), false, false)[1]);
         merge3(m1, m2, m3, o1, o2, o3);
-        if (h == 0) tb[(c & 1) * 256 + wave * 64 + 32 * jn + r] = f32x4{m1, m2, m3, 0.f};
+        if (h == 0) {
+            float* dst = tb + (c & 7) * 768 + wave * 192 + 32 * jn + r;
+            dst[0] = m1; dst[64] = m2; dst[128] = m3;
+        }
     };
     int stage = 0;
     for (int c = 0; c < ((abl & 2) ? 0 : 16); ++c) {
         __syncthreads();                                  // chunk c is in its stage; the other stage and tb parity are free
-        if (c + 1 < 16) wreg = w3_load(w3h, 64 * (c + 1), wave, lane);
-        if (c > 0 && wave == ((c - 1) & 3)) publish(c - 1);
+        if (c + 1 < 16 && !(abl & 1024)) wreg = w3_load(w3h, 64 * (c + 1), wave, lane);
+        if (c == 8 && !(abl & 256)) {                      // chunks 0..7 are complete (barrier above): two per wave
+            publish(2 * wave);
+            publish(2 * wave + 1);
+            __syncthreads();                              // before chunk 8's triples overwrite slot 0
+        }
         const char* st = fl + stage * F_STAGE3;
         qf16x8 wf0[8], wf1[8];
 #pragma unroll
@@ -416,20 +427,21 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         F_CHAIN_BLOCK(accA, 0, b1m, b2m, b3m);
         F_INTERLEAVE();
         F_CHAIN_BLOCK(accB, 1, b1m, b2m, b3m);
-        finish(c, 0, a1, a2, a3m);
-        finish(c, 1, b1m, b2m, b3m);
-        if (wave == (c & 3)) {                             // consumed after the next barrier (its vmcnt(0) covers the loads)
-            pub_wn = wnorm_g[64 * c + lane];
-            pub_rn = rnorm_g[64 * c + lane];
-        }
-        if (c + 1 < 16) w3_store(fl + (stage ^ 1) * F_STAGE3, wave, lane, wreg);
+        if (!(abl & 512)) {
+            finish(c, 0, a1, a2, a3m);
+            finish(c, 1, b1m, b2m, b3m);
+        } else if (a1 + b1m + a2 + b2m + a3m + b3m == 12345.f) tb[lane] = a1;
+        if (c + 1 < 16 && !(abl & 1024)) w3_store(fl + (stage ^ 1) * F_STAGE3, wave, lane, wreg);
         stage ^= 1;
     }
 #undef F_MFMA_BLOCK
 #undef F_CHAIN_BLOCK
 #undef F_INTERLEAVE
     __syncthreads();
-    if (wave == 3) publish(15);
+    if (!(abl & 256)) {
+        publish(8 + 2 * wave);
+        publish(8 + 2 * wave + 1);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -477,12 +489,12 @@ __device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k &
 // stats (optional): channels with one candidate, with another count, wave entries, candidates.
 constexpr int PAIR_CAP = 1024;
 constexpr int FB_CAP = 2048;
-__global__ __launch_bounds__(256) void pn_exact_kernel(const f32x4* __restrict__ part, int tiles, const float* __restrict__ h2buf,
+__global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restrict__ part, int tiles, const float* __restrict__ h2buf,
                                                        int N, int Npad, const float* __restrict__ w3, const float* __restrict__ b3,
                                                        const float* __restrict__ wnorm, const float* __restrict__ rnorm,
                                                        const unsigned* __restrict__ tstat, int relu, int exhaustive,
                                                        int pair_cap, int fb_cap, float* __restrict__ feat, long ld_feat,
-                                                       unsigned long long* __restrict__ stats) {
+                                                       unsigned long long* __restrict__ stats, int abl) {
     __shared__ unsigned short cand[1024][4];
     __shared__ unsigned char cand_n[1024];
     __shared__ int pair_list[PAIR_CAP];
@@ -509,29 +521,49 @@ __global__ __launch_bounds__(256) void pn_exact_kernel(const f32x4* __restrict__
     for (int n = tid; n < 1024; n += 256) {
         best_k[n] = f2key(NEG_BIG);
         const float wn = wnorm[n], rn = rnorm[n];
-        float lb = NEG_BIG, e_all = 0.f;
-        for (int t = 0; t < tiles; ++t) {
-            const float et = fmaf(rn, dm[t], fmaf(wn, rd[t], fmaf(C_ID * wn, dm[t], 2.0f * DELTA * wn * hm[t])));
-            e_all = fmaxf(e_all, et);
-            lb = fmaxf(lb, pt[t * 1024 + n][0] - et);
+        float lb, e_all;
+        auto bound = [&](int t) { return fmaf(rn, dm[t], fmaf(wn, rd[t], fmaf(C_ID * wn, dm[t], 2.0f * DELTA * wn * hm[t]))); };
+        // the first four tiles' entries are loaded once (N <= 1024: all of them), the rest in blocks of four
+        const f32x4 f0 = pt[n], f1 = pt[min(1, tiles - 1) * 1024 + n], f2 = pt[min(2, tiles - 1) * 1024 + n],
+                    f3 = pt[min(3, tiles - 1) * 1024 + n];
+        {
+            const float e0 = bound(0);
+            e_all = e0;
+            lb = f0[0] - e0;
+            if (tiles > 1) { const float e = bound(1); e_all = fmaxf(e_all, e); lb = fmaxf(lb, f1[0] - e); }
+            if (tiles > 2) { const float e = bound(2); e_all = fmaxf(e_all, e); lb = fmaxf(lb, f2[0] - e); }
+            if (tiles > 3) { const float e = bound(3); e_all = fmaxf(e_all, e); lb = fmaxf(lb, f3[0] - e); }
+        }
+        for (int t0 = 4; t0 < tiles; t0 += 4) {
+            float top[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) top[u] = pt[min(t0 + u, tiles - 1) * 1024 + n][0];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (t0 + u < tiles) {
+                    const float et = bound(t0 + u);
+                    e_all = fmaxf(e_all, et);
+                    lb = fmaxf(lb, top[u] - et);
+                }
         }
         int cands = 0;
+        bool whole = false;
         const bool all = exhaustive || !(e_all < 3.0e38f) || !(lb > NEG_BIG) || !(lb < 3.0e38f);   // non-finite inputs: evaluate everything
         if (all) {
             all_list[atomicAdd(&all_count, 1)] = (short)n;
             cand_n[n] = 0;
             continue;
         }
-        for (int t = 0; t < tiles; ++t) {
-            const f32x4 q = pt[t * 1024 + n];
-            const float et = fmaf(rn, dm[t], fmaf(wn, rd[t], fmaf(C_ID * wn, dm[t], 2.0f * DELTA * wn * hm[t])));
-            if (!(q[0] + et >= lb)) continue;               // the tile's largest score is out of range: so is the rest of it
+        auto consider = [&](int t, const f32x4& q) {
+            const float et = bound(t);
+            if (!(q[0] + et >= lb)) return;                 // the tile's largest score is out of range: so is the rest of it
             unsigned flags = __float_as_uint(q[3]) & 15u;
 #pragma unroll
             for (int k = 0; k < 3; ++k)
                 if (q[k] + et >= lb) {
                     int p = point_of_slot(t, slot_of_id(__float_as_uint(q[k]) & 255u), tiles);
                     if (p >= N) p = N - 1;
+                    if (abl & 16) p &= 63;
                     if (cands < 4) cand[n][cands] = (unsigned short)p;
                     else {
                         const int slot = atomicAdd(&pair_count, 1);
@@ -545,53 +577,66 @@ __global__ __launch_bounds__(256) void pn_exact_kernel(const f32x4* __restrict__
                 flags &= flags - 1;
                 const int slot = atomicAdd(&fb_count, 1);
                 if (slot < fb_cap) fb_list[slot] = n | (t << 10) | (w << 20);
-                else {                                       // list full (never seen): this thread walks the wave's points itself
-                    for (int sl = 64 * w; sl < 64 * w + 64; ++sl) {
-                        int p = point_of_slot(t, sl, tiles);
-                        if (p >= N) p = N - 1;
-                        float sacc[16];
-                        // same arithmetic as exact_dot, one thread playing the sixteen lanes
-                        for (int l = 0; l < 16; ++l) {
-                            const float* wr = w3 + n * 128 + 8 * l;
-                            const float* hr = h2 + (long)p * 128 + 8 * l;
-                            float a = wr[0] * hr[0];
-                            for (int k = 1; k < 8; ++k) a = fmaf(wr[k], hr[k], a);
-                            sacc[l] = a;
-                        }
-                        for (int l = 0; l < 16; l += 2) sacc[l] = sacc[l] + sacc[l + 1];       // xor 1
-                        for (int l = 0; l < 16; l += 4) sacc[l] = sacc[l] + sacc[l + 2];       // xor 2
-                        const float lo = sacc[0] + sacc[4], hi = sacc[8] + sacc[12];           // half mirror, mirror
-                        atomicMax(&best_k[n], f2key(lo + hi));
-                    }
+                else if (!whole) {                           // list full (never seen): the channel goes on the "everything" list
+                    whole = true;
+                    all_list[atomicAdd(&all_count, 1)] = (short)n;
                 }
                 ++n_wave;
             }
+        };
+        consider(0, f0);
+        if (tiles > 1) consider(1, f1);
+        if (tiles > 2) consider(2, f2);
+        if (tiles > 3) consider(3, f3);
+        for (int t0 = 4; t0 < tiles; t0 += 4) {
+            f32x4 q0 = pt[min(t0, tiles - 1) * 1024 + n], q1 = pt[min(t0 + 1, tiles - 1) * 1024 + n];
+            f32x4 q2 = pt[min(t0 + 2, tiles - 1) * 1024 + n], q3 = pt[min(t0 + 3, tiles - 1) * 1024 + n];
+            consider(t0, q0);
+            if (t0 + 1 < tiles) consider(t0 + 1, q1);
+            if (t0 + 2 < tiles) consider(t0 + 2, q2);
+            if (t0 + 3 < tiles) consider(t0 + 3, q3);
         }
-        cand_n[n] = (unsigned char)min(cands, 4);
+        cand_n[n] = whole ? 0 : (unsigned char)min(cands, 4);
         n_single += cands == 1;
         n_multi += cands != 1;
         n_cand += cands;
     }
     __syncthreads();
-    // ---- phase B: table
-    for (int n = g; n < 1024; n += 16) {
-        const int cn = cand_n[n];
-        if (cn == 0) continue;
-        const float* wr = w3 + n * 128 + 8 * j;
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr), w1 = *reinterpret_cast<const f32x4*>(wr + 4);
-        f32x4 ha[4], hb[4];
+    // ---- phase B: table; four channels of a group in flight (first candidates), further candidates afterwards
+    for (int n0 = g; n0 < ((abl & 64) ? 0 : 1024); n0 += 64) {
+        f32x4 w0[4], w1[4], ha[4], hb[4];
+        int cn[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (u < cn) {                                  // all loads first, then the arithmetic
-                const float* hr = h2 + (long)cand[n][u] * 128 + 8 * j;
-                ha[u] = *reinterpret_cast<const f32x4*>(hr);
-                hb[u] = *reinterpret_cast<const f32x4*>(hr + 4);
+        for (int u = 0; u < 4; ++u) {
+            const int n = n0 + 16 * u;
+            cn[u] = cand_n[n];
+            const float* wr = w3 + n * 128 + 8 * j;
+            w0[u] = *reinterpret_cast<const f32x4*>(wr);
+            w1[u] = *reinterpret_cast<const f32x4*>(wr + 4);
+            const float* hr = h2 + (long)(cn[u] ? cand[n][0] : 0) * 128 + 8 * j;
+            ha[u] = *reinterpret_cast<const f32x4*>(hr);
+            hb[u] = *reinterpret_cast<const f32x4*>(hr + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int n = n0 + 16 * u;
+            if (cn[u] == 0) continue;
+            float best = exact_dot_regs(w0[u], w1[u], ha[u], hb[u]);
+            if (cn[u] > 1) {
+                f32x4 xa[3], xb[3];
+#pragma unroll
+                for (int k = 1; k < 4; ++k)
+                    if (k < cn[u]) {
+                        const float* hr = h2 + (long)cand[n][k] * 128 + 8 * j;
+                        xa[k - 1] = *reinterpret_cast<const f32x4*>(hr);
+                        xb[k - 1] = *reinterpret_cast<const f32x4*>(hr + 4);
+                    }
+#pragma unroll
+                for (int k = 1; k < 4; ++k)
+                    if (k < cn[u]) best = fmaxf(best, exact_dot_regs(w0[u], w1[u], xa[k - 1], xb[k - 1]));
             }
-        float best = exact_dot_regs(w0, w1, ha[0], hb[0]);
-#pragma unroll
-        for (int u = 1; u < 4; ++u)
-            if (u < cn) best = fmaxf(best, exact_dot_regs(w0, w1, ha[u], hb[u]));
-        if (j == 0) atomicMax(&best_k[n], f2key(best));
+            if (j == 0) atomicMax(&best_k[n], f2key(best));
+        }
     }
     // ---- phase B: overflow list
     const int npairs = min(pair_count, pair_cap);
@@ -603,17 +648,17 @@ __global__ __launch_bounds__(256) void pn_exact_kernel(const f32x4* __restrict__
         if (j == 0) atomicMax(&best_k[n], f2key(v));
     }
     // ---- phase C: flagged waves, one wave of the workgroup per entry, its four groups take 16 points each
-    const int nfb = min(fb_count, fb_cap);
+    const int nfb = (abl & 32) ? 0 : min(fb_count, fb_cap);
     for (int i = tid >> 6; i < nfb; i += 4) {
         const int code = fb_list[i];
         const int n = code & 1023, t = (code >> 10) & 1023, w = (code >> 20) & 3;
         const float* wr = w3 + n * 128 + 8 * j;
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr), w1 = *reinterpret_cast<const f32x4*>(wr + 4);
         float best = NEG_BIG;
-        for (int q0 = 0; q0 < 16; q0 += 4) {
-            f32x4 ha[4], hb[4];
+        for (int q0 = 0; q0 < 16; q0 += 8) {
+            f32x4 ha[8], hb[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 int p = point_of_slot(t, 64 * w + 16 * (g & 3) + q0 + u, tiles);
                 if (p >= N) p = N - 1;
                 const float* hr = h2 + (long)p * 128 + 8 * j;
@@ -621,7 +666,7 @@ __global__ __launch_bounds__(256) void pn_exact_kernel(const f32x4* __restrict__
                 hb[u] = *reinterpret_cast<const f32x4*>(hr + 4);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) best = fmaxf(best, exact_dot_regs(w0, w1, ha[u], hb[u]));
+            for (int u = 0; u < 8; ++u) best = fmaxf(best, exact_dot_regs(w0, w1, ha[u], hb[u]));
         }
         if (j == 0) atomicMax(&best_k[n], f2key(best));
     }
@@ -813,7 +858,7 @@ int dvq_launch_pn_trunk_filter(const float* pc, int C, int N, int Npad, long B, 
         DVQ_LAUNCH(pn_exact_kernel, dim3((unsigned)B), dim3(256), 0, st, (const f32x4*)part, tiles, h2buf, N, Npad, w3, b3,
                    reinterpret_cast<const float*>((const char*)w3f + 1024 * 256 + 4096),
                    reinterpret_cast<const float*>((const char*)w3f + 1024 * 256 + 8192), tstat, relu, exhaustive, pair_cap, fb_cap,
-                   feat, ld_feat, stats);
+                   feat, ld_feat, stats, abl);
     }
     DVQ_CHECK_LAUNCH("pn_exact");
     if (stats) {                                          // diagnostics (DVQ_PN_STATS=1): synchronises
