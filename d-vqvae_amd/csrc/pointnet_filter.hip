@@ -27,6 +27,7 @@ namespace {
 typedef __bf16 qbf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 qf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 qf16x2 __attribute__((ext_vector_type(2)));
+typedef float qf32x2 __attribute__((ext_vector_type(2)));
 
 // beyond the two measured rounding residuals: 2^-15 from the 8 id bits, 2^-19 from the matrix core's fp32 accumulation of
 // 128 exact products, the product of the two residuals (2^-22); rounded up
@@ -50,6 +51,14 @@ constexpr int F_OFF_WS = F_OFF_CS + 512;                  // [3][4] per-wave |h|
 constexpr int F_LDS = F_OFF_WS + 64;                      // 63 872 B -> 2 workgroups per CU
 static_assert(F_OFF_W1 >= 2 * F_STAGE2, "the conv3 stages and the triple buffer cover the W2 region");
 
+// h - x with h the low (HI = 0) or high (HI = 1) fp16 half of hp: one v_fma_mix_f32, exact
+template <int HI>
+__device__ __forceinline__ float mix_diff(unsigned hp, float x) {
+    float d;
+    if (HI) asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hp), "v"(x));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hp), "v"(x));
+    return d;
+}
 __device__ __forceinline__ float max_nc(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, 3.0e38f); }
 __device__ __forceinline__ float min_nc(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, NEG_BIG); }
 
@@ -295,19 +304,24 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
         float sq = 0.f;
+        const float s_pb = pidx[pb] < N ? s_w : 0.f;
 #pragma unroll
         for (int st = 0; st < 8; ++st) {
-            qf16x8 f;
+            // a padding slot plays the sample's centre (score w.c = mean of four real scores <= the maximum), not a
+            // copy of the last point: copies would tie with each other and flag their waves
+            unsigned pk[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                // a padding slot plays the sample's centre (score w.c = mean of four real scores <= the maximum), not a
-                // copy of the last point: copies would tie with each other and flag their waves
-                const float v = pidx[pb] < N ? hv[pb][8 * st + j] * s_w : 0.f;
-                f[j] = (_Float16)v;
-                const float res = v - (float)f[j];
-                sq = fmaf(res, res, sq);
+            for (int j2 = 0; j2 < 4; ++j2) {
+                qf32x2 v;
+                v[0] = hv[pb][8 * st + 2 * j2] * s_pb;
+                v[1] = hv[pb][8 * st + 2 * j2 + 1] * s_pb;
+                const qf16x2 hpair = __builtin_convertvector(v, qf16x2);      // v_cvt_pk_f16_f32, round to nearest even
+                pk[j2] = __builtin_bit_cast(unsigned, hpair);
+                const float r0 = mix_diff<0>(pk[j2], v[0]), r1 = mix_diff<1>(pk[j2], v[1]);
+                sq = fmaf(r0, r0, sq);
+                sq = fmaf(r1, r1, sq);
             }
-            a3[pb][st] = f;
+            a3[pb][st] = __builtin_bit_cast(qf16x8, uint4{pk[0], pk[1], pk[2], pk[3]});
         }
         sq += __shfl_xor(sq, 32);
         rn2 = fmaxf(rn2, sq);
