@@ -21,6 +21,7 @@
 // Matrix-core cost per (32 points x 32 channels x K=128): 8 x v_mfma_f32_32x32x16_f16 instead of 48 bf16 MFMAs; the
 // kernel is co-bound by the vector port (4 instructions per score: id, max, two med3) -- see DESIGN.md 3.3.
 #include "dvq_internal.h"
+#include <vector>
 
 namespace {
 
@@ -181,6 +182,8 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     const long b = blockIdx.x / tiles;
     const int tile = blockIdx.x % tiles;
 
+    const unsigned long long t_start = (abl & 4096) ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long t_a = 0, t_b = 0, t_c = 0;
     w2_issue(W2p, 0, fl, wave, lane);
     w2_issue(W2p, 64, fl + F_STAGE2, wave, lane);
     w1s[tid] = W1[tid];
@@ -209,6 +212,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         xin[pb][0] = x0; xin[pb][1] = x1; xin[pb][2] = x2; xin[pb][3] = x3;
     }
     __syncthreads();                                      // W1/b1/b2 visible, W2 planes landed
+    if (abl & 4096) t_a = __builtin_amdgcn_s_memtime();
 
     // ---- conv1 + conv2 (six-product split-bf16), h2 = relu(conv2 + b2) kept in fp32: hv[pb][16 t4 + e]
     float hv[2][64];
@@ -264,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         sq += __shfl_xor(sq, 32);                         // the two lane halves hold the two halves of a point's channels
         nrm2 = fmaxf(nrm2, sq);
     }
+    if (abl & 4096) t_b = __builtin_amdgcn_s_memtime();
     // ---- centre the rows on the sample's centre (pn_center_kernel)
     float amax = 0.f, dn2 = 0.f;
 #pragma unroll
@@ -336,6 +341,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         atomicMax(tstat + 4 * blockIdx.x + 2, __float_as_uint(rdm));
     }
     __syncthreads();                                      // everybody is done with W2 in the stages; scs visible
+    if (abl & 4096) t_c = __builtin_amdgcn_s_memtime();
 
     // ---- conv3, filtered: 16 chunks of 64 channels, one fp16 product, top three scores per channel
     const char* w3h = w3f;
@@ -455,6 +461,11 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     if (!(abl & 256)) {
         publish(8 + 2 * wave);
         publish(8 + 2 * wave + 1);
+    }
+    if ((abl & 4096) && tid == 0) {                        // diagnostics: phase durations in units of 64 ticks, 8 bits each
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        auto q = [](unsigned long long d) { d >>= 6; return (unsigned)(d > 255 ? 255 : d); };
+        tstat[4 * blockIdx.x + 3] = q(t_a - t_start) | (q(t_b - t_a) << 8) | (q(t_c - t_b) << 16) | (q((t_end - t_c) >> 3) << 24);
     }
 }
 
@@ -875,6 +886,18 @@ int dvq_launch_pn_trunk_filter(const float* pc, int C, int N, int Npad, long B, 
                    feat, ld_feat, stats, abl);
     }
     DVQ_CHECK_LAUNCH("pn_exact");
+    if (stats && (abl & 4096)) {
+        std::vector<unsigned> ts((size_t)grid * 4);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(ts.data(), tstat, ts.size() * 4, hipMemcpyDeviceToHost);
+        double a = 0, b2_ = 0, c = 0, d = 0;
+        for (long i = 0; i < grid; ++i) {
+            const unsigned v = ts[4 * i + 3];
+            a += v & 255; b2_ += (v >> 8) & 255; c += (v >> 16) & 255; d += (v >> 24) & 255;
+        }
+        fprintf(stderr, "[dvq pn] mean phase ticks per workgroup (s_memtime, 100 MHz?): start->loaded %.0f, conv1+conv2 %.0f, centre/convert %.0f, conv3 loop %.0f\n",
+                a / grid * 64, b2_ / grid * 64, c / grid * 64, d / grid * 512);
+    }
     if (stats) {                                          // diagnostics (DVQ_PN_STATS=1): synchronises
         unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         (void)hipStreamSynchronize(st);
