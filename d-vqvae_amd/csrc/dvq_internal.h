@@ -11,6 +11,16 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Workgroup barrier that publishes LDS-DMA data (global_load_lds): the wave's own pieces must have landed BEFORE it arrives.
+// __syncthreads() alone only guarantees lgkmcnt(0): the compiler does not treat the DMA's LDS write as a store to release
+// (seen in the ISA of gemm_bf16x3_wide_kernel: s_barrier first, the vmcnt wait after it).
+#ifdef __HIPCC__
+__device__ __forceinline__ void dvq_dma_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+#endif
+
 void dvq_set_error(const char* fmt, ...);
 
 #define DVQ_REQUIRE(cond, ...)                      \

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_dma_kernel(const GemmParam
         w_sw[i] = (wrow >> 2) & 3;
     }
     while (true) {
-        __syncthreads();                                   // the DMA of this tile has landed for every wave (vmcnt(0) + barrier);
+        dvq_dma_barrier();                                 // the DMA of this tile has landed for every wave (vmcnt(0) + barrier);
                                                            // everybody is done reading the other stage
         const bool more = cur.valid();
         if (more) {
@@ -494,6 +494,190 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
     return DVQ_OK;
 }
 
+// ================================================================================================================
+// Wide variant for N % 256 == 0 (the gated PixelCNN GEMMs: N = 512): tile 128 x 256, eight waves as 2 x 4 of 64 x 64, one
+// workgroup per CU.  The fp32 activation tile goes through registers and is split ONCE per element into its three bf16
+// planes before it reaches the LDS (44 vector instructions per thread and K-tile instead of 176 per wave in the 128 x 128
+// kernel, where every wave splits the fragments it reads); the weight planes arrive by LDS-DMA (6 pieces per wave and K-tile
+// for twice the MFMAs of ... no: the same 48 MFMAs per wave; the activation DMA pieces are gone).  Both operands sit in the
+// LDS as bf16 planes with 64-byte rows, chunk c of row r at c ^ ((r >> 2) & 3).
+constexpr int W_A_PL = 128 * 64;                           // one activation plane [128][32] bf16
+constexpr int W_W_PL = 256 * 64;                           // one weight plane [256][32] bf16
+constexpr int W_STAGE = 3 * W_A_PL + 3 * W_W_PL;           // 73 728 B
+constexpr size_t W_SMEM = 2 * W_STAGE;                     // 147 456 B: one workgroup per CU
+
+struct WideCursor {
+    int s, k_left;
+    const float* a_ptr;
+    const uint16_t* w_ptr[6];
+
+    __device__ __forceinline__ void open(const GemmParams& p, int src_i, long m0, int n0, int tid, int wave, int lane) {
+        s = src_i;
+        if (s >= p.nsrc) { k_left = 0; return; }
+        const GemmSrc& src = p.src[s];
+        k_left = src.K;
+        {
+            long m = m0 + (tid >> 2);
+            if (m >= p.M) m = p.M - 1;                     // clamped rows only feed outputs the epilogue masks
+            a_ptr = src.A + m * src.lda + 8 * (tid & 3);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {                      // 48 pieces of 16 rows x 64 B, six per wave
+            const int id = wave * 6 + i;
+            const int pl = id >> 4, rb = id & 15;
+            const int row = rb * 16 + (lane >> 2);
+            w_ptr[i] = src.Wp + pl * src.wp_plane + (long)(n0 + row) * src.ldw + 8 * ((lane & 3) ^ ((row >> 2) & 3));
+        }
+    }
+    __device__ __forceinline__ bool valid() const { return k_left > 0; }
+    struct ARegs { f32x4 lo, hi; };
+    __device__ __forceinline__ ARegs load_a() const {
+        ARegs r;
+        r.lo = *reinterpret_cast<const f32x4*>(a_ptr);
+        r.hi = *reinterpret_cast<const f32x4*>(a_ptr + 4);
+        return r;
+    }
+    __device__ __forceinline__ void issue_w(char* stage, int wave) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int id = wave * 6 + i;
+            const int pl = id >> 4, rb = id & 15;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[i],
+                                             (__attribute__((address_space(3))) void*)(stage + 3 * W_A_PL + pl * W_W_PL + rb * 1024), 16, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void advance(const GemmParams& p, long m0, int n0, int tid, int wave, int lane) {
+        a_ptr += BK;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w_ptr[i] += BK;
+        k_left -= BK;
+        if (k_left <= 0) open(p, s + 1, m0, n0, tid, wave, lane);
+    }
+};
+
+// split the thread's eight activation values and write the three 16-byte pieces
+__device__ __forceinline__ void wide_store_a(char* stage, int tid, const WideCursor::ARegs& a) {
+    bf16x8 pl[3];
+    split_frag(a.lo, a.hi, pl);
+    const int row = tid >> 2, q = tid & 3;
+    char* dst = stage + row * 64 + 16 * (q ^ ((row >> 2) & 3));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) *reinterpret_cast<bf16x8*>(dst + i * W_A_PL) = pl[i];
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_bf16x3_wide_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    const int tid = threadIdx.x;
+    const int tiles_n = p.N / 256;
+    const long tiles_m = (p.M + 127) / 128;
+    const long b = blockIdx.x;
+    const long j = b >> 3;
+    const long mt = (j / tiles_n) * 8 + (b & 7);
+    const int nt = (int)(j % tiles_n);
+    if (mt >= tiles_m) return;
+    const long m0 = mt * 128;
+    const int n0 = nt * 256;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 31, h = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
+
+    WideCursor cur;
+    cur.open(p, 0, m0, n0, tid, wave, lane);
+    WideCursor::ARegs areg = cur.load_a();
+    cur.issue_w(smem_c, wave);
+    cur.advance(p, m0, n0, tid, wave, lane);
+    wide_store_a(smem_c, tid, areg);
+    bool more = cur.valid();
+    if (more) areg = cur.load_a();                        // tile 1's activations: stored into the other stage during tile 0
+    int a_off[2], a_sw[2], w_off[2], w_sw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int arow = wm * 64 + i * 32 + r, wrow = wn * 64 + i * 32 + r;
+        a_off[i] = arow * 64;
+        a_sw[i] = (arow >> 2) & 3;
+        w_off[i] = 3 * W_A_PL + wrow * 64;
+        w_sw[i] = (wrow >> 2) & 3;
+    }
+    int stage = 0;
+    while (true) {
+        dvq_dma_barrier();                                 // this stage is complete (weight DMA landed, activation planes written);
+                                                           // everybody is done reading the other stage
+        const char* st = smem_c + stage * W_STAGE;
+        char* nx = smem_c + (stage ^ 1) * W_STAGE;
+        if (more) {
+            wide_store_a(nx, tid, areg);                   // loaded a K-tile ago; before the DMA issue: a wait for these loads
+            cur.issue_w(nx, wave);                         // after it would also wait for the DMA (vmcnt counts in order)
+            cur.advance(p, m0, n0, tid, wave, lane);
+            if (cur.valid()) areg = cur.load_a();
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 w[2][3], a[2][3];
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    w[jn][pl] = *reinterpret_cast<const bf16x8*>(st + w_off[jn] + pl * W_W_PL + 16 * ((2 * ks + h) ^ w_sw[jn]));
+                    a[jn][pl] = *reinterpret_cast<const bf16x8*>(st + a_off[jn] + pl * W_A_PL + 16 * ((2 * ks + h) ^ a_sw[jn]));
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) {
+                    f32x16 c = acc[i][jn];           // weights as operand A: lanes <-> rows, registers <-> columns (16-byte stores)
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[jn][0], a[i][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[jn][2], a[i][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[jn][1], a[i][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[jn][0], a[i][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[jn][1], a[i][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[jn][0], a[i][0], c, 0, 0, 0);
+                    acc[i][jn] = c;
+                }
+        }
+        if (!more) break;
+        more = cur.valid();
+        stage ^= 1;
+    }
+    gemm_epilogue_t_at<EPI>(p, acc, m0, n0, tid, wm, wn);
+}
+
+template <int EPI>
+int launch_wide(const GemmParams& p, hipStream_t stream) {
+    static DvqOncePerDevice attr_once;
+    {
+        const hipError_t e = attr_once.run([] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_wide_kernel<EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)W_SMEM);
+        });
+        if (e != hipSuccess) {
+            dvq_set_error("gemm_bf16x3: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return DVQ_ELAUNCH;
+        }
+    }
+    const long tiles_m = (p.M + 127) / 128;
+    const long tiles_n = p.N / 256;
+    const long grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
+    static const char* const names[] = {"gemm_bias", "gemm_resid", "gemm_gate"};
+    double ksum = 0;
+    for (int s = 0; s < p.nsrc; ++s) ksum += p.src[s].K;
+    {
+        DVQ_PROF(names[EPI], 2.0 * (double)p.M * p.N * ksum, ((double)p.M + p.N) * ksum * 4, stream);
+        DVQ_LAUNCH((gemm_bf16x3_wide_kernel<EPI>), dim3((unsigned)grid), dim3(512), W_SMEM, stream, p);
+    }
+    DVQ_CHECK_LAUNCH("gemm_bf16x3_wide");
+    return DVQ_OK;
+}
+
 __global__ void split_bf16x3_kernel(const float* __restrict__ w, long n, uint16_t* __restrict__ planes) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -547,6 +731,19 @@ int dvq_launch_gemm_bf16x3(const GemmParams& p, GemmEpilogue epi, hipStream_t st
         for (int s = 0; s < p.nsrc; ++s)
             aligned = aligned && ((reinterpret_cast<uintptr_t>(p.src[s].Wp) & 15) == 0) && (p.src[s].wp_plane % 8 == 0) &&
                       (p.src[s].ldw % 8 == 0);
+        // 128 x 256 tiles where they fill the chip (N = 256 leaves one tile column: the 128 x 128 kernel is faster there)
+        static const bool use_wide = !(getenv("DVQ_GEMM_WIDE") && getenv("DVQ_GEMM_WIDE")[0] == '0');
+        if (aligned && use_wide && p.N % 256 == 0 && p.N >= 512) {
+            bool a_ok = true;                      // 16-byte activation loads
+            for (int s = 0; s < p.nsrc; ++s)
+                a_ok = a_ok && ((reinterpret_cast<uintptr_t>(p.src[s].A) & 15) == 0) && (p.src[s].lda % 4 == 0);
+            if (a_ok) switch (epi) {
+                case EPI_BIAS: return launch_wide<EPI_BIAS>(p, stream);
+                case EPI_RESID: return launch_wide<EPI_RESID>(p, stream);
+                case EPI_GATE: return launch_wide<EPI_GATE>(p, stream);
+                default: break;
+            }
+        }
         if (aligned) {
             switch (epi) {
                 case EPI_BIAS: return launch_dma<EPI_BIAS>(p, stream);

@@ -135,9 +135,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 // 4g..4g+3 are FOUR CONSECUTIVE columns of one row: every store is a 16-byte store (the default layout needs 4x as many
 // 4-byte store instructions, and the store tail is issue-bound).  Store epilogues only (bias / residual / gate).
 template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_t_at(const GemmParams& p, f32x16 (&acc)[2][2], long m0, int n0, int tid, int wm, int wn);
+
+template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_t(const GemmParams& p, f32x16 (&acc)[2][2], long m0, int n0, int nt, int tid) {
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wave = tid >> 6;
+    gemm_epilogue_t_at<EPI>(p, acc, m0, n0, tid, wave >> 1, wave & 1);      // 128 x 128 tile, waves 2 x 2
+}
+
+// the same for any wave grid: the wave owns rows m0 + wm*64 .. +63 and columns n0 + wn*64 .. +63 (n0 a multiple of 128)
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_t_at(const GemmParams& p, f32x16 (&acc)[2][2], long m0, int n0, int tid, int wm, int wn) {
+    const int lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
     const bool vec_ok = (p.N % 4 == 0);
 #pragma unroll
@@ -176,7 +185,7 @@ __device__ __forceinline__ void gemm_epilogue_t(const GemmParams& p, f32x16 (&ac
                 const int nl = 8 * g + 4 * h;
                 const int na = n0 + wn * 64 + nl;        // gate-packed index of the tanh channels
                 const int nb = na + 32;                  // ... of their sigmoid partners
-                const int c = nt * 64 + wn * 32 + nl;    // natural output channels
+                const int c = (n0 >> 1) + wn * 32 + nl;  // natural output channels
                 f32x4 a = {acc[i][0][4 * g], acc[i][0][4 * g + 1], acc[i][0][4 * g + 2], acc[i][0][4 * g + 3]};
                 f32x4 gg = {acc[i][1][4 * g], acc[i][1][4 * g + 1], acc[i][1][4 * g + 2], acc[i][1][4 * g + 3]};
                 if (p.bias) {

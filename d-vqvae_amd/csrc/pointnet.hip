@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_kernel(const float* __restric
         const float n2 = fmaf(x2, t[8], fmaf(x1, t[5], x0 * t[2]));
         x0 = n0; x1 = n1; x2 = n2;
     }
-    __syncthreads();                                       // W1/b1/b2 visible, W2 planes landed
+    dvq_dma_barrier();                                     // W1/b1/b2 visible, W2 planes landed
     pbf16x8 h1f[4][3];                                     // B-operand fragments of conv2: k = 16 s + 8 h + j
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_kernel(const float* __restric
             for (int e = 0; e < 16; ++e) acc2[jn][e] = 0.f;
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
-            __syncthreads();                               // this half-chunk landed everywhere; the other stage is free
+            dvq_dma_barrier();                             // this half-chunk landed everywhere; the other stage is free
             const int nxt = 2 * c + kh + 1;
             if (nxt < 32) t_issue(W3p, 1024L * 128, 128, 64 * (nxt >> 1), 64 * (nxt & 1), tl + (stage ^ 1) * T_STAGE, wave, lane);
             const char* st = tl + stage * T_STAGE;

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         }
         xin[pb][0] = x0; xin[pb][1] = x1; xin[pb][2] = x2; xin[pb][3] = x3;
     }
-    __syncthreads();                                      // W1/b1/b2 visible, W2 planes landed
+    dvq_dma_barrier();                                    // W1/b1/b2 visible, W2 planes landed
     if (abl & 4096) t_a = __builtin_amdgcn_s_memtime();
 
     // ---- conv1 + conv2 (six-product split-bf16), h2 = relu(conv2 + b2) kept in fp32: hv[pb][16 t4 + e]
