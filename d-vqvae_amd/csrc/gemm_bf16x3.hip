@@ -565,7 +565,7 @@ __device__ __forceinline__ void wide_store_a(char* stage, int tid, const WideCur
     for (int i = 0; i < 3; ++i) *reinterpret_cast<bf16x8*>(dst + i * W_A_PL) = pl[i];
 }
 
-template <int EPI>
+template <int EPI, bool DEPHASE>
 __global__ __launch_bounds__(512, 1) void gemm_bf16x3_wide_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     const int tid = threadIdx.x;
@@ -614,14 +614,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_wide_kernel(const GemmPara
                                                            // everybody is done reading the other stage
         const char* st = smem_c + stage * W_STAGE;
         char* nx = smem_c + (stage ^ 1) * W_STAGE;
-        if (more) {
+        // The two waves of a SIMD (w and w + 4) are in lock step (one workgroup per CU, one barrier per K-tile): waves 0..3
+        // feed the next stage at the top of the tile, waves 4..7 between the two k-steps, so that one of the pair runs MFMAs
+        // while the other sits in the DMA issue (an LDS-DMA piece holds the issuing wave for ~150 cycles).
+        auto feed = [&]() {
             wide_store_a(nx, tid, areg);                   // loaded a K-tile ago; before the DMA issue: a wait for these loads
             cur.issue_w(nx, wave);                         // after it would also wait for the DMA (vmcnt counts in order)
             cur.advance(p, m0, n0, tid, wave, lane);
             if (cur.valid()) areg = cur.load_a();
-        }
+        };
+        if (more && (wave < 4 || !DEPHASE)) feed();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            if (DEPHASE && ks == 1 && more && wave >= 4) feed();
             bf16x8 w[2][3], a[2][3];
 #pragma unroll
             for (int jn = 0; jn < 2; ++jn)
@@ -656,8 +661,11 @@ int launch_wide(const GemmParams& p, hipStream_t stream) {
     static DvqOncePerDevice attr_once;
     {
         const hipError_t e = attr_once.run([] {
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_wide_kernel<EPI>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)W_SMEM);
+            const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_wide_kernel<EPI, false>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)W_SMEM);
+            const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_wide_kernel<EPI, true>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)W_SMEM);
+            return e0 != hipSuccess ? e0 : e1;
         });
         if (e != hipSuccess) {
             dvq_set_error("gemm_bf16x3: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -672,7 +680,9 @@ int launch_wide(const GemmParams& p, hipStream_t stream) {
     for (int s = 0; s < p.nsrc; ++s) ksum += p.src[s].K;
     {
         DVQ_PROF(names[EPI], 2.0 * (double)p.M * p.N * ksum, ((double)p.M + p.N) * ksum * 4, stream);
-        DVQ_LAUNCH((gemm_bf16x3_wide_kernel<EPI>), dim3((unsigned)grid), dim3(512), W_SMEM, stream, p);
+        static const bool dephase = !(getenv("DVQ_GEMM_DEPHASE") && getenv("DVQ_GEMM_DEPHASE")[0] == '0');
+        if (dephase) DVQ_LAUNCH((gemm_bf16x3_wide_kernel<EPI, true>), dim3((unsigned)grid), dim3(512), W_SMEM, stream, p);
+        else DVQ_LAUNCH((gemm_bf16x3_wide_kernel<EPI, false>), dim3((unsigned)grid), dim3(512), W_SMEM, stream, p);
     }
     DVQ_CHECK_LAUNCH("gemm_bf16x3_wide");
     return DVQ_OK;
