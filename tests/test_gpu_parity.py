@@ -770,6 +770,74 @@ def test_fp32_gemm_branch_matches_goldens(tmp_path):
     assert " passed" in r.stdout
 
 
+_GEMM_VARIANT_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[2]); sys.path.insert(0, sys.argv[2] + "/tests")
+import dvqvae_amd
+from dvqvae_amd import ops, packing
+from dvqvae_amd.network.pixelcnn.models import GatedPixelCNN
+from util import load_synth
+dev, out = "cuda:0", {}
+torch.manual_seed(0)
+for (M, N, K) in ((300, 512, 512), (4, 768, 1024), (16384, 1024, 512), (1000, 256, 96)):
+    x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * 0.05; b = torch.randn(N, device=dev)
+    out[f"lin{M}x{N}x{K}"] = ops.linear(x, w, b, relu=True, planes=packing.split_bf16x3(w)).cpu()
+net = GatedPixelCNN(512, 512, 15, 128); load_synth(net, 5); net = net.to(dev)
+g = torch.Generator().manual_seed(1)
+x = torch.randint(0, 512, (150, 3, 3), generator=g).to(dev); lab = torch.randint(0, 128, (150,), generator=g).to(dev)
+out["pixelcnn_logits"] = net(x, lab).cpu()
+torch.save(out, sys.argv[1])
+"""
+
+
+def test_gemm_tile_variants_agree_bitwise(tmp_path):
+    """The 128x256 eight-wave GEMM tile (default where N % 256 == 0, N >= 512) and the 128x128 tile (DVQ_GEMM_WIDE=0) use the
+    same accumulation order: bias/ReLU GEMMs and the full 15-layer PixelCNN forward (gate, residual, multi-tap sources, ragged
+    M) must agree bit for bit -- and repeat bit for bit (a missing wait before the K-loop barrier showed up as run-to-run noise)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for tag, wide in (("wide", "1"), ("narrow", "0"), ("wide2", "1")):
+        path = str(tmp_path / f"{tag}.pt")
+        r = subprocess.run([sys.executable, "-c", _GEMM_VARIANT_SCRIPT, path, root], env=dict(os.environ, DVQ_GEMM_WIDE=wide),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(torch.load(path))
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), f"{k}: wide tile != 128x128 tile"
+        assert torch.equal(outs[0][k], outs[2][k]), f"{k}: wide tile not repeatable"
+
+
+def test_pointnet_large_clouds_nonfinite_inputs_and_missing_filter_image():
+    """N > 16384 runs the six-product trunk (the filter's tile records are sized for 64 tiles); NaN / Inf coordinates (ReLU =
+    fmaxf(x, 0) squashes a NaN in conv1/conv2, as in every kernel of this path; Inf survives) neither crash nor leak into the
+    neighbouring samples, and the filtered result still equals the exhaustive one bit for bit; a weights struct without filter
+    images (raw ABI users) selects the six-product trunk."""
+    net, _ = _pointnet(4, SEED + 9)
+    big = gpu(synth.synthetic_clouds(1, 17000, seed=3, channels=4))
+    f_big, _, _ = net(big)
+    f_big6, _, _ = _with_env("DVQ_PN_FILTER", "0", lambda: net(big))
+    assert torch.equal(f_big, f_big6)
+    x = gpu(synth.synthetic_clouds(3, 500, seed=4, channels=4))
+    x[1, 0, 17] = float("nan")
+    x[2, 2, 400] = float("inf")
+    feat, _, _ = net(x)
+    ref, _, _ = net(x[:1].contiguous())
+    assert torch.equal(feat[0], ref[0]) and torch.isfinite(feat[0]).all(), "a finite sample next to non-finite ones must not change"
+    feat_all, _, _ = _with_env("DVQ_PN_EXHAUSTIVE", "1", lambda: net(x))
+    same = (feat == feat_all) | (torch.isnan(feat) & torch.isnan(feat_all))
+    assert bool(same.all()), "non-finite inputs: filtered != exhaustive"
+    packed = net.packed()
+    saved = (packed.cstruct.w3f, packed.cstruct.s_w3f)
+    try:
+        packed.cstruct.w3f, packed.cstruct.s_w3f = None, None
+        f_nofilter, _, _ = net(x[:1].contiguous())
+    finally:
+        packed.cstruct.w3f, packed.cstruct.s_w3f = saved
+    f6, _, _ = _with_env("DVQ_PN_FILTER", "0", lambda: net(x[:1].contiguous()))
+    assert torch.equal(f_nofilter, f6)
+
+
 @pytest.mark.parametrize("dataset", ["obman", "grab", "FHAB"])
 def test_other_entry_points_write_reference_json(tmp_path, dataset):
     """gen_diverse_grasp_{obman,grab,FHAB}.py end to end on two synthetic objects (the ho3d one is covered above): the shims'
