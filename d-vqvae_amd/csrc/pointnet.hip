@@ -73,6 +73,10 @@ PnScratch plan(int64_t B, int N, void* ws) {
                               (1024 + 512 + 256 + 16 + 1) * 4;
     const size_t budget = (size_t)6 << 30;
     long chunk = (long)(budget / per_sample);
+    if (const char* e = getenv("DVQ_PN_CHUNK")) {          // samples per launch (default: what 6 GB of scratch hold)
+        const long v = atol(e);
+        if (v > 0 && v < chunk) chunk = v;
+    }
     if (chunk < 1) chunk = 1;
     if (chunk > B) chunk = B;
     if (chunk < 1) chunk = 1;

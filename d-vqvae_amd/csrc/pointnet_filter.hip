@@ -30,9 +30,10 @@ typedef _Float16 qf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 qf16x2 __attribute__((ext_vector_type(2)));
 typedef float qf32x2 __attribute__((ext_vector_type(2)));
 
-// beyond the two measured rounding residuals: 2^-15 from the 8 id bits, 2^-19 from the matrix core's fp32 accumulation of
-// 128 exact products, the product of the two residuals (2^-22); rounded up
-constexpr float C_ID = 3.6e-5f;
+// beyond the two measured rounding residuals, relative to |w| max|d|: the 8 id bits 2^-15 (3.05e-5); the matrix core's fp32
+// accumulation of the 128 exact products -- at most 128 additions of 2^-23 each even if they truncated (1.53e-5; round to
+// nearest: half of that); the product of the two residuals (2^-22); rounded up
+constexpr float C_ID = 5.0e-5f;
 // |exact_dot(w, h) - w.h| <= DELTA |w| |h|: 8 chained FMAs + 4 butterfly adds = 12 roundings (7.2e-7), + the fp32 add of
 // the centre term
 constexpr float DELTA = 1.0e-6f;
