@@ -111,15 +111,19 @@ int dense(const float* x, long ldx, int K, const float* w, const uint16_t* wp, c
     return dvq_launch_gemm(p, EPI_BIAS, st);
 }
 
-bool filter_enabled() {
+// DVQ_PN_FILTER: 0 = six-product trunk everywhere, 2 = filtered trunk whatever the fill of its tiles (tests), default 1
+int filter_mode() {
     const char* e = getenv("DVQ_PN_FILTER");
-    return !(e && e[0] == '0');
+    return e && e[0] == '0' ? 0 : (e && e[0] == '2' ? 2 : 1);
 }
 
 int trunk(const float* pc, int C, int N, long Bc, const float* trans, const float* w1, const float* b1, const float* w2,
           const uint16_t* w2p, const float* b2, const float* w3, const uint16_t* w3p, const void* w3f, const float* b3, int relu3,
           const PnScratch& s, float* feat, long ld_feat, hipStream_t st) {
-    if (w2p && w3f && dvq_gemm_mode() == 1 && filter_enabled() && N <= 16384)     // filtered trunk (pointnet_filter.hip)
+    // filtered trunk (pointnet_filter.hip) when its 256-point tiles are at least 3/4 full: padding slots repeat real points, and
+    // many repeats mean many ties for the exact stage (N = 300 in two tiles: 4.6 ms against 3.6 ms for the six-product trunk)
+    const int fm = filter_mode();
+    if (w2p && w3f && dvq_gemm_mode() == 1 && fm && N <= 16384 && (fm == 2 || 4L * N >= 3L * ((N + 255) / 256) * 256))
         return dvq_launch_pn_trunk_filter(pc, C, N, s.Npad, Bc, trans, w1, b1, w2, w2p, b2, w3f, w3, b3, relu3, s.h2, s.part, s.tstat,
                                           s.cbuf, feat, ld_feat, getenv("DVQ_PN_STATS") ? s.stats : nullptr, st);
     if (w2p && w3p && dvq_gemm_mode() == 1) {       // fused trunk; w3p is the k-permuted plane image (see pn_trunk_kernel)

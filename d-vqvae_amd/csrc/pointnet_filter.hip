@@ -199,7 +199,8 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     for (int pb = 0; pb < 2; ++pb) {
         int p = point_of_slot(tile, wave * 64 + pb * 32 + r, tiles);
         pidx[pb] = p;
-        if (p >= N) p = N - 1;                            // padding slots load the last point (their conv3 rows are zeroed below)
+        if (p >= N) p %= N;                               // padding slots repeat real points cyclically (a max ignores repeats; a point
+                                                          // repeated once costs nothing: both copies carry ids that map back to it)
         const float* src = pc + b * (long)C * N + p;
         float x0 = src[0], x1 = src[N], x2 = src[2L * N];
         const float x3 = (C > 3) ? src[3L * N] : 0.f;
@@ -310,11 +311,9 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
         float sq = 0.f;
-        const float s_pb = pidx[pb] < N ? s_w : 0.f;
+        const float s_pb = s_w;
 #pragma unroll
         for (int st = 0; st < 8; ++st) {
-            // a padding slot plays the sample's centre (score w.c = mean of four real scores <= the maximum), not a
-            // copy of the last point: copies would tie with each other and flag their waves
             unsigned pk[4];
 #pragma unroll
             for (int j2 = 0; j2 < 4; ++j2) {
@@ -588,8 +587,11 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
             for (int k = 0; k < 3; ++k)
                 if (q[k] + et >= lb) {
                     int p = point_of_slot(t, slot_of_id(__float_as_uint(q[k]) & 255u), tiles);
-                    if (p >= N) p = N - 1;
+                    if (p >= N) p %= N;                      // a padding slot: the real point it repeats
                     if (abl & 16) p &= 63;
+                    bool seen = false;                       // a repeated point (padding slots) is evaluated once
+                    for (int c2 = 0; c2 < min(cands, 4); ++c2) seen = seen || cand[n][c2] == (unsigned short)p;
+                    if (seen) continue;
                     if (cands < 4) cand[n][cands] = (unsigned short)p;
                     else {
                         const int slot = atomicAdd(&pair_count, 1);
@@ -686,7 +688,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 int p = point_of_slot(t, 64 * w + 16 * (g & 3) + q0 + u, tiles);
-                if (p >= N) p = N - 1;
+                if (p >= N) p %= N;
                 const float* hr = h2 + (long)p * 128 + 8 * j;
                 ha[u] = *reinterpret_cast<const f32x4*>(hr);
                 hb[u] = *reinterpret_cast<const f32x4*>(hr + 4);

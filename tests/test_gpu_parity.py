@@ -215,8 +215,9 @@ def test_pointnet_filter_equals_exhaustive_exact_evaluation(C, N, B):
     path's tolerance of the six-product trunk kernel (DVQ_PN_FILTER=0)."""
     net, _ = _pointnet(C, SEED + 10 * C)
     x = gpu(synth.synthetic_clouds(B, N, seed=300 + N, channels=C))
-    feat, trans, _ = net(x)
-    feat_all, trans_all, _ = _with_env("DVQ_PN_EXHAUSTIVE", "1", lambda: net(x))
+    # DVQ_PN_FILTER=2: the filtered trunk also where the default prefers the six-product one (tiles less than 3/4 full)
+    feat, trans, _ = _with_env("DVQ_PN_FILTER", "2", lambda: net(x))
+    feat_all, trans_all, _ = _with_env("DVQ_PN_FILTER", "2", lambda: _with_env("DVQ_PN_EXHAUSTIVE", "1", lambda: net(x)))
     assert torch.equal(trans, trans_all), "STN trunk: filtered != exhaustive"
     assert torch.equal(feat, feat_all), "main trunk: filtered != exhaustive"
     feat6, trans6, _ = _with_env("DVQ_PN_FILTER", "0", lambda: net(x))
@@ -247,8 +248,8 @@ def test_pointnet_filter_ties_scales_and_degenerate_clouds():
     cases["outlier"] = out
     for name, x in cases.items():
         x = gpu(x.contiguous())
-        feat, trans, _ = net(x)
-        feat_all, trans_all, _ = _with_env("DVQ_PN_EXHAUSTIVE", "1", lambda: net(x))
+        feat, trans, _ = _with_env("DVQ_PN_FILTER", "2", lambda: net(x))
+        feat_all, trans_all, _ = _with_env("DVQ_PN_FILTER", "2", lambda: _with_env("DVQ_PN_EXHAUSTIVE", "1", lambda: net(x)))
         assert torch.isfinite(feat).all(), name
         assert torch.equal(trans, trans_all) and torch.equal(feat, feat_all), f"{name}: filtered != exhaustive"
         feat6, _, _ = _with_env("DVQ_PN_FILTER", "0", lambda: net(x))
