@@ -13,6 +13,9 @@
 // Activations are split on the fly while they are staged (global fp32 -> registers -> 3 LDS planes); weights come
 // pre-split from the packer when GemmSrc::Wp is set (3 bf16 planes), else they are split on the fly too.
 // The accumulation order is still independent of the M tiling (batched == loop, bitwise).
+// Three kernels share the arithmetic: gemm_bf16x3_kernel (register-staged, any alignment), gemm_bf16x3_dma_kernel (LDS-DMA of
+// the fp32 activation tile and the pre-split weight planes, 128 x 128) and gemm_bf16x3_wide_kernel (128 x 256, eight waves,
+// activations split once on their way into the LDS; the default where N % 256 == 0 and N >= 512).
 #include "dvq_internal.h"
 #include "gemm_common.h"
 #include <vector>
@@ -498,9 +501,10 @@ int launch_dma(const GemmParams& p, hipStream_t stream) {
 // Wide variant for N % 256 == 0 (the gated PixelCNN GEMMs: N = 512): tile 128 x 256, eight waves as 2 x 4 of 64 x 64, one
 // workgroup per CU.  The fp32 activation tile goes through registers and is split ONCE per element into its three bf16
 // planes before it reaches the LDS (44 vector instructions per thread and K-tile instead of 176 per wave in the 128 x 128
-// kernel, where every wave splits the fragments it reads); the weight planes arrive by LDS-DMA (6 pieces per wave and K-tile
-// for twice the MFMAs of ... no: the same 48 MFMAs per wave; the activation DMA pieces are gone).  Both operands sit in the
-// LDS as bf16 planes with 64-byte rows, chunk c of row r at c ^ ((r >> 2) & 3).
+// kernel, where every wave splits the fragments it reads); the weight planes arrive by LDS-DMA, 6 pieces per wave and K-tile
+// for the same 48 MFMAs per wave (10 in the 128 x 128 kernel: its 4 activation pieces are gone).  Both operands sit in the LDS
+// as bf16 planes with 64-byte rows, chunk c of row r at c ^ ((r >> 2) & 3).  Same accumulation order as the 128 x 128 kernel:
+// bit-identical results (tests/test_gpu_parity.py::test_gemm_tile_variants_agree_bitwise).
 constexpr int W_A_PL = 128 * 64;                           // one activation plane [128][32] bf16
 constexpr int W_W_PL = 256 * 64;                           // one weight plane [256][32] bf16
 constexpr int W_STAGE = 3 * W_A_PL + 3 * W_W_PL;           // 73 728 B
