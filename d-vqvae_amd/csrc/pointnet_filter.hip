@@ -731,45 +731,52 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
 
 // Centre of a sample: mean of the conv2 rows of the points 0, N/4, N/2, 3N/4, plain fp32 (any vector would do -- it shifts
 // every score of a channel by the same w.c -- but one close to the rows makes the fp16 residuals, hence the bounds, small).
+// One workgroup takes CENTER_SPB samples: W2 (32 KB) is staged in the LDS once (transposed, conflict-free) for all of them.
+constexpr int CENTER_SPB = 8;
 template <int C>
-__global__ __launch_bounds__(256) void pn_center_kernel(const float* __restrict__ pc, const float* __restrict__ trans, int N,
+__global__ __launch_bounds__(256) void pn_center_kernel(const float* __restrict__ pc, const float* __restrict__ trans, int N, long B,
                                                         const float* __restrict__ W1, const float* __restrict__ b1,
                                                         const float* __restrict__ W2, const float* __restrict__ b2,
                                                         float* __restrict__ cbuf) {
+    __shared__ float w2t[64][129];                         // w2t[k][ch] = W2[ch][k] (row stride 129: conflict-free both ways)
     __shared__ float h1c[4][64];
     __shared__ float h2c[4][128];
     const int tid = threadIdx.x, q = tid >> 6, k = tid & 63;
-    const long b = blockIdx.x;
-    {
-        const int p = (int)(((long)q * N) / 4);
-        const float* src = pc + b * (long)C * N + p;
-        float x0 = src[0], x1 = src[N], x2 = src[2L * N];
-        const float x3 = (C > 3) ? src[3L * N] : 0.f;
-        if (trans) {
-            const float* t = trans + b * 9;
-            const float n0 = fmaf(x2, t[6], fmaf(x1, t[3], x0 * t[0]));
-            const float n1 = fmaf(x2, t[7], fmaf(x1, t[4], x0 * t[1]));
-            const float n2 = fmaf(x2, t[8], fmaf(x1, t[5], x0 * t[2]));
-            x0 = n0; x1 = n1; x2 = n2;
+    for (int i = tid; i < 128 * 64; i += 256) w2t[i & 63][i >> 6] = W2[i];
+    for (int sb = 0; sb < CENTER_SPB; ++sb) {
+        const long b = (long)blockIdx.x * CENTER_SPB + sb;
+        if (b >= B) break;
+        {
+            const int p = (int)(((long)q * N) / 4);
+            const float* src = pc + b * (long)C * N + p;
+            float x0 = src[0], x1 = src[N], x2 = src[2L * N];
+            const float x3 = (C > 3) ? src[3L * N] : 0.f;
+            if (trans) {
+                const float* t = trans + b * 9;
+                const float n0 = fmaf(x2, t[6], fmaf(x1, t[3], x0 * t[0]));
+                const float n1 = fmaf(x2, t[7], fmaf(x1, t[4], x0 * t[1]));
+                const float n2 = fmaf(x2, t[8], fmaf(x1, t[5], x0 * t[2]));
+                x0 = n0; x1 = n1; x2 = n2;
+            }
+            const float* w = W1 + 4 * k;
+            float a = x0 * w[0];
+            a = fmaf(x1, w[1], a);
+            a = fmaf(x2, w[2], a);
+            a = fmaf(x3, w[3], a);
+            h1c[q][k] = fmaxf(a + b1[k], 0.f);
         }
-        const float* w = W1 + 4 * k;
-        float a = x0 * w[0];
-        a = fmaf(x1, w[1], a);
-        a = fmaf(x2, w[2], a);
-        a = fmaf(x3, w[3], a);
-        h1c[q][k] = fmaxf(a + b1[k], 0.f);
-    }
-    __syncthreads();
+        __syncthreads();                                   // h1c (and, the first time, w2t) complete
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int ch = k + 64 * half;
-        const float* w = W2 + ch * 64;
-        float a = 0.f;
-        for (int i = 0; i < 64; ++i) a = fmaf(w[i], h1c[q][i], a);
-        h2c[q][ch] = fmaxf(a + b2[ch], 0.f);
+        for (int half = 0; half < 2; ++half) {
+            const int ch = k + 64 * half;
+            float a = 0.f;
+            for (int i = 0; i < 64; ++i) a = fmaf(w2t[i][ch], h1c[q][i], a);
+            h2c[q][ch] = fmaxf(a + b2[ch], 0.f);
+        }
+        __syncthreads();
+        if (tid < 128) cbuf[b * 128 + tid] = 0.25f * ((h2c[0][tid] + h2c[1][tid]) + (h2c[2][tid] + h2c[3][tid]));
+        // the next sample's h1c writes come after this barrier pair: h2c reads above are done before its second barrier
     }
-    __syncthreads();
-    if (tid < 128) cbuf[b * 128 + tid] = 0.25f * ((h2c[0][tid] + h2c[1][tid]) + (h2c[2][tid] + h2c[3][tid]));
 }
 
 // One wave per conv3 output channel: fp16 image (k permuted to conv2's accumulator order, scaled by a power of two so that
@@ -853,8 +860,9 @@ int dvq_launch_pn_trunk_filter(const float* pc, int C, int N, int Npad, long B, 
     }
     {
         DVQ_PROF("pn_center", 2.0 * (double)B * 4 * (4.0 * 64 + 64.0 * 128), (double)B * (64 + 512), st);
-        if (C == 3) DVQ_LAUNCH(pn_center_kernel<3>, dim3((unsigned)B), dim3(256), 0, st, pc, trans, N, W1, b1, W2, b2, cbuf);
-        else DVQ_LAUNCH(pn_center_kernel<4>, dim3((unsigned)B), dim3(256), 0, st, pc, trans, N, W1, b1, W2, b2, cbuf);
+        const unsigned cgrid = (unsigned)((B + CENTER_SPB - 1) / CENTER_SPB);
+        if (C == 3) DVQ_LAUNCH(pn_center_kernel<3>, dim3(cgrid), dim3(256), 0, st, pc, trans, N, B, W1, b1, W2, b2, cbuf);
+        else DVQ_LAUNCH(pn_center_kernel<4>, dim3(cgrid), dim3(256), 0, st, pc, trans, N, B, W1, b1, W2, b2, cbuf);
     }
     DVQ_CHECK_LAUNCH("pn_center");
     const double pts = (double)B * tiles * 256;
