@@ -42,15 +42,15 @@ constexpr int MAX_TILES = 64;                             // filtered trunk: N <
 
 constexpr int F_STAGE2 = 3 * 64 * 128;                    // conv2: one half of W2's planes (3 x 64 rows x 128 B)
 constexpr int F_STAGE3 = 64 * 256;                        // conv3: 64 channels x 128 k fp16
-constexpr int F_OFF_TB = 2 * F_STAGE3;                    // conv3 phase: [8 chunks][4 waves][3][64] fp32 behind the two W3 stages
-constexpr int F_OFF_W1 = F_OFF_TB + 8 * 4 * 3 * 64 * 4;   // [64][4] fp32
+constexpr int F_OFF_TB = 2 * F_STAGE3;                    // conv3 phase: [8 chunks][4 waves][4][64] fp32 behind the two W3 stages
+constexpr int F_OFF_W1 = F_OFF_TB + 8 * 4 * 4 * 64 * 4;   // [64][4] fp32
 constexpr int F_OFF_B1 = F_OFF_W1 + 64 * 4 * 4;           // [64]
 constexpr int F_OFF_B2 = F_OFF_B1 + 64 * 4;               // [128]
 constexpr int F_OFF_SC = F_OFF_B2 + 128 * 4;              // [4] 1 / (wave scale)
 constexpr int F_OFF_TI = F_OFF_SC + 64;                   // [1024] 1 / (channel scale)
 constexpr int F_OFF_CS = F_OFF_TI + 4096;                 // [128] centre of the sample
 constexpr int F_OFF_WS = F_OFF_CS + 512;                  // [3][4] per-wave |h|max, |d|max, |rd|max
-constexpr int F_LDS = F_OFF_WS + 64;                      // 63 872 B -> 2 workgroups per CU
+constexpr int F_LDS = F_OFF_WS + 64;                      // 72 064 B -> 2 workgroups per CU
 static_assert(F_OFF_W1 >= 2 * F_STAGE2, "the conv3 stages and the triple buffer cover the W2 region");
 
 // h - x with h the low (HI = 0) or high (HI = 1) fp16 half of hp: one v_fma_mix_f32, exact
@@ -349,35 +349,43 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     w3_store(fl, wave, lane, wreg);
     const float* wnorm_g = reinterpret_cast<const float*>(w3f + 1024 * 256 + 4096);
     const float* rnorm_g = reinterpret_cast<const float*>(w3f + 1024 * 256 + 8192);
-    // per channel of chunk c the three largest id-carrying scores of the tile (real units) and, per wave, a flag "holds a
-    // point within 2 E of the tile's largest score that is not among the three".  Every wave publishes two chunks after
+    // per channel of chunk c the three largest id-carrying scores of the tile (real units) and, per lane half of every wave
+    // (32 points), a flag "holds a point within 2 E of the tile's largest score that is not among the three".  Every wave publishes two chunks after
     // chunk 7 and after chunk 15 (all four busy at the same time: no wave waits for a publisher at the chunk barriers).
     auto publish = [&](int c) {
-        const float* src = tb + (c & 7) * 768;
+        const float* src = tb + (c & 7) * 1024;
         const float ti = tis[64 * c + lane];
         const float pub_wn = wnorm_g[64 * c + lane], pub_rn = rnorm_g[64 * c + lane];
         const float hm = fmaxf(fmaxf(wst[0], wst[1]), fmaxf(wst[2], wst[3])) * 1.00001f;
         const float dmx = fmaxf(fmaxf(wst[4], wst[5]), fmaxf(wst[6], wst[7])) * 1.00001f;
         const float rdm = fmaxf(fmaxf(wst[8], wst[9]), fmaxf(wst[10], wst[11])) * 1.00001f;
         const float e2 = 2.0f * fmaf(pub_rn, dmx, fmaf(pub_wn, rdm, fmaf(C_ID * pub_wn, dmx, 2.0f * DELTA * pub_wn * hm)));
-        float v1[4], v2[4], v3[4];
+        float v1[4], v2[4], u0[4], u1[4];
         float c1 = NEG_BIG, c2 = NEG_BIG, c3 = NEG_BIG;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const float q0 = src[w * 192 + lane], q1 = src[w * 192 + 64 + lane], q2 = src[w * 192 + 128 + lane];
+            const float q0 = src[w * 256 + lane], q1 = src[w * 256 + 64 + lane];
             const float f = scs[w] * ti;
+            u0[w] = src[w * 256 + 128 + lane] * f;
+            u1[w] = src[w * 256 + 192 + lane] * f;
             v1[w] = __uint_as_float((__float_as_uint(q0 * f) & ~0xC0u) | (unsigned)(w << 6));
             v2[w] = __uint_as_float((__float_as_uint(q1 * f) & ~0xC0u) | (unsigned)(w << 6));
-            v3[w] = q2 * f;
             c3 = __builtin_amdgcn_fmed3f(c2, c3, v1[w]); c2 = __builtin_amdgcn_fmed3f(c1, c2, v1[w]); c1 = max_nc(c1, v1[w]);
             c3 = __builtin_amdgcn_fmed3f(c2, c3, v2[w]); c2 = __builtin_amdgcn_fmed3f(c1, c2, v2[w]); c1 = max_nc(c1, v2[w]);
         }
         const float thr = c1 - e2;                         // NaN -> no flag here; pn_exact_kernel sees the non-finite bound
-        unsigned flags = 0;
+        unsigned flags = 0;                                // bit 2 w + h: lane half h of wave w holds a point in range that is not kept
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const bool f = (v3[w] >= thr) || (v2[w] >= thr && v2[w] < c3) || (v1[w] >= thr && v1[w] < c3);
-            flags |= f ? (1u << w) : 0u;
+            flags |= (u0[w] >= thr) ? (1u << (2 * w)) : 0u;
+            flags |= (u1[w] >= thr) ? (2u << (2 * w)) : 0u;
+        }
+        if (__builtin_amdgcn_ballot_w64(c3 >= thr) != 0) {  // three kept scores in range somewhere in the wave: a fourth id-carrying
+#pragma unroll                                               // one may be in range and not kept -- its half is flagged too
+            for (int w = 0; w < 4; ++w) {
+                if (v1[w] >= thr && v1[w] < c3) flags |= 1u << (2 * w + ((__float_as_uint(v1[w]) >> 5) & 1u));
+                if (v2[w] >= thr && v2[w] < c3) flags |= 1u << (2 * w + ((__float_as_uint(v2[w]) >> 5) & 1u));
+            }
         }
         part[((long)blockIdx.x) * 1024 + 64 * c + lane] = f32x4{c1, c2, c3, __uint_as_float(flags)};
     };
@@ -413,10 +421,16 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         const float o1 = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(m1), __float_as_uint(m1), false, false)[1]);
         const float o2 = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(m2), __float_as_uint(m2), false, false)[1]);
         const float o3 = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(m3), __float_as_uint(m3), false, false)[1]);
-        merge3(m1, m2, m3, o1, o2, o3);
+        // lanes 0..31: (m1, m2, m3) = half 0, (o1, o2, o3) = half 1.  The wave's two largest keep their ids; u0 / u1 = the
+        // largest score of half 0 / half 1 that is NOT one of the two (pn_exact_kernel evaluates a half whose u is in range)
+        const float c1 = max_nc(m1, o1);
+        const float c2 = max_nc(min_nc(m1, o1), max_nc(m2, o2));
+        const bool a2top = m2 > o1, b2top = o2 > m1;       // both of the two come from half 0 / from half 1
+        const float u0 = a2top ? m3 : (b2top ? m1 : m2);
+        const float u1 = b2top ? o3 : (a2top ? o1 : o2);
         if (h == 0) {
-            float* dst = tb + (c & 7) * 768 + wave * 192 + 32 * jn + r;
-            dst[0] = m1; dst[64] = m2; dst[128] = m3;
+            float* dst = tb + (c & 7) * 1024 + wave * 256 + 32 * jn + r;
+            dst[0] = c1; dst[64] = c2; dst[128] = u0; dst[192] = u1;
         }
     };
     int stage = 0;
@@ -509,7 +523,7 @@ __device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k &
 //           becomes a candidate point of the channel (table of 4 per channel, the rest in a list); flagged waves of tiles in
 //           contention become (channel, tile, wave) entries;
 //   phase B (one group per channel): the weight row once, its candidates' rows together, exact_dot, maximum;
-//   phase C (one wave per entry, no barrier): the 64 points of a flagged wave; then, whole workgroup per channel, every
+//   phase C (one wave per entry, no barrier): the 32 points of a flagged lane half of a wave; then, whole workgroup per channel, every
 //           point for the channels on the "everything" list (DVQ_PN_EXHAUSTIVE / non-finite inputs).
 // stats (optional): channels with one candidate, with another count, wave entries, candidates.
 constexpr int PAIR_CAP = 1024;
@@ -582,7 +596,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
         auto consider = [&](int t, const f32x4& q) {
             const float et = bound(t);
             if (!(q[0] + et >= lb)) return;                 // the tile's largest score is out of range: so is the rest of it
-            unsigned flags = __float_as_uint(q[3]) & 15u;
+            unsigned flags = __float_as_uint(q[3]) & 255u;
 #pragma unroll
             for (int k = 0; k < 3; ++k)
                 if (q[k] + et >= lb) {
@@ -596,15 +610,15 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
                     else {
                         const int slot = atomicAdd(&pair_count, 1);
                         if (slot < pair_cap) pair_list[slot] = n | (p << 10);
-                        else flags |= 1u << ((__float_as_uint(q[k]) >> 6) & 3u);   // list full (never seen): evaluate its wave instead
+                        else flags |= 1u << ((__float_as_uint(q[k]) >> 5) & 7u);   // list full (never seen): evaluate its 32-point half instead
                     }
                     ++cands;
                 }
             while (flags) {
-                const int w = __ffs(flags) - 1;
+                const int wh = __ffs(flags) - 1;             // 2 * wave + lane half
                 flags &= flags - 1;
                 const int slot = atomicAdd(&fb_count, 1);
-                if (slot < fb_cap) fb_list[slot] = n | (t << 10) | (w << 20);
+                if (slot < fb_cap) fb_list[slot] = n | (t << 10) | (wh << 20);
                 else if (!whole) {                           // list full (never seen): the channel goes on the "everything" list
                     whole = true;
                     all_list[atomicAdd(&all_count, 1)] = (short)n;
@@ -679,15 +693,16 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
     const int nfb = (abl & 32) ? 0 : min(fb_count, fb_cap);
     for (int i = tid >> 6; i < nfb; i += 4) {
         const int code = fb_list[i];
-        const int n = code & 1023, t = (code >> 10) & 1023, w = (code >> 20) & 3;
+        const int n = code & 1023, t = (code >> 10) & 1023, w = (code >> 21) & 3, hh = (code >> 20) & 1;
         const float* wr = w3 + n * 128 + 8 * j;
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr), w1 = *reinterpret_cast<const f32x4*>(wr + 4);
         float best = NEG_BIG;
-        for (int q0 = 0; q0 < 16; q0 += 8) {
+        {
             f32x4 ha[8], hb[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                int p = point_of_slot(t, 64 * w + 16 * (g & 3) + q0 + u, tiles);
+            for (int u = 0; u < 8; ++u) {                   // this group's 8 of the half's 32 points (both point blocks)
+                const int i = 8 * (g & 3) + u, e = i & 15;
+                int p = point_of_slot(t, 64 * w + 32 * (i >> 4) + 8 * (e >> 2) + 4 * hh + (e & 3), tiles);
                 if (p >= N) p %= N;
                 const float* hr = h2 + (long)p * 128 + 8 * j;
                 ha[u] = *reinterpret_cast<const f32x4*>(hr);
