@@ -215,10 +215,16 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     }
     dvq_dma_barrier();                                    // W1/b1/b2 visible, W2 planes landed
     if (abl & 4096) t_a = __builtin_amdgcn_s_memtime();
+    float cnorm;                                          // |c| (every wave for itself: no ordering between the waves needed)
+    {
+        float cq = fmaf(cs[lane], cs[lane], cs[64 + lane] * cs[64 + lane]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) cq += __shfl_xor(cq, o);
+        cnorm = sqrtf(cq) * 1.0001f;
+    }
 
     // ---- conv1 + conv2 (six-product split-bf16), h2 = relu(conv2 + b2) kept in fp32: hv[pb][16 t4 + e]
     float hv[2][64];
-    float nrm2 = 0.f;
 #pragma unroll
     for (int pb = 0; pb < 2; ++pb) {
         qbf16x8 h1f[4][3];
@@ -237,7 +243,6 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
             }
             q_split8(v, h1f[s]);
         }
-        float sq = 0.f;
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
             const char* st = fl + (t4 >> 1) * F_STAGE2;
@@ -255,9 +260,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int ch = 32 * t4 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const float v = fmaxf(acc[e] + b2s[ch], 0.f);
-                hv[pb][16 * t4 + e] = v;
-                sq = fmaf(v, v, sq);
+                hv[pb][16 * t4 + e] = fmaxf(acc[e] + b2s[ch], 0.f);
             }
             if (pidx[pb] < N && !(abl & 1)) {             // natural channel order: 4 consecutive channels per 16-byte store
                 float* dst = h2buf + ((b * Npad + pidx[pb]) * 128 + 32 * t4 + 4 * h);
@@ -267,12 +270,10 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
                         f32x4{hv[pb][16 * t4 + 4 * g], hv[pb][16 * t4 + 4 * g + 1], hv[pb][16 * t4 + 4 * g + 2], hv[pb][16 * t4 + 4 * g + 3]};
             }
         }
-        sq += __shfl_xor(sq, 32);                         // the two lane halves hold the two halves of a point's channels
-        nrm2 = fmaxf(nrm2, sq);
     }
     if (abl & 4096) t_b = __builtin_amdgcn_s_memtime();
     // ---- centre the rows on the sample's centre (pn_center_kernel)
-    float amax = 0.f, dn2 = 0.f;
+    float dn2 = 0.f;
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
@@ -288,20 +289,16 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     for (int pb = 0; pb < 2; ++pb) {
         float sq = 0.f;
 #pragma unroll
-        for (int i = 0; i < 64; ++i) {
-            amax = fmaxf(amax, fabsf(hv[pb][i]));
-            sq = fmaf(hv[pb][i], hv[pb][i], sq);
-        }
-        sq += __shfl_xor(sq, 32);
+        for (int i = 0; i < 64; ++i) sq = fmaf(hv[pb][i], hv[pb][i], sq);
+        sq += __shfl_xor(sq, 32);                         // the two lane halves hold the two halves of a point's channels
         dn2 = fmaxf(dn2, sq);
     }
-    amax = wave_max(amax);
-    nrm2 = wave_max(nrm2);
     dn2 = wave_max(dn2);
-    // per-wave power-of-two scale: amax * s in [2^14, 2^15)
+    // per-wave power-of-two scale: (largest row norm) * s in [2^14, 2^15) -- every element is at most its row's norm
     float s_w = 1.f;
+    const float dnorm = sqrtf(dn2) * 1.0001f;
     {
-        const int ex = (int)((__float_as_uint(amax) >> 23) & 255u);              // amax in [2^(ex-127), 2^(ex-126))
+        const int ex = (int)((__float_as_uint(dnorm) >> 23) & 255u);             // dnorm in [2^(ex-127), 2^(ex-126))
         if (ex > 20 && ex < 235) s_w = __uint_as_float((unsigned)(127 + 15 - (ex - 126)) << 23);
     }
     // conv3's A operand, one fp16 plane: step = 2 t4 + q, k order inside a step as conv2's accumulator delivers it;
@@ -333,7 +330,8 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     }
     rn2 = wave_max(rn2);
     if (lane == 0) {              // per-tile maxima; non-negative floats (and NaN, above all of them) order as integers
-        const float hm = sqrtf(nrm2), dmx = sqrtf(dn2), rdm = sqrtf(rn2) / s_w;
+        const float dmx = sqrtf(dn2), rdm = sqrtf(rn2) / s_w;
+        const float hm = (dmx + cnorm) * 1.0001f;          // |h_p| <= |h_p - c| + |c|
         scs[wave] = 1.0f / s_w;
         wst[wave] = hm; wst[4 + wave] = dmx; wst[8 + wave] = rdm;
         atomicMax(tstat + 4 * blockIdx.x + 0, __float_as_uint(hm));
