@@ -11,6 +11,10 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdvq_hip.so")
+if os.environ.get("DVQ_DIAG_LIB") == "1":          # tools/ only: the diagnostics build (`make -C csrc diag`), never the product
+    LIB_PATH = os.path.join(_HERE, "libdvq_hip_diag.so")
+    print("[dvq] DVQ_DIAG_LIB=1: loading the DIAGNOSTICS build; results are invalid when a DVQ_*_ABL variable is set",
+          file=__import__("sys").stderr)
 CSRC = os.path.join(_HERE, "csrc")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "dvq.h")
 
@@ -64,6 +68,7 @@ SIGNATURES = {
     "dvq_abi_version": (C.c_int, []),
     "dvq_last_error": (C.c_char_p, []),
     "dvq_device_count": (C.c_int, []),
+    "dvq_reload_env": (C.c_int, []),
     "dvq_linear": (C.c_int, [C.POINTER(GemmSrc), C.c_int, C.c_int64, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int64, c_stream]),
     "dvq_split_bf16x3": (C.c_int, [c_f32p, C.c_int64, C.c_void_p, c_stream]),
     "dvq_vq_argmin_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),

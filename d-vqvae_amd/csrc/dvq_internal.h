@@ -8,6 +8,18 @@
 #include <mutex>
 #include "../../include/dvq.h"
 
+// Diagnostics build (make EXTRA=-DDVQ_DIAG): timing-only ablation variants (DVQ_VQ_ABL, DVQ_PN_ABL, DVQ_GEMM_ABL: results
+// INVALID), phase stamps (DVQ_VQ_DBG, DVQ_GEMM_CLK) and the DVQ_GEMM_NODMA switch exist only there.  The shipped library
+// never reads those variables: a stray one in the environment cannot change a result.
+#ifdef DVQ_DIAG
+#define DVQ_DIAG_ON 1
+#ifndef DVQ_GEMM_DIAG
+#define DVQ_GEMM_DIAG
+#endif
+#else
+#define DVQ_DIAG_ON 0
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -151,6 +163,21 @@ int dvq_launch_gemm(const GemmParams& p, GemmEpilogue epi, hipStream_t stream);
 int dvq_launch_gemm_bf16x3(const GemmParams& p, GemmEpilogue epi, hipStream_t stream);
 // 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split-bf16 (default); env DVQ_GEMM=fp32|bf16x3
 int dvq_gemm_mode();
+
+// Behaviour knobs read from the environment ONCE (first use) -- DVQ_GEMM_WIDE, DVQ_GEMM_DEPHASE, DVQ_PN_FILTER, DVQ_PN_EXHAUSTIVE,
+// DVQ_PN_CAPS, DVQ_PN_CHUNK, DVQ_PN_STATS, DVQ_PIXELCNN_CHUNK -- none of them changes a result (tile shapes, chunk sizes, the
+// exhaustive PointNet evaluation the filter is tested against).  dvq_reload_env() re-reads them (tests flip them in-process).
+struct DvqKnobs {
+    int gemm_wide;        // 0: 128 x 128 kernels only
+    int gemm_dephase;
+    int pn_filter;        // 0 six-product trunk, 1 default, 2 filtered trunk whatever the tile fill
+    int pn_exhaustive;    // 1: exact stage evaluates every point (what the filter must reproduce bit for bit)
+    int pn_caps[2];       // candidate-list capacities (tests shrink them to reach the overflow paths); <= 0: default
+    long pn_chunk;        // samples per PointNet launch (<= 0: what 6 GB of scratch hold)
+    int pn_stats;
+    long pixelcnn_chunk;  // <= 0: default
+};
+const DvqKnobs& dvq_knobs();
 
 // simple helpers implemented in misc.hip
 int dvq_launch_gather_rows(const float* table, const int64_t* idx, long idx_stride, long M, int K, int D,

@@ -684,8 +684,7 @@ int launch_wide(const GemmParams& p, hipStream_t stream) {
     for (int s = 0; s < p.nsrc; ++s) ksum += p.src[s].K;
     {
         DVQ_PROF(names[EPI], 2.0 * (double)p.M * p.N * ksum, ((double)p.M + p.N) * ksum * 4, stream);
-        static const bool dephase = !(getenv("DVQ_GEMM_DEPHASE") && getenv("DVQ_GEMM_DEPHASE")[0] == '0');
-        if (dephase) DVQ_LAUNCH((gemm_bf16x3_wide_kernel<EPI, true>), dim3((unsigned)grid), dim3(512), W_SMEM, stream, p);
+        if (dvq_knobs().gemm_dephase) DVQ_LAUNCH((gemm_bf16x3_wide_kernel<EPI, true>), dim3((unsigned)grid), dim3(512), W_SMEM, stream, p);
         else DVQ_LAUNCH((gemm_bf16x3_wide_kernel<EPI, false>), dim3((unsigned)grid), dim3(512), W_SMEM, stream, p);
     }
     DVQ_CHECK_LAUNCH("gemm_bf16x3_wide");
@@ -736,17 +735,21 @@ int launch(const GemmParams& p, hipStream_t stream) {
 
 // Called by dvq_launch_gemm (gemm_f32.hip) after argument validation.  K of every source must be a multiple of 16.
 int dvq_launch_gemm_bf16x3(const GemmParams& p, GemmEpilogue epi, hipStream_t stream) {
+#ifdef DVQ_GEMM_DIAG
     if (const char* e = getenv("DVQ_GEMM_ABL")) const_cast<GemmParams&>(p).dbg_abl = atoi(e);
+    static const bool use_dma = !(getenv("DVQ_GEMM_NODMA") && getenv("DVQ_GEMM_NODMA")[0] == '1');
+#else
+    constexpr bool use_dma = true;
+#endif
     bool planes = true;                                              // pre-split weights: all-or-nothing per launch
     for (int s = 0; s < p.nsrc; ++s) planes = planes && p.src[s].Wp != nullptr;
-    static const bool use_dma = !(getenv("DVQ_GEMM_NODMA") && getenv("DVQ_GEMM_NODMA")[0] == '1');
     if (planes && use_dma) {
         bool aligned = true;                       // the DMA moves 16-byte chunks: every pointer and row stride must allow it
         for (int s = 0; s < p.nsrc; ++s)
             aligned = aligned && ((reinterpret_cast<uintptr_t>(p.src[s].Wp) & 15) == 0) && (p.src[s].wp_plane % 8 == 0) &&
                       (p.src[s].ldw % 8 == 0);
         // 128 x 256 tiles where they fill the chip (N = 256 leaves one tile column: the 128 x 128 kernel is faster there)
-        static const bool use_wide = !(getenv("DVQ_GEMM_WIDE") && getenv("DVQ_GEMM_WIDE")[0] == '0');
+        const bool use_wide = dvq_knobs().gemm_wide != 0;
         if (aligned && use_wide && p.N % 256 == 0 && p.N >= 512) {
             bool a_ok = true;                      // 16-byte activation loads
             for (int s = 0; s < p.nsrc; ++s)

@@ -12,7 +12,44 @@ void dvq_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* dvq_last_error(void) { return g_err; }
-extern "C" int dvq_abi_version(void) { return 4; }
+extern "C" int dvq_abi_version(void) { return 5; }
+
+// ---------------------------------------------------------------- environment knobs, read once (dvq_internal.h)
+namespace {
+std::mutex g_knob_lock;
+std::atomic<const DvqKnobs*> g_knobs{nullptr};
+DvqKnobs* read_knobs() {
+    DvqKnobs* k = new DvqKnobs();                       // a superseded set is leaked on purpose: launches may still read it
+    auto is = [](const char* name, char c) { const char* e = getenv(name); return e && e[0] == c; };
+    auto num = [](const char* name) { const char* e = getenv(name); return e ? atol(e) : 0L; };
+    k->gemm_wide = !is("DVQ_GEMM_WIDE", '0');
+    k->gemm_dephase = !is("DVQ_GEMM_DEPHASE", '0');
+    k->pn_filter = is("DVQ_PN_FILTER", '0') ? 0 : (is("DVQ_PN_FILTER", '2') ? 2 : 1);
+    k->pn_exhaustive = is("DVQ_PN_EXHAUSTIVE", '1');
+    k->pn_caps[0] = k->pn_caps[1] = -1;
+    if (const char* e = getenv("DVQ_PN_CAPS")) {
+        int a = 0, c = 0;
+        if (sscanf(e, "%d,%d", &a, &c) == 2) { k->pn_caps[0] = a < 0 ? 0 : a; k->pn_caps[1] = c < 0 ? 0 : c; }
+    }
+    k->pn_chunk = num("DVQ_PN_CHUNK");
+    k->pn_stats = getenv("DVQ_PN_STATS") != nullptr;
+    k->pixelcnn_chunk = num("DVQ_PIXELCNN_CHUNK");
+    return k;
+}
+}  // namespace
+const DvqKnobs& dvq_knobs() {
+    const DvqKnobs* k = g_knobs.load(std::memory_order_acquire);
+    if (k) return *k;
+    std::lock_guard<std::mutex> g(g_knob_lock);
+    k = g_knobs.load(std::memory_order_relaxed);
+    if (!k) { k = read_knobs(); g_knobs.store(k, std::memory_order_release); }
+    return *k;
+}
+extern "C" int dvq_reload_env(void) {
+    std::lock_guard<std::mutex> g(g_knob_lock);
+    g_knobs.store(read_knobs(), std::memory_order_release);
+    return DVQ_OK;
+}
 extern "C" int dvq_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return -1;

@@ -116,10 +116,7 @@ Plan make_plan(const dvq_pixelcnn_weights* w, int64_t B, void* ws) {
     p.L = w->n_layers;
     p.dim = w->dim;
     long chunk = 16384;
-    if (const char* e = getenv("DVQ_PIXELCNN_CHUNK")) {
-        const long v = atol(e);
-        if (v > 0) chunk = v;
-    }
+    if (dvq_knobs().pixelcnn_chunk > 0) chunk = dvq_knobs().pixelcnn_chunk;
     if (chunk > B) chunk = B;
     if (chunk < 1) chunk = 1;
     p.chunk = chunk;

@@ -73,13 +73,15 @@ PnScratch plan(int64_t B, int N, void* ws) {
                               (1024 + 512 + 256 + 16 + 1) * 4;
     const size_t budget = (size_t)6 << 30;
     long chunk = (long)(budget / per_sample);
-    if (const char* e = getenv("DVQ_PN_CHUNK")) {          // samples per launch (default: what 6 GB of scratch hold)
-        const long v = atol(e);
+    {                                                     // samples per launch (default: what 6 GB of scratch hold)
+        const long v = dvq_knobs().pn_chunk;
         if (v > 0 && v < chunk) chunk = v;
     }
     if (chunk < 1) chunk = 1;
     if (chunk > B) chunk = B;
     if (chunk < 1) chunk = 1;
+    // equal launches: 8 192 samples (an eighth of the benchmark batch) run as 2 x 4 096, not 7 500 + 692
+    if (B > 0) chunk = (B + ((B + chunk - 1) / chunk) - 1) / ((B + chunk - 1) / chunk);
     s.chunk = chunk;
     char* p = (char*)ws;
     auto take = [&](size_t n) { char* q = p; p += dvq_round_up(n, 256); return (float*)q; };
@@ -112,10 +114,7 @@ int dense(const float* x, long ldx, int K, const float* w, const uint16_t* wp, c
 }
 
 // DVQ_PN_FILTER: 0 = six-product trunk everywhere, 2 = filtered trunk whatever the fill of its tiles (tests), default 1
-int filter_mode() {
-    const char* e = getenv("DVQ_PN_FILTER");
-    return e && e[0] == '0' ? 0 : (e && e[0] == '2' ? 2 : 1);
-}
+int filter_mode() { return dvq_knobs().pn_filter; }
 
 int trunk(const float* pc, int C, int N, long Bc, const float* trans, const float* w1, const float* b1, const float* w2,
           const uint16_t* w2p, const float* b2, const float* w3, const uint16_t* w3p, const void* w3f, const float* b3, int relu3,
@@ -125,7 +124,7 @@ int trunk(const float* pc, int C, int N, long Bc, const float* trans, const floa
     const int fm = filter_mode();
     if (w2p && w3f && dvq_gemm_mode() == 1 && fm && N <= 16384 && (fm == 2 || 4L * N >= 3L * ((N + 255) / 256) * 256))
         return dvq_launch_pn_trunk_filter(pc, C, N, s.Npad, Bc, trans, w1, b1, w2, w2p, b2, w3f, w3, b3, relu3, s.h2, s.part, s.tstat,
-                                          s.cbuf, feat, ld_feat, getenv("DVQ_PN_STATS") ? s.stats : nullptr, st);
+                                          s.cbuf, feat, ld_feat, dvq_knobs().pn_stats ? s.stats : nullptr, st);
     if (w2p && w3p && dvq_gemm_mode() == 1) {       // fused trunk; w3p is the k-permuted plane image (see pn_trunk_kernel)
         DVQ_PROPAGATE(dvq_launch_pn_trunk(pc, C, N, Bc, trans, w1, b1, w2p, b2, w3p, b3, s.part, st));
         return dvq_launch_colmax_reduce(s.part, Bc, (N + 127) / 128, 1024, relu3, feat, ld_feat, st);   // the kernel's own tiling

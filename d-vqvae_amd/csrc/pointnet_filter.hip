@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
                                                                  const float* __restrict__ b2, const char* __restrict__ w3f,
                                                                  float* __restrict__ h2buf, f32x4* __restrict__ part,
                                                                  unsigned* __restrict__ tstat, const float* __restrict__ cbuf,
-                                                                 int abl /* timing diagnostics only (DVQ_PN_ABL) */) {
+                                                                 int abl_arg /* timing diagnostics only (DVQ_PN_ABL, -DDVQ_DIAG builds) */) {
+    const int abl = DVQ_DIAG_ON ? abl_arg : 0;
     extern __shared__ __attribute__((aligned(16))) char fl[];
     float* tb = reinterpret_cast<float*>(fl + F_OFF_TB);
     float* w1s = reinterpret_cast<float*>(fl + F_OFF_W1);
@@ -531,7 +532,8 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
                                                        const float* __restrict__ wnorm, const float* __restrict__ rnorm,
                                                        const unsigned* __restrict__ tstat, int relu, int exhaustive,
                                                        int pair_cap, int fb_cap, float* __restrict__ feat, long ld_feat,
-                                                       unsigned long long* __restrict__ stats, int abl) {
+                                                       unsigned long long* __restrict__ stats, int abl_arg) {
+    const int abl = DVQ_DIAG_ON ? abl_arg : 0;
     __shared__ unsigned short cand[1024][4];
     __shared__ unsigned char cand_n[1024];
     __shared__ int pair_list[PAIR_CAP];
@@ -879,8 +881,12 @@ int dvq_launch_pn_trunk_filter(const float* pc, int C, int N, int Npad, long B, 
     }
     DVQ_CHECK_LAUNCH("pn_center");
     const double pts = (double)B * tiles * 256;
-    const char* abl_e = getenv("DVQ_PN_ABL");
+#ifdef DVQ_DIAG
+    const char* abl_e = getenv("DVQ_PN_ABL");              // timing-only ablations / phase stamps: diagnostics build only
     const int abl = abl_e ? atoi(abl_e) : 0;
+#else
+    constexpr int abl = 0;
+#endif
     {
         DVQ_PROF("pn_trunk", 2.0 * pts * (4.0 * 64 + 64.0 * 128 + 128.0 * 1024), pts * (16 + 512) + (double)grid * 16384, st);
         if (C == 3)
@@ -891,16 +897,12 @@ int dvq_launch_pn_trunk_filter(const float* pc, int C, int N, int Npad, long B, 
                        b2, (const char*)w3f, h2buf, (f32x4*)part, tstat, cbuf, abl);
     }
     DVQ_CHECK_LAUNCH("pn_trunk_filter");
-    static const bool exhaustive_default = false;
-    const char* ex = getenv("DVQ_PN_EXHAUSTIVE");
-    const int exhaustive = (ex && ex[0] == '1') ? 1 : (int)exhaustive_default;
+    const DvqKnobs& kn = dvq_knobs();
+    const int exhaustive = kn.pn_exhaustive;
     int pair_cap = PAIR_CAP, fb_cap = FB_CAP;              // tests shrink the lists to reach the overflow paths
-    if (const char* e = getenv("DVQ_PN_CAPS")) {
-        int a = 0, c = 0;
-        if (sscanf(e, "%d,%d", &a, &c) == 2) {
-            pair_cap = a < 0 ? 0 : (a > PAIR_CAP ? PAIR_CAP : a);
-            fb_cap = c < 0 ? 0 : (c > FB_CAP ? FB_CAP : c);
-        }
+    if (kn.pn_caps[0] >= 0) {
+        pair_cap = kn.pn_caps[0] > PAIR_CAP ? PAIR_CAP : kn.pn_caps[0];
+        fb_cap = kn.pn_caps[1] > FB_CAP ? FB_CAP : kn.pn_caps[1];
     }
     {
         DVQ_PROF("pn_exact", 2.0 * (double)B * 1024 * 128, (double)B * (tiles * 16384.0 + 1024.0 * 512 + 4096), st);

@@ -914,11 +914,15 @@ extern "C" int dvq_vq_argmin_fast(const float* z, const float* E, const void* pa
     {
         const hipError_t e = attr_once.run([] {
             hipError_t e = hipSuccess;
+#ifdef DVQ_DIAG
             for (const void* fn : {(const void*)&vq_stream_kernel<0, false>, (const void*)&vq_stream_kernel<0, true>,
                                (const void*)&vq_stream_kernel<1, true>, (const void*)&vq_stream_kernel<2, true>,
                                (const void*)&vq_stream_kernel<4, true>, (const void*)&vq_stream_kernel<8, true>,
                                (const void*)&vq_stream_kernel<16, true>, (const void*)&vq_stream_kernel<32, true>,
                                (const void*)&vq_stream_kernel<15, true>, (const void*)&vq_stream_kernel<47, true>}) {
+#else
+            for (const void* fn : {(const void*)&vq_stream_kernel<0, false>}) {
+#endif
                 const hipError_t e1 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
                 if (e1 != hipSuccess) e = e1;
             }
@@ -933,13 +937,16 @@ extern "C" int dvq_vq_argmin_fast(const float* z, const float* E, const void* pa
     const int cus = device_cus();
     const long tiles = (M + TILE - 1) / TILE;
     const long per_launch = (long)cus * MAX_TILES;                 // one workgroup per CU, <= MAX_TILES tiles each
-    const bool want_dbg = getenv("DVQ_VQ_DBG") != nullptr;
-    const char* abl_s = getenv("DVQ_VQ_ABL");                      // diagnostics only (timing of ablated variants)
+#ifdef DVQ_DIAG
+    const bool want_dbg = getenv("DVQ_VQ_DBG") != nullptr;       // phase stamps / timing-only ablations: diagnostics build only
+    const char* abl_s = getenv("DVQ_VQ_ABL");
     const int abl = abl_s ? atoi(abl_s) : 0;
+#endif
     DVQ_PROF("vq_argmin_fast", 2.0 * M * K * D, (double)M * D * 4 + (double)K * D * 4 + (double)M * 8, st);
     for (long t0 = 0; t0 < tiles; t0 += per_launch) {
         const long nt = (tiles - t0 < per_launch) ? tiles - t0 : per_launch;
         const unsigned grid = (unsigned)(nt < cus ? nt : cus);
+#ifdef DVQ_DIAG
         unsigned long long* dbgp = (want_dbg && t0 == 0) ? (unsigned long long*)workspace : nullptr;
 #define DVQ_VQ_GO(A) DVQ_LAUNCH((vq_stream_kernel<A, true>), dim3(grid), dim3(NT), LDS_BYTES, st, z, E, (long)M, t0, nt, pk, idx, slow_rows, dbgp)
         switch (abl) {
@@ -957,6 +964,10 @@ extern "C" int dvq_vq_argmin_fast(const float* z, const float* E, const void* pa
                 break;
         }
 #undef DVQ_VQ_GO
+#else
+        DVQ_LAUNCH((vq_stream_kernel<0, false>), dim3(grid), dim3(NT), LDS_BYTES, st, z, E, (long)M, t0, nt, pk, idx, slow_rows,
+                   (unsigned long long*)nullptr);
+#endif
         DVQ_CHECK_LAUNCH("vq_stream");
     }
     return DVQ_OK;

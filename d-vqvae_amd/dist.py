@@ -16,13 +16,23 @@ def env_world() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-def init(backend: Optional[str] = None, share_gpu: bool = False) -> Tuple[int, int, int]:
-    """``share_gpu``: every rank drives cuda:0 (plumbing tests of the N > 1 path on a one-GPU box; needs "gloo",
-    RCCL refuses two ranks on one device).  Returns (rank, local_rank or 0, world)."""
+_force_collectives = False     # world size 1 with a live process group: run the collectives anyway (first-contact tests of RCCL)
+
+
+def init(backend: Optional[str] = None, share_gpu: bool = False, force_group: bool = False) -> Tuple[int, int, int]:
+    """``share_gpu`` (or DVQ_SHARE_GPU=1): every rank drives cuda:0 (plumbing tests of the N > 1 path on a one-GPU box;
+    needs "gloo", RCCL refuses two ranks on one device).  ``force_group`` (or DVQ_FORCE_PG=1): create the process group and
+    run every collective even at world size 1, so that RCCL initialisation, all_gather_into_tensor, barrier and
+    all_reduce execute on a one-GPU box.  ``backend`` defaults to DVQ_DIST_BACKEND, then "nccl" (= RCCL) on GPUs.
+    Returns (rank, local_rank or 0, world)."""
+    global _force_collectives
     rank, local_rank, world = env_world()
+    share_gpu = share_gpu or os.environ.get("DVQ_SHARE_GPU") == "1"
+    force_group = force_group or os.environ.get("DVQ_FORCE_PG") == "1"
+    backend = backend or os.environ.get("DVQ_DIST_BACKEND") or None
     if share_gpu:
         local_rank = 0
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
@@ -30,7 +40,12 @@ def init(backend: Optional[str] = None, share_gpu: bool = False) -> Tuple[int, i
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    _force_collectives = bool(force_group) and dist.is_initialized()
     return rank, local_rank, world
+
+
+def _active() -> bool:
+    return dist.is_initialized() and (dist.get_world_size() > 1 or _force_collectives)
 
 
 def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
@@ -40,31 +55,42 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def all_gather_rows(local: torch.Tensor, total_rows: Optional[int] = None) -> torch.Tensor:
-    """Rank-major concatenation of every rank's ``[rows_r, C]`` tensor (ragged shards allowed)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+def all_gather_rows(local: torch.Tensor, total_rows: Optional[int] = None, verify: bool = True) -> torch.Tensor:
+    """Rank-major concatenation of every rank's ``[rows_r, C]`` tensor (ragged shards allowed).
+
+    Every rank takes the same sequence of collectives whatever its own row count: the shard sizes are exchanged first
+    (one all-gather of ``world`` int64) and the data path -- one equal-size all-gather, or a padded one -- follows from the
+    exchanged sizes alone, so a rank whose rows disagree with ``total_rows`` makes EVERY rank raise instead of leaving the
+    others inside a collective.  ``verify=False`` with ``total_rows``: the caller guarantees rank r holds
+    ``shard_range(total_rows, r, world)`` rows (checked locally) and the exchange + its host sync are skipped -- the timed
+    loop of bench.py after one verified call."""
+    if not _active():
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
     local = local.contiguous()
     if local.is_cuda and dist.get_backend() == "gloo":       # gloo gathers host tensors only (one-GPU plumbing tests)
-        return all_gather_rows(local.cpu(), total_rows).to(local.device)
-    if total_rows is not None and total_rows % world == 0 and local.shape[0] * world == total_rows:
-        out = torch.empty((total_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local)
-        return out
-    if total_rows is None:                                   # shard sizes unknown: exchange them first (one tiny all-gather)
+        return all_gather_rows(local.cpu(), total_rows, verify).to(local.device)
+    if total_rows is not None and not verify:
+        sizes = [shard_range(total_rows, r, world) for r in range(world)]
+        if sizes[rank][1] - sizes[rank][0] != local.shape[0]:
+            raise RuntimeError(f"all_gather_rows(verify=False): rank {rank} holds {local.shape[0]} rows, shard_range says "
+                               f"{sizes[rank][1] - sizes[rank][0]}")
+    else:
         counts = torch.empty(world, dtype=torch.int64, device=local.device)
         dist.all_gather_into_tensor(counts, torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device))
         counts = [int(v) for v in counts.tolist()]
+        if total_rows is not None and sum(counts) != total_rows:       # the same verdict on every rank
+            raise RuntimeError(f"all_gather_rows: the ranks hold {counts} rows, {sum(counts)} in all, expected {total_rows}")
         sizes, lo = [], 0
         for n in counts:
             sizes.append((lo, lo + n))
             lo += n
-    else:
-        sizes = [shard_range(total_rows, r, world) for r in range(world)]
-        if sizes[rank][1] - sizes[rank][0] != local.shape[0]:
-            raise RuntimeError(f"all_gather_rows: rank {rank} holds {local.shape[0]} rows, shard_range says {sizes[rank][1] - sizes[rank][0]}")
+    total = sizes[-1][1]
     pad = max(hi - lo for lo, hi in sizes)
+    if all(hi - lo == pad for lo, hi in sizes):               # equal shards: one collective straight into the result
+        out = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local)
+        return out
     buf = torch.zeros((pad,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     buf[: local.shape[0]] = local
     out = torch.empty((pad * world,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -73,13 +99,18 @@ def all_gather_rows(local: torch.Tensor, total_rows: Optional[int] = None) -> to
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.barrier()
 
 
 def max_over_ranks(value: float, device) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()

@@ -177,4 +177,7 @@ def main(dataset: str, argv: Optional[Sequence[str]] = None) -> List[str]:
         written.append(path)
     if total_g:
         print(f"rank {rank}: {total_g} grasps in {total_t:.3f} s ({total_g / max(total_t, 1e-9):.1f} grasps/s incl. first-call packing)")
+    dist.barrier()                                       # every rank's files are on disk when any rank returns
+    if world > 1:
+        dist.shutdown()
     return written

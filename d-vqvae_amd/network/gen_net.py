@@ -27,7 +27,8 @@ class GenNet(nn.Module):
         self.recon_encoder = PointNetEncoder(global_feat=True, feature_transform=False, channel=3)
         self.pos_decoder = Decoder(layer_sizes=[1024, 128, 6], latent_size=2048)
         self.GatedPixelCNN = GatedPixelCNN(prior_tokens, prior_dim, prior_layers, prior_classes)
-        self.noise_seed = 0          # key of the device Philox generator that replaces multinomial's draws (set_noise_seed)
+        self.noise_seed = None       # key of the device Philox generator that replaces multinomial's draws (set_noise_seed);
+        #                              None: torch.initial_seed(), i.e. torch.manual_seed governs the draws as it does the reference's
         self._noise_stream = 0       # one Philox stream per gen() call unless the caller names it
 
     def set_noise_seed(self, seed, first_stream=0):
@@ -63,11 +64,13 @@ class GenNet(nn.Module):
         return self.decoder(z_out).view(B, 55)
 
     @torch.no_grad()
-    def gen(self, obj, noise=None, return_aux=False, seed=None, row0=0, stream_id=None):
+    def gen(self, obj, noise=None, return_aux=False, seed=None, row0=None, stream_id=None):
         """obj [B,4,N] f32 on the GPU -> (recon [B,55], recon_pos [B,6]).
         ``noise`` [B,9,prior_tokens] ~ Exp(1) fixes the prior's draws (parity runs).  Without it the draws come from the
         device Philox generator keyed by (seed, stream_id, row0 + b): a batch sharded over ranks (``row0`` = first global
-        row of the shard, same ``seed`` / ``stream_id``) generates exactly what the unsharded call generates."""
+        row of the shard, same ``seed`` / ``stream_id``) generates exactly what the unsharded call generates.
+        Defaults: seed = set_noise_seed's, else torch.initial_seed(); one stream per call; rows of this rank
+        (ops.default_noise_key), so ranks that name nothing never share noise."""
         if obj.dim() != 3:
             raise RuntimeError(f"gen: expected obj [B,4,N], got {tuple(obj.shape)}")
         B, dev = obj.shape[0], obj.device
@@ -85,7 +88,10 @@ class GenNet(nn.Module):
             if stream_id is None:
                 stream_id = self._noise_stream
                 self._noise_stream += 1
-            noise = ops.exp1_noise(B, 9 * pk.n_in, self.noise_seed if seed is None else seed, row0, stream_id, device=dev).view(B, 9, pk.n_in)
+            dseed, drow = ops.default_noise_key()
+            if seed is None:
+                seed = dseed if self.noise_seed is None else self.noise_seed
+            noise = ops.exp1_noise(B, 9 * pk.n_in, seed, drow if row0 is None else row0, stream_id, device=dev).view(B, 9, pk.n_in)
         codes = ops.pixelcnn_sample(pk, label, noise.contiguous(), err=err)   # :92
         recon = self._decode(codes, {"z_out": z_out}, None, err)           # :95-113
         verts = self._hand_vertices(recon)                                 # :116-118

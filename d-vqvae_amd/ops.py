@@ -218,6 +218,14 @@ def exp1_noise(rows: int, cols: int, seed: int, row0: int = 0, stream_id: int = 
     """[rows, cols] Exp(1) variates from the device Philox generator, keyed by (seed, stream_id, GLOBAL row row0 + r, column):
     a shard of a batch (row0 = its first row) draws exactly the rows the whole batch would draw (dvq_exp1_noise)."""
     lib = _lib.load()
+    if cols % 4 != 0:                                     # the generator writes 16-byte quads: draw a padded row, keep the columns asked for
+        if device is None and out is not None:
+            device = out.device
+        wide = exp1_noise(rows, (cols + 3) // 4 * 4, seed, row0, stream_id, device=device)
+        if out is None:
+            return wide[:, :cols].contiguous()
+        out.copy_(wide[:, :cols])
+        return out
     if out is None:
         if device is None:
             raise RuntimeError("exp1_noise: pass `device` or `out`")
@@ -225,12 +233,19 @@ def exp1_noise(rows: int, cols: int, seed: int, row0: int = 0, stream_id: int = 
     dev = _require_gpu(out)
     if tuple(out.shape) != (rows, cols) or not out.is_contiguous() or out.dtype != torch.float32:
         raise RuntimeError("exp1_noise: `out` must be a contiguous float32 [rows, cols] tensor")
-    if cols % 4 != 0:
-        raise RuntimeError("exp1_noise: cols must be a multiple of 4")
     with torch.cuda.device(dev):
         check(lib.dvq_exp1_noise(int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_id) & 0xFFFFFFFF, int(row0), rows, cols, out.data_ptr(),
                                  _stream(dev)), "dvq_exp1_noise")
     return out
+
+
+def default_noise_key():
+    """(seed, first global row) of noise drawn without an explicit key: the seed follows torch.manual_seed (initial_seed of
+    the default generator), and every rank of a process group draws rows of its own (rank * 2^40 + b), so that ranks calling
+    gen(obj) on different objects without naming seed / row0 do not all draw the same noise."""
+    import torch.distributed as td
+    rank = td.get_rank() if td.is_available() and td.is_initialized() else 0
+    return int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF, rank << 40
 
 
 def probe_f16_subnormal(device) -> Tuple[float, float]:

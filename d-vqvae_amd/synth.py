@@ -74,6 +74,45 @@ def synthetic_clouds(B: int, N: int, seed: int = 0, channels: int = 4) -> torch.
     return torch.from_numpy(out)
 
 
+OBJECT_CODEBOOK = "vqvae6.vector_quantization.embedding.weight"
+
+
+def feature_codebook(features: torch.Tensor, spread: float = 1.0) -> torch.Tensor:
+    """Codebook rows = the given encoder features rounded to fp16 (exactly representable in fp32, so fixtures store them as
+    float16).  Random N(0, 0.5) codebook rows are all about equally far from every PointNet feature of the synthetic
+    clouds (the features of different clouds differ by ~0.02 per channel around a common mean), so every object would get
+    the same code; rows that ARE features of distinct seed clouds make the in-path argmin a real decision.
+    ``spread`` > 1 moves the rows away from their mean by that factor (wider top-2 gaps, fewer distinct codes in use)."""
+    f = features.detach().float().cpu()
+    if spread != 1.0:
+        m = f.mean(0, keepdim=True)
+        f = m + spread * (f - m)
+    return f.half().float().contiguous()
+
+
+def seed_clouds(K: int, N: int, seed: int = 4100, channels: int = 4) -> torch.Tensor:
+    """The K clouds whose object-type features become the K rows of the object codebook (``feature_codebook``)."""
+    return synthetic_clouds(K, N, seed=seed, channels=channels)
+
+
+def diversify_object_codebook(net, sd: Dict[str, torch.Tensor], N: int, seed: int = 4100, spread: float = 2.0) -> Dict[str, torch.Tensor]:
+    """Replace the object codebook of ``sd`` (already loaded into ``net``, which sits on its device in eval mode) by the
+    net's OWN object-type features of K seed clouds (K = codebook rows) and load it back.  Used where no reference exists
+    (benchmark network, smoke): the codebook is a free synthetic parameter, and the CPU oracle is then given the same ``sd``."""
+    E = sd[OBJECT_CODEBOOK]
+    dev = next(net.parameters()).device
+    with torch.no_grad():
+        feats = []
+        clouds = seed_clouds(E.shape[0], N, seed=seed)
+        for b0 in range(0, E.shape[0], 256):
+            feats.append(net.obj_encoder_type(clouds[b0:b0 + 256].to(dev))[0].float().cpu())
+    sd = dict(sd)
+    sd[OBJECT_CODEBOOK] = feature_codebook(torch.cat(feats), spread)
+    net.load_state_dict(sd)
+    net.eval().to(dev)
+    return sd
+
+
 def synthetic_normal(shape, seed: int, name: str, scale: float = 1.0) -> torch.Tensor:
     a = _rng(seed, name).normal(0.0, scale, size=tuple(shape))
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))

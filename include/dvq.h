@@ -41,6 +41,9 @@ int dvq_abi_version(void);
 const char* dvq_last_error(void);
 /* number of visible HIP devices, or -1; does not create a context */
 int dvq_device_count(void);
+/* The library reads its environment knobs (tile/chunk choices and the PointNet test switches DVQ_PN_FILTER / _EXHAUSTIVE /
+ * _CAPS: none changes a result) ONCE, at first use; this re-reads them (tests that flip a knob in-process call it). */
+int dvq_reload_env(void);
 
 /* ------------------------------------------------------------------ generic dense layer (MFMA fp32)
  * y[M,N] = act( sum_s x_s[M,K_s] @ w_s[N,K_s]^T + bias[N] ) -- nn.Linear / 1x1 conv / conv taps.

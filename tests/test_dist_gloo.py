@@ -67,3 +67,44 @@ def test_shard_ranges_cover_the_batch_in_rank_major_order():
         assert spans[0][0] == 0 and spans[-1][1] == total
         assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
         assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+
+
+def _mismatch_worker(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from dvqvae_amd import dist
+    dist.init(backend="gloo")
+    full = _params(10)
+    mine = full[:5] if rank == 0 else full[5:9]                       # rank 1 is one row short of total_rows = 10
+    try:
+        dist.all_gather_rows(mine.clone(), total_rows=10)
+        ret[rank] = "no error"
+    except RuntimeError as e:
+        ret[rank] = str(e)
+    dist.barrier()                                                    # both ranks are still in step: nobody hangs in a collective
+    td.destroy_process_group()
+
+
+def test_row_count_mismatch_raises_on_every_rank_instead_of_hanging():
+    world, port = 2, _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_mismatch_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all("expected 10" in ret[r] for r in range(world)), dict(ret)
+
+
+def _forced_worker(rank, world, port, ret):
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from dvqvae_amd import dist
+    r, lr, w = dist.init(backend="gloo", force_group=True)            # world size 1, collectives executed anyway
+    full = _params(12)
+    ok = td.is_initialized() and w == 1 and torch.equal(dist.all_gather_rows(full.clone(), total_rows=12), full)
+    ok = ok and torch.equal(dist.all_gather_rows(full.clone(), total_rows=12, verify=False), full)
+    ok = ok and dist.max_over_ranks(3.5, "cpu") == 3.5
+    dist.barrier()
+    dist.shutdown()
+    ret[0] = ok and not td.is_initialized()
+
+
+def test_forced_process_group_at_world_size_one():
+    ret = mp.Manager().dict()
+    mp.spawn(_forced_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
+    assert ret[0]

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import SEED
+from conftest import SEED, dvqvae_state_dict, gen_state_dict
 from dvqvae_amd import synth
 from oracle import dvq_oracle as O
 from oracle import mano_oracle
@@ -137,26 +137,25 @@ def test_decoders(golden):
         close(O.mlp_decoder(sd, "", z), g[tag + "_y"])
 
 
-def _gennet_sd():
+def _gennet_sd(g7):
     from dvqvae_amd.network.gen_net import GenNet
-    sd = synth.synthetic_state_dict(GenNet().state_dict(), SEED)
-    sd["GatedPixelCNN.output_conv.2.bias"][128:] = -1e4
-    return sd
+    return gen_state_dict(GenNet().state_dict(), g7)
 
 
 def test_gen_end_to_end_vs_reference(golden):
     """G7 / BASELINE config 1: oracle.gen batched over 8 objects == 8 reference GenNet.gen(B=1) calls."""
     g = golden("g7_gen")
-    sd = _gennet_sd()
+    sd = _gennet_sd(g)
     mano = mano_oracle.ManoOracle(mano_oracle.synthetic_mano_arrays())
     obj = synth.synthetic_clouds(8, int(g["n_points"]), seed=int(g["cloud_seed"]))
     q = synth.exp1_noise(8, 9, 512, seed=int(g["noise_seed"]))
     with torch.no_grad():
         recon, pos, aux = O.gen(sd, obj, q, mano, return_aux=True)
-    safe = g["idx6_gap"] > 0.05
+    safe = g["idx6_gap"] > float(g["idx6_margin"])
+    assert safe.sum() >= 6 and len(set(g["idx6"][safe].tolist())) >= 6, "the fixture must bite: distinct, well separated object codes"
     assert np.array_equal(aux["idx6"][:, 0].numpy()[safe], g["idx6"][safe])
     same = np.all(aux["codes"].numpy().reshape(8, 9) == g["codes"].reshape(8, 9), axis=1) & (aux["idx6"][:, 0].numpy() == g["idx6"])
-    print(f"set aside by the gap check (fp64 top-2 distance gap of the object code <= 0.05): {(~safe).sum()} of 8")
+    print(f"set aside by the gap check (fp64 top-2 distance gap of the object code <= {float(g['idx6_margin'])}): {(~safe).sum()} of 8")
     assert same[safe].all()
     close(recon[torch.from_numpy(same)], g["recon"][same])
     close(pos[torch.from_numpy(same)], g["recon_pos"][same])
@@ -170,13 +169,16 @@ def test_gen_end_to_end_vs_reference(golden):
 def test_dvqvae_eval_vs_reference(golden):
     from dvqvae_amd.network.DVQVAE import DVQVAE, HAND_PARTS
     g = golden("g8_dvqvae")
-    sd = synth.synthetic_state_dict(DVQVAE().state_dict(), SEED + 8)
+    sd = dvqvae_state_dict(DVQVAE().state_dict(), g)
     obj = synth.synthetic_clouds(3, 512, seed=80)
     hand = synth.synthetic_normal((3, 3, 778), SEED, "dvq/hand", 0.05)
     with torch.no_grad():
         emb_idx, obj_emb = O.dvqvae_eval_forward(sd, obj, hand, HAND_PARTS)
-    assert np.array_equal(emb_idx[:, 0].numpy(), g["emb_idx"])
-    close(obj_emb, g["obj_emb"], atol=0)
+    safe = g["emb_gap"] > float(g["emb_margin"])
+    assert safe.sum() >= 18 and all(len(set(r.tolist())) == 3 for r in g["emb_idx"].reshape(7, 3)), "the fixture must bite"
+    assert np.array_equal(emb_idx[:, 0].numpy()[safe], g["emb_idx"][safe])
+    if safe[:3].all():
+        close(obj_emb, g["obj_emb"], atol=0)
     assert HAND_PARTS[0] == O._thumb_vertices() and sorted(set(sum(HAND_PARTS, []))) == list(range(778))
 
 

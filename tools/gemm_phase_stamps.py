@@ -1,8 +1,9 @@
 """Diagnostic (GPU box): DVQ_GEMM_CLK=1 makes the bf16x3 DMA GEMM stamp every block (start, loop end, block end) and
-print the in-kernel clock (build with `make -C d-vqvae_amd/csrc EXTRA=-DDVQ_GEMM_DIAG` after touching gemm_bf16x3.hip); DVQ_GEMM_ABL=4/5/6 ablate the activation split / all DMA / the weight DMA pieces (timing only)."""
+print the in-kernel clock (needs the diagnostics build `make -C d-vqvae_amd/csrc diag`, loaded with DVQ_DIAG_LIB=1); DVQ_GEMM_ABL=4/5/6 ablate the activation split / all DMA / the weight DMA pieces (timing only)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["DVQ_GEMM_CLK"] = "1"
+os.environ["DVQ_DIAG_LIB"] = "1"
 import dvqvae_amd
 from dvqvae_amd import ops, packing
 dev = "cuda:0"

@@ -238,12 +238,23 @@ class RefManoStandIn:
         return types.SimpleNamespace(vertices=self.oracle(betas, hand_pose, global_orient, transl))
 
 
-def g7_gen(sampler):
-    net = RefGenNet()
+def gen_state_dict(net):
+    """Synthetic GenNet weights with the object codebook made of the REFERENCE's object-type features of 128 seed clouds
+    (synth.feature_codebook), so that idx6 differs from object to object; the codebook is stored in the fixture (fp16)."""
     sd = synth.synthetic_state_dict(net.state_dict(), SEED)
     sd["GatedPixelCNN.output_conv.2.bias"][128:] = -1e4                       # (4)
     net.load_state_dict(sd, strict=True)
     net.eval()
+    with torch.no_grad():
+        f, _, _ = net.obj_encoder_type(synth.seed_clouds(128, 1024))
+    sd[synth.OBJECT_CODEBOOK] = synth.feature_codebook(f)
+    net.load_state_dict(sd, strict=True)
+    return sd
+
+
+def g7_gen(sampler):
+    net = RefGenNet()
+    sd = gen_state_dict(net)
     mano = mano_oracle.ManoOracle(mano_oracle.synthetic_mano_arrays())
     net.set_rh_mano(RefManoStandIn(mano))
     n_obj, N = 8, 1024
@@ -268,21 +279,26 @@ def g7_gen(sampler):
         net.GatedPixelCNN.generate = orig_gen
         rec.append(r); pos.append(p); codes.append(captured["codes"]); idx6s.append(i6); feats.append(f)
     feats = torch.cat(feats)
-    E6 = sd["vqvae6.vector_quantization.embedding.weight"].double()
-    d64 = (feats.double() ** 2).sum(1, keepdim=True) + (E6 ** 2).sum(1) - 2 * feats.double() @ E6.t()
+    E6 = sd[synth.OBJECT_CODEBOOK].double()
+    d64 = ((feats.double()[:, None, :] - E6[None]) ** 2).sum(-1)
     top2 = torch.topk(d64, 2, dim=1, largest=False)[0]
+    idx6 = torch.cat(idx6s).squeeze(1)
+    gap = (top2[:, 1] - top2[:, 0]).float()
+    print("g7 idx6", idx6.tolist(), "gaps", [f"{v:.2e}" for v in gap.tolist()])
+    assert len(set(idx6[gap > G7_MARGIN].tolist())) >= 6, "fixture must bite: >= 6 distinct, well separated object codes"
     save("g7_gen", recon=torch.cat(rec), recon_pos=torch.cat(pos), codes=torch.cat(codes),
-         idx6=torch.cat(idx6s).squeeze(1), idx6_gap=(top2[:, 1] - top2[:, 0]).float(),
+         idx6=idx6, idx6_gap=gap, idx6_margin=G7_MARGIN, E6_f16=sd[synth.OBJECT_CODEBOOK].half(),
          feat_type=feats, n_points=N, cloud_seed=42, noise_seed=43)
+
+
+G8_MARGIN = 2e-4      # same for the seven codes of G8 (D = 256 / 1024 embeddings of magnitude ~1)
+G7_MARGIN = 5e-4      # fp64 top-2 gap of the object code's squared distance above which fp32 paths must agree (noise ~2e-5)
 
 
 def g7_gen_juice(sampler):
     """Re-run the juice case on the fp16-rounded cloud actually stored (keeps the fixture small and exact)."""
     net = RefGenNet()
-    sd = synth.synthetic_state_dict(net.state_dict(), SEED)
-    sd["GatedPixelCNN.output_conv.2.bias"][128:] = -1e4
-    net.load_state_dict(sd, strict=True)
-    net.eval()
+    gen_state_dict(net)
     net.set_rh_mano(RefManoStandIn(mano_oracle.ManoOracle(mano_oracle.synthetic_mano_arrays())))
     pts = np.load(os.path.join(REF, "models/Object_models/juice_model/juice_modelresampled.npy"))
     diag = np.linalg.norm(pts.max(0) - pts.min(0))
@@ -297,14 +313,48 @@ def g7_gen_juice(sampler):
 
 # ---- G8: DVQVAE.forward eval --------------------------------------------------------------------------
 def g8_dvqvae():
+    """DVQVAE.forward eval.  The seven codebooks are the reference's own encoder outputs for 128 seed samples (hand-part
+    embeddings / object-type features, fp16-rounded, stored in the fixture), so every sample gets its own codes."""
     net = ref_dvq.DVQVAE(obj_inchannel=4)
-    load_synth(net, SEED + 8)
+    sd = load_synth(net, SEED + 8)
+    K = 128
+    seed_obj = synth.seed_clouds(K, 512, seed=4180)
+    seed_hand = synth.synthetic_normal((K, 3, 778), SEED, "dvq/seed_hand", 0.05)
+    got = {}
+    hooks = [m.register_forward_hook(lambda mod, a, out, k=k: got.__setitem__(k, out.detach())) for k, m in enumerate(net.handembnns)]
+    hooks.append(net.obj_encoder_type.register_forward_hook(lambda mod, a, out: got.__setitem__(6, out[0].detach())))
+    with torch.no_grad():
+        for b0 in range(0, K, 16):
+            net(seed_obj[b0:b0 + 16], seed_hand[b0:b0 + 16])
+            for k in range(7):
+                got.setdefault(("all", k), []).append(got[k])
+    books = {}
+    for k in range(7):
+        E = synth.feature_codebook(torch.cat(got[("all", k)]))
+        sd[f"vqvae{k}.vector_quantization.embedding.weight"] = E
+        books[f"E{k}_f16"] = E.half()
+    net.load_state_dict(sd, strict=True)
+    net.eval()
     B = 3
     obj = synth.synthetic_clouds(B, 512, seed=80)
     hand = synth.synthetic_normal((B, 3, 778), SEED, "dvq/hand", 0.05)
     with torch.no_grad():
         emb_idx, obj_emb = net(obj, hand)
-    save("g8_dvqvae", emb_idx=emb_idx.squeeze(1), obj_emb=obj_emb)
+    for h in hooks:
+        h.remove()
+    rows = emb_idx.squeeze(1).view(7, B)
+    gaps = []
+    for k in (6, 0, 1, 2, 3, 4, 5):                                            # emb_idx order: idx6, idx0..5
+        E = sd[f"vqvae{k}.vector_quantization.embedding.weight"].double()
+        d64 = ((got[k].double()[:, None, :] - E[None]) ** 2).sum(-1)
+        t2 = torch.topk(d64, 2, dim=1, largest=False)[0]
+        gaps.append((t2[:, 1] - t2[:, 0]).float())
+    gaps = torch.cat(gaps)
+    print("g8 emb_idx", rows.tolist(), "min gap", float(gaps.min()))
+    assert all(len(set(r.tolist())) == B for r in rows), "fixture must bite: pairwise-different codes across the samples"
+    books["emb_gap"] = gaps
+    books["emb_margin"] = G8_MARGIN
+    save("g8_dvqvae", emb_idx=emb_idx.squeeze(1), obj_emb=obj_emb, **books)
 
 
 def g0_state_dict_layout():

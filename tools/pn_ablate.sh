@@ -1,8 +1,9 @@
 #!/bin/bash
 export TMPDIR=/tmp
+# needs the diagnostics build: make -C d-vqvae_amd/csrc diag
 for abl in ${ABLS:-0}; do
   rm -rf /tmp/pnprof
-  DVQ_PN_ABL=$abl PN_B=4096 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pnprof -o pn --output-format csv -- python3 tools/pn_filter_bench.py > /tmp/pnprof.log 2>&1
+  DVQ_DIAG_LIB=1 DVQ_PN_ABL=$abl PN_B=4096 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pnprof -o pn --output-format csv -- python3 tools/pn_filter_bench.py > /tmp/pnprof.log 2>&1
   f=$(find /tmp/pnprof -name "*kernel_stats.csv" | head -1)
   python3 - "$f" $abl <<'PY'
 import csv, sys

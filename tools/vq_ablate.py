@@ -3,7 +3,7 @@
 import os, sys, subprocess
 here = os.path.dirname(os.path.abspath(__file__))
 for abl in (0, 1, 2, 4, 8, 16, 32, 15, 47):
-    env = dict(os.environ, DVQ_VQ_ABL=str(abl))
+    env = dict(os.environ, DVQ_VQ_ABL=str(abl), DVQ_DIAG_LIB="1")   # diagnostics build: make -C d-vqvae_amd/csrc diag
     out = subprocess.run([sys.executable, os.path.join(here, "vq_phase_stamps.py")], env=env, capture_output=True, text=True).stdout
     keep = [l for l in out.splitlines() if l.startswith(("train", "prologue", "tile loop", "refine", "-- iteration t=2"))]
     print(f"=== ABL {abl}")

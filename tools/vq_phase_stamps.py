@@ -31,6 +31,7 @@ alg = M * 256 * 4 + 512 * 256 * 4 + M * 8
 print(f"train of {n} calls: {us:.2f} us per call = {alg / us / 1e3:.1f} GB/s = {alg / us / 1e3 / 8000:.3f} of 8 TB/s")
 
 os.environ["DVQ_VQ_DBG"] = "1"
+os.environ["DVQ_DIAG_LIB"] = "1"          # diagnostics build: make -C d-vqvae_amd/csrc diag
 for _ in range(3):
     idx = ops.vq_argmin(z, E, packed=pk)
 torch.cuda.synchronize()
