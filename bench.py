@@ -351,7 +351,7 @@ def main():
 
     # this rank's clouds: a pool of 4096 synthetic objects tiled over the shard (host RAM / time bound), de-duplicated by a
     # per-row offset that depends on the GLOBAL row (so a row's input does not depend on the sharding)
-    pool = synth.synthetic_clouds(min(max(B, 1), 4096), N, seed=1000).to(dev)
+    pool = synth.synthetic_clouds(min(max(B_global, 1), 4096), N, seed=1000).to(dev)   # keyed by the GLOBAL batch: same pool on every rank
     rows = torch.arange(lo, hi, device=dev)
     obj = pool[rows % pool.shape[0]].contiguous()
     obj[:, :3] += ((rows // pool.shape[0]).float() * 1e-3)[:, None, None]

@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, the committed golden vectors
 (produced by the real reference) and size-independent properties.  Indices bit-exact; floats within the
 tolerance BASELINE.json states for the path (1e-5 abs on MANO pose/shape)."""
+import os
+
 import numpy as np
 import pytest
 import torch

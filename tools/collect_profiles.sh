@@ -12,11 +12,11 @@ run() { # name, then the rocprofv3 args
   timeout 900 rocprofv3 "$@" -d $OUT/$name -o $name --output-format csv -- python3 bench.py ${BENCH_ARGS} > $OUT/$name.json 2> $OUT/$name.log
   echo "$name rc=$?"
 }
-BENCH_ARGS="--steps 2 --warmup 1 --no-cpu-baseline --prof-steps 0" run bench_stats --kernel-trace --stats
+BENCH_ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-latency --prof-steps 0" run bench_stats --kernel-trace --stats
 BENCH_ARGS="--vq-only" run vq_stats --kernel-trace --stats
 BENCH_ARGS="--vq-only" run vq_pmc_fetch --kernel-trace --pmc FETCH_SIZE
 BENCH_ARGS="--vq-only" run vq_pmc_write --kernel-trace --pmc WRITE_SIZE
-BENCH_ARGS="--steps 1 --warmup 1 --no-cpu-baseline --prof-steps 0" run bench_pmc_fetch --kernel-trace --pmc FETCH_SIZE
-BENCH_ARGS="--steps 1 --warmup 1 --no-cpu-baseline --prof-steps 0" run bench_pmc_write --kernel-trace --pmc WRITE_SIZE
+BENCH_ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-latency --prof-steps 0" run bench_pmc_fetch --kernel-trace --pmc FETCH_SIZE
+BENCH_ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-latency --prof-steps 0" run bench_pmc_write --kernel-trace --pmc WRITE_SIZE
 timeout 300 python3 bench.py --vq-only --vq-tie-prone > $OUT/vq_tie_prone.json 2> $OUT/vq_tie_prone.log; echo "tie_prone rc=$?"
 find $OUT -name "*.csv" | head -30
