@@ -164,12 +164,14 @@ int dvq_launch_gemm_bf16x3(const GemmParams& p, GemmEpilogue epi, hipStream_t st
 // 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split-bf16 (default); env DVQ_GEMM=fp32|bf16x3
 int dvq_gemm_mode();
 
-// Behaviour knobs read from the environment ONCE (first use) -- DVQ_GEMM_WIDE, DVQ_GEMM_DEPHASE, DVQ_PN_FILTER, DVQ_PN_EXHAUSTIVE,
+// Behaviour knobs read from the environment ONCE (first use) -- DVQ_GEMM_WIDE, DVQ_GEMM_DEPHASE, DVQ_GEMM_SKINNY, DVQ_PN_FILTER, DVQ_PN_EXHAUSTIVE,
 // DVQ_PN_CAPS, DVQ_PN_CHUNK, DVQ_PN_STATS, DVQ_PIXELCNN_CHUNK -- none of them changes a result (tile shapes, chunk sizes, the
 // exhaustive PointNet evaluation the filter is tested against).  dvq_reload_env() re-reads them (tests flip them in-process).
 struct DvqKnobs {
     int gemm_wide;        // 0: 128 x 128 kernels only
     int gemm_dephase;
+    int gemm_skinny_prefetch;   // 0: no helper workgroups (DVQ_GEMM_SKINNY_PREFETCH=0)
+    int gemm_skinny;      // 0: tiled kernels also for M <= 256 (DVQ_GEMM_SKINNY=0; the two must agree bitwise)
     int pn_filter;        // 0 six-product trunk, 1 default, 2 filtered trunk whatever the tile fill
     int pn_exhaustive;    // 1: exact stage evaluates every point (what the filter must reproduce bit for bit)
     int pn_caps[2];       // candidate-list capacities (tests shrink them to reach the overflow paths); <= 0: default

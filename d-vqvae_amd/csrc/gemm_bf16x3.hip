@@ -691,6 +691,272 @@ int launch_wide(const GemmParams& p, hipStream_t stream) {
     return DVQ_OK;
 }
 
+// ================================================================================================================
+// Skinny variant for small M (the reference's own call pattern: GenNet.gen with B = 1 per call, 1 / 20 / 49 / 100 grasps per
+// object, gen_diverse_grasp_ho3d.py:212-236).  With M <= 128 the tiled kernels above run one workgroup per 128 or 256 output
+// columns, each streaming its whole weight panel through ONE CU (125 us per gated GEMM at M = 1: 4 workgroups busy).  Here every
+// WAVE owns one 32 x 32 output block over the full K: weights go global -> registers (three bf16 planes), the activation
+// fragment is split in registers, and the six partial products run in EXACTLY the order of the tiled kernels -- the same MFMA
+// sequence on the same operands, so the result is bit-identical to the batched path (tests: skinny == tiled bitwise, gen
+// batched == loop of B = 1 calls).  A workgroup is two waves: two adjacent column blocks, which for the gate epilogue are a
+// tanh block and its sigmoid partner (exchanged through 4 KB of LDS).  Grid = (N / 64) x (M / 32) workgroups.
+//
+// Loads are shaped in whole 128-byte lines: a lane (row r, half h) fetches 64 contiguous bytes of its weight row per plane
+// (four k-steps of 16) and 128 bytes of its activation row with back-to-back 16-byte loads, so every line is touched by
+// consecutive instructions and crosses L2 -> L1 once.  The 16-byte pieces then sit in the wrong lane half for two of the four
+// k-steps; v_permlane32_swap puts them where the MFMA operand layout wants them (lane half h <-> k = 8h .. 8h+7).
+// Measured (tools/gemm_skinny_bench.py, M = 1, N = 1024, K = 2048, launches issued from Python): 30.5 us against 125 us for
+// the tiled kernel, the same on L2-warm and on rotating panels (not memory-bound: a k-step costs ~370 cycles -- six dependent
+// MFMAs = 192, and ~55 vector instructions (split 44, swaps 10) that the in-order wave issues between them).  Tried: one
+// k-step per load (32 bytes of each of 32 lines per instruction: 4x the L1 fill traffic, 590 cycles per k-step), 12 k-steps
+// in flight (no change), four waves sharing the split through the LDS with a barrier per chunk (49.8 us: the round trip
+// serialises), prefetch helper workgroups sweeping the panel into the Infinity Cache (-7 %, kept).
+struct SkinnyChunk {
+    uint4 w[3][4];      // after load: piece 4h+q of the row's 128 bytes; after fix(): [0],[2],[1],[3] = k-steps 0,1,2,3
+    f32x4 a[8];         // after load: piece 8h+q of the row's 256 bytes; after fix(): (a[0],a[1]),(a[4],a[5]),(a[2],a[3]),(a[6],a[7])
+};
+
+__device__ __forceinline__ void swap_halves(uint4& x, uint4& y) {      // x.hi <-> y.lo (per dword)
+    unsigned* px = reinterpret_cast<unsigned*>(&x);
+    unsigned* py = reinterpret_cast<unsigned*>(&y);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const auto r = __builtin_amdgcn_permlane32_swap(px[i], py[i], false, false);
+        px[i] = r[0];
+        py[i] = r[1];
+    }
+}
+__device__ __forceinline__ void swap_halves(f32x4& x, f32x4& y) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[i]), __float_as_uint(y[i]), false, false);
+        x[i] = __uint_as_float(r[0]);
+        y[i] = __uint_as_float(r[1]);
+    }
+}
+
+struct SkinnyCursor {
+    int s, k_left;
+    const float* a_ptr;
+    const uint16_t* w_ptr[3];
+
+    __device__ __forceinline__ void open(const GemmParams& p, int src_i, long m, int n, int h) {
+        s = src_i;
+        if (s >= p.nsrc) { k_left = 0; return; }
+        const GemmSrc& src = p.src[s];
+        k_left = src.K;
+        a_ptr = src.A + m * src.lda + 32 * h;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) w_ptr[pl] = src.Wp + pl * src.wp_plane + (long)n * src.ldw + 32 * h;
+    }
+    __device__ __forceinline__ void load(const GemmParams& p, long m, int n, int h, SkinnyChunk& t) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) t.w[pl][q] = *reinterpret_cast<const uint4*>(w_ptr[pl] + 8 * q);
+            w_ptr[pl] += 64;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t.a[q] = *reinterpret_cast<const f32x4*>(a_ptr + 4 * q);
+        a_ptr += 64;
+        k_left -= 64;
+        if (k_left <= 0) open(p, s + 1, m, n, h);
+    }
+};
+
+__device__ __forceinline__ void skinny_fix(SkinnyChunk& t) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        swap_halves(t.w[pl][0], t.w[pl][1]);     // -> k-steps 0 and 2
+        swap_halves(t.w[pl][2], t.w[pl][3]);     // -> k-steps 1 and 3
+    }
+    swap_halves(t.a[0], t.a[2]);                 // -> k-step 0 low, k-step 2 low
+    swap_halves(t.a[1], t.a[3]);
+    swap_halves(t.a[4], t.a[6]);                 // -> k-step 1 low, k-step 3 low
+    swap_halves(t.a[5], t.a[7]);
+}
+
+__device__ __forceinline__ void skinny_mfma(const uint4& u0, const uint4& u1, const uint4& u2, const f32x4& lo, const f32x4& hi, f32x16& c) {
+    bf16x8 a[3];
+    split_frag(lo, hi, a);
+    const bf16x8 w0 = __builtin_bit_cast(bf16x8, u0), w1 = __builtin_bit_cast(bf16x8, u1), w2 = __builtin_bit_cast(bf16x8, u2);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a[2], c, 0, 0, 0);       // the tiled kernels' order (weights as operand A)
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, a[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a[0], c, 0, 0, 0);
+}
+// four k-steps of a chunk, in k order
+__device__ __forceinline__ void skinny_chunk(SkinnyChunk& t, f32x16& c) {
+    skinny_fix(t);
+    skinny_mfma(t.w[0][0], t.w[1][0], t.w[2][0], t.a[0], t.a[1], c);
+    skinny_mfma(t.w[0][2], t.w[1][2], t.w[2][2], t.a[4], t.a[5], c);
+    skinny_mfma(t.w[0][1], t.w[1][1], t.w[2][1], t.a[2], t.a[3], c);
+    skinny_mfma(t.w[0][3], t.w[1][3], t.w[2][3], t.a[6], t.a[7], c);
+}
+
+// Helper workgroups (blockIdx.x >= n_work): a gated GEMM at M <= 32 occupies 16 of the 256 CUs.  The idle CUs sweep the launch's
+// weight planes once, in whole 1 KiB wave reads, which brings them into the memory-side Infinity Cache just ahead of the
+// compute waves (the data itself is discarded).
+__device__ __forceinline__ void skinny_prefetch(const GemmParams& p, int helper, int n_helpers, int tid) {
+    unsigned sink = 0;
+    for (int s = 0; s < p.nsrc; ++s) {
+        const GemmSrc& src = p.src[s];
+        const long bytes = (long)p.N * src.ldw * 2;                      // one plane's rows [0, N)
+        for (int pl = 0; pl < 3; ++pl) {
+            const char* base = reinterpret_cast<const char*>(src.Wp + pl * src.wp_plane);
+            for (long off = ((long)helper * 128 + tid) * 16; off < bytes; off += (long)n_helpers * 2048 * 4) {
+                uint4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long o = off + (long)u * n_helpers * 2048;
+                    v[u] = o < bytes ? *reinterpret_cast<const uint4*>(base + o) : uint4{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sink ^= v[u].x ^ v[u].w;
+            }
+        }
+    }
+    if (sink == 0x9e3779b9u && p.M < 0) p.out[0] = 0.f;                   // never true: keeps the loads alive
+}
+
+template <int EPI>
+__global__ __launch_bounds__(128) void gemm_bf16x3_skinny_kernel(const GemmParams p, int n_col_wgs, int n_work) {
+    __shared__ __attribute__((aligned(16))) float xch[64 * 16];          // gate: the sigmoid block's 16 values per lane
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= n_work) {
+        skinny_prefetch(p, (int)blockIdx.x - n_work, (int)gridDim.x - n_work, tid);
+        return;
+    }
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const long m0 = (long)((int)blockIdx.x / n_col_wgs) * 32;
+    const int n0 = ((int)blockIdx.x % n_col_wgs) * 64;                   // two 32-column blocks per workgroup
+    const int nb0 = n0 + 32 * wave;                                      // this wave's block
+    long m = m0 + r;
+    const bool m_ok = m < p.M;
+    if (!m_ok) m = p.M - 1;                                              // clamped rows / columns only feed masked outputs
+    int nrow = nb0 + r;
+    if (nrow >= p.N) nrow = p.N - 1;
+
+    f32x16 c;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) c[e] = 0.f;
+    SkinnyCursor cur;
+    cur.open(p, 0, m, nrow, h);
+    // two chunks (eight k-steps) in flight behind the one being multiplied; every K is a multiple of 64 here (launch check).
+    // The steady state has no branch around a load: with one the compiler's wait insertion falls back to vmcnt(0) before every
+    // use, i.e. one full memory latency per chunk.
+    int chunks = 0;
+    for (int s2 = 0; s2 < p.nsrc; ++s2) chunks += p.src[s2].K >> 6;
+    SkinnyChunk q0, q1, q2;
+    if (chunks >= 3) {
+        cur.load(p, m, nrow, h, q0);
+        cur.load(p, m, nrow, h, q1);
+        cur.load(p, m, nrow, h, q2);
+        int t = 0;
+        for (; t + 6 <= chunks; t += 3) {
+            skinny_chunk(q0, c); cur.load(p, m, nrow, h, q0);
+            skinny_chunk(q1, c); cur.load(p, m, nrow, h, q1);
+            skinny_chunk(q2, c); cur.load(p, m, nrow, h, q2);
+        }
+        const int rem = chunks - t - 3;                                  // 0 .. 2 chunks not yet loaded
+        skinny_chunk(q0, c); if (rem > 0) cur.load(p, m, nrow, h, q0);
+        skinny_chunk(q1, c); if (rem > 1) cur.load(p, m, nrow, h, q1);
+        skinny_chunk(q2, c);
+        if (rem > 0) skinny_chunk(q0, c);
+        if (rem > 1) skinny_chunk(q1, c);
+    } else {
+        if (chunks > 0) cur.load(p, m, nrow, h, q0);
+        if (chunks > 1) cur.load(p, m, nrow, h, q1);
+        if (chunks > 0) skinny_chunk(q0, c);
+        if (chunks > 1) skinny_chunk(q1, c);
+    }
+    // ---- epilogues: lane <-> row m, registers 4g..4g+3 <-> four consecutive columns nb0 + 8g + 4h (gemm_common.h,
+    // gemm_epilogue_t_at: the same arithmetic in the same order)
+    m = m0 + r;
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_RESID) {
+        if (!m_ok) return;
+        const bool vec_ok = (p.N % 4 == 0) && (p.ldo % 4 == 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = nb0 + 8 * g + 4 * h;
+            if (n >= p.N) continue;
+            f32x4 v = {c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
+            if (vec_ok && n + 3 < p.N) {
+                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                if constexpr (EPI == EPI_RESID) v += *reinterpret_cast<const f32x4*>(p.resid + m * p.ldr + n);
+                if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                *reinterpret_cast<f32x4*>(p.out + m * p.ldo + n) = v;
+            } else {
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    if (n + cc >= p.N) continue;
+                    float x = v[cc] + (p.bias ? p.bias[n + cc] : 0.f);
+                    if constexpr (EPI == EPI_RESID) x += p.resid[m * p.ldr + n + cc];
+                    if (p.relu) x = fmaxf(x, 0.f);
+                    p.out[m * p.ldo + n + cc] = x;
+                }
+            }
+        }
+    } else if constexpr (EPI == EPI_GATE) {
+        // wave 0 holds the tanh channels na = n0 + ..., wave 1 their sigmoid partners nb = na + 32 (gate-packed order)
+        f32x4 mine[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            mine[g] = f32x4{c[4 * g], c[4 * g + 1], c[4 * g + 2], c[4 * g + 3]};
+            const int n = nb0 + 8 * g + 4 * h;
+            if (p.bias) mine[g] += *reinterpret_cast<const f32x4*>(p.bias + n);
+            if (p.pre && m_ok) *reinterpret_cast<f32x4*>(p.pre + m * p.ldpre + n) = mine[g];
+        }
+        if (wave == 1) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(xch + (g * 64 + lane) * 4) = mine[g];
+        }
+        __syncthreads();
+        if (wave == 0 && m_ok) {
+            const float* crow = p.cls ? p.cls + (long)p.label[m] * p.N : nullptr;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = 8 * g + 4 * h;
+                const int na = n0 + nl, nb = na + 32;
+                const int co = (n0 >> 1) + nl;                            // natural output channels
+                f32x4 a = mine[g];
+                f32x4 gg = *reinterpret_cast<const f32x4*>(xch + (g * 64 + lane) * 4);
+                if (crow) {
+                    a += *reinterpret_cast<const f32x4*>(crow + na);
+                    gg += *reinterpret_cast<const f32x4*>(crow + nb);
+                }
+                f32x4 o;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) o[qq] = tanhf(a[qq]) * sigmoidf_(gg[qq]);
+                *reinterpret_cast<f32x4*>(p.out + m * p.ldo + co) = o;
+            }
+        }
+    }
+}
+
+constexpr long SKINNY_MAX_M = 256;     // above this the tiled kernels win (every 32-row block re-reads the weight panel from L2)
+
+template <int EPI>
+int launch_skinny(const GemmParams& p, hipStream_t stream) {
+    static const char* const names[] = {"gemm_bias", "gemm_resid", "gemm_gate"};
+    double ksum = 0;
+    for (int s = 0; s < p.nsrc; ++s) ksum += p.src[s].K;
+    {
+        DVQ_PROF(names[EPI], 2.0 * (double)p.M * p.N * ksum, ((double)p.M + p.N) * ksum * 4, stream);
+        const int n_col = (int)((p.N + 63) / 64), n_work = n_col * (int)((p.M + 31) / 32);
+        // helpers only where most of the chip would idle AND the panel is worth it (>= 1 MB of planes)
+        const bool big = 6.0 * p.N * ksum >= 1.0e6;
+        const int helpers = (dvq_knobs().gemm_skinny_prefetch && big && n_work <= 64) ? 192 : 0;
+        DVQ_LAUNCH((gemm_bf16x3_skinny_kernel<EPI>), dim3((unsigned)(n_work + helpers)), dim3(128), 0, stream, p, n_col, n_work);
+    }
+    DVQ_CHECK_LAUNCH("gemm_bf16x3_skinny");
+    return DVQ_OK;
+}
+
 __global__ void split_bf16x3_kernel(const float* __restrict__ w, long n, uint16_t* __restrict__ planes) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -748,6 +1014,17 @@ int dvq_launch_gemm_bf16x3(const GemmParams& p, GemmEpilogue epi, hipStream_t st
         for (int s = 0; s < p.nsrc; ++s)
             aligned = aligned && ((reinterpret_cast<uintptr_t>(p.src[s].Wp) & 15) == 0) && (p.src[s].wp_plane % 8 == 0) &&
                       (p.src[s].ldw % 8 == 0);
+        if (aligned && dvq_knobs().gemm_skinny && p.M <= SKINNY_MAX_M) {
+            bool a_ok = true;                      // 16-byte activation loads; the gate's two blocks need N % 64 == 0
+            for (int s = 0; s < p.nsrc; ++s)
+                a_ok = a_ok && ((reinterpret_cast<uintptr_t>(p.src[s].A) & 15) == 0) && (p.src[s].lda % 4 == 0) && (p.src[s].K % 64 == 0);
+            if (a_ok) switch (epi) {
+                case EPI_BIAS: return launch_skinny<EPI_BIAS>(p, stream);
+                case EPI_RESID: return launch_skinny<EPI_RESID>(p, stream);
+                case EPI_GATE: if (p.N % 64 == 0) return launch_skinny<EPI_GATE>(p, stream); break;
+                default: break;
+            }
+        }
         // 128 x 256 tiles where they fill the chip (N = 256 leaves one tile column: the 128 x 128 kernel is faster there)
         const bool use_wide = dvq_knobs().gemm_wide != 0;
         if (aligned && use_wide && p.N % 256 == 0 && p.N >= 512) {

@@ -904,3 +904,33 @@ def test_default_noise_is_fresh_per_call_and_follows_manual_seed():
     assert not torch.equal(a1["codes"], a2["codes"])
     n = ops.exp1_noise(5, 30, 1, device=DEV)
     assert tuple(n.shape) == (5, 30) and n.is_contiguous() and torch.equal(n, ops.exp1_noise(5, 32, 1, device=DEV)[:, :30])
+
+
+def test_skinny_gemm_equals_tiled_kernels_bitwise():
+    """Small M (the reference's B = 1 / 8 / 100 call pattern) runs the per-wave 32 x 32 kernel; it issues the tiled kernels' MFMA
+    sequence, so bias / ReLU, residual, multi-source and gated results (the whole PixelCNN forward) must be bit-identical with
+    DVQ_GEMM_SKINNY=0, and a batch must equal its rows computed one by one."""
+    from dvqvae_amd.network.pixelcnn.models import GatedPixelCNN
+    torch.manual_seed(5)
+
+    def run():
+        out = {}
+        for (M, N, K) in ((1, 9, 256), (5, 55, 256), (32, 512, 512), (33, 1024, 1024), (100, 2048, 512), (256, 128, 1024), (7, 6, 128)):
+            g = torch.Generator().manual_seed(M * 1000 + N)
+            x = gpu(torch.randn(M, K, generator=g)); w = gpu(torch.randn(N, K, generator=g) * 0.05); b = gpu(torch.randn(N, generator=g))
+            out[f"lin{M}x{N}x{K}"] = ops.linear(x, w, b, relu=True, planes=packing.split_bf16x3(w))
+            x2 = gpu(torch.randn(M, 64, generator=g)); w2 = gpu(torch.randn(N, 64, generator=g))
+            out[f"multi{M}x{N}"] = ops.linear_multi([(x, w), (x2, w2)], b, planes=[packing.split_bf16x3(w), packing.split_bf16x3(w2)])
+        net = GatedPixelCNN(512, 512, 15, 128)
+        load_synth(net, 5)
+        net = net.to(DEV)
+        g = torch.Generator().manual_seed(1)
+        x = gpu(torch.randint(0, 512, (37, 3, 3), generator=g)); lab = gpu(torch.randint(0, 128, (37,), generator=g))
+        out["logits"] = net(x, lab)
+        out["logits_row3"] = net(x[3:4], lab[3:4])
+        return out
+    a = run()
+    b = _with_env("DVQ_GEMM_SKINNY", "0", run)
+    for k in a:
+        assert torch.equal(a[k], b[k]), f"{k}: skinny kernel != tiled kernel"
+    assert torch.equal(a["logits"][3:4], a["logits_row3"])
