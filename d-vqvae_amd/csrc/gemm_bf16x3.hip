@@ -776,9 +776,7 @@ __device__ __forceinline__ void skinny_fix(SkinnyChunk& t) {
     swap_halves(t.a[5], t.a[7]);
 }
 
-__device__ __forceinline__ void skinny_mfma(const uint4& u0, const uint4& u1, const uint4& u2, const f32x4& lo, const f32x4& hi, f32x16& c) {
-    bf16x8 a[3];
-    split_frag(lo, hi, a);
+__device__ __forceinline__ void skinny_mfma(const uint4& u0, const uint4& u1, const uint4& u2, const bf16x8 (&a)[3], f32x16& c) {
     const bf16x8 w0 = __builtin_bit_cast(bf16x8, u0), w1 = __builtin_bit_cast(bf16x8, u1), w2 = __builtin_bit_cast(bf16x8, u2);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a[2], c, 0, 0, 0);       // the tiled kernels' order (weights as operand A)
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, a[0], c, 0, 0, 0);
@@ -787,13 +785,45 @@ __device__ __forceinline__ void skinny_mfma(const uint4& u0, const uint4& u1, co
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a[0], c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a[0], c, 0, 0, 0);
 }
-// four k-steps of a chunk, in k order
-__device__ __forceinline__ void skinny_chunk(SkinnyChunk& t, f32x16& c) {
-    skinny_fix(t);
-    skinny_mfma(t.w[0][0], t.w[1][0], t.w[2][0], t.a[0], t.a[1], c);
-    skinny_mfma(t.w[0][2], t.w[1][2], t.w[2][2], t.a[4], t.a[5], c);
-    skinny_mfma(t.w[0][1], t.w[1][1], t.w[2][1], t.a[2], t.a[3], c);
-    skinny_mfma(t.w[0][3], t.w[1][3], t.w[2][3], t.a[6], t.a[7], c);
+// one dependent chain of six MFMAs; the in-order wave issues nothing between them unless it is PLACED there: the split of the
+// next k-step's activation fragment (44 vector instructions) goes into the six gaps, 1 MFMA : 8 VALU
+#define DVQ_SK_INTERLEAVE()                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {                \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);              \
+        __builtin_amdgcn_sched_group_barrier(0x2, 8, 0);              \
+    }
+// four k-steps of a chunk, in k order; `a0` = the split fragment of its first k-step (prepared under the previous chunk's last
+// MFMAs), `next` = the chunk that follows (its lane fix-up and first split are prepared under this chunk's last MFMAs)
+__device__ __forceinline__ void skinny_chunk(SkinnyChunk& t, SkinnyChunk& next, bf16x8 (&a0)[3], f32x16& c) {
+    bf16x8 a1[3], a2[3], a3[3];
+    split_frag(t.a[4], t.a[5], a1);
+    skinny_mfma(t.w[0][0], t.w[1][0], t.w[2][0], a0, c);
+    DVQ_SK_INTERLEAVE();
+    split_frag(t.a[2], t.a[3], a2);
+    skinny_mfma(t.w[0][2], t.w[1][2], t.w[2][2], a1, c);
+    DVQ_SK_INTERLEAVE();
+    split_frag(t.a[6], t.a[7], a3);
+    skinny_mfma(t.w[0][1], t.w[1][1], t.w[2][1], a2, c);
+    DVQ_SK_INTERLEAVE();
+    skinny_fix(next);
+    split_frag(next.a[0], next.a[1], a0);
+    skinny_mfma(t.w[0][3], t.w[1][3], t.w[2][3], a3, c);
+#pragma unroll
+    for (int i_ = 0; i_ < 6; ++i_) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x2, 14, 0);
+    }
+}
+// the same without a successor
+__device__ __forceinline__ void skinny_chunk_last(SkinnyChunk& t, bf16x8 (&a0)[3], f32x16& c) {
+    bf16x8 a1[3], a2[3], a3[3];
+    split_frag(t.a[4], t.a[5], a1);
+    skinny_mfma(t.w[0][0], t.w[1][0], t.w[2][0], a0, c);
+    split_frag(t.a[2], t.a[3], a2);
+    skinny_mfma(t.w[0][2], t.w[1][2], t.w[2][2], a1, c);
+    split_frag(t.a[6], t.a[7], a3);
+    skinny_mfma(t.w[0][1], t.w[1][1], t.w[2][1], a2, c);
+    skinny_mfma(t.w[0][3], t.w[1][3], t.w[2][3], a3, c);
 }
 
 // Helper workgroups (blockIdx.x >= n_work): a gated GEMM at M <= 32 occupies 16 of the 256 CUs.  The idle CUs sweep the launch's
@@ -852,27 +882,35 @@ __global__ __launch_bounds__(128) void gemm_bf16x3_skinny_kernel(const GemmParam
     int chunks = 0;
     for (int s2 = 0; s2 < p.nsrc; ++s2) chunks += p.src[s2].K >> 6;
     SkinnyChunk q0, q1, q2;
+    bf16x8 a0[3];
     if (chunks >= 3) {
         cur.load(p, m, nrow, h, q0);
         cur.load(p, m, nrow, h, q1);
         cur.load(p, m, nrow, h, q2);
+        skinny_fix(q0);
+        split_frag(q0.a[0], q0.a[1], a0);
         int t = 0;
         for (; t + 6 <= chunks; t += 3) {
-            skinny_chunk(q0, c); cur.load(p, m, nrow, h, q0);
-            skinny_chunk(q1, c); cur.load(p, m, nrow, h, q1);
-            skinny_chunk(q2, c); cur.load(p, m, nrow, h, q2);
+            // q0's successor q1 is already in flight; q0 itself is re-loaded only AFTER q1's fix-up has read ... nothing of q0
+            skinny_chunk(q0, q1, a0, c); cur.load(p, m, nrow, h, q0);
+            skinny_chunk(q1, q2, a0, c); cur.load(p, m, nrow, h, q1);
+            // q2's successor is the q0 just loaded: its fix-up waits for that load (two chunks of MFMAs behind it)
+            skinny_chunk(q2, q0, a0, c); cur.load(p, m, nrow, h, q2);
         }
-        const int rem = chunks - t - 3;                                  // 0 .. 2 chunks not yet loaded
-        skinny_chunk(q0, c); if (rem > 0) cur.load(p, m, nrow, h, q0);
-        skinny_chunk(q1, c); if (rem > 1) cur.load(p, m, nrow, h, q1);
-        skinny_chunk(q2, c);
-        if (rem > 0) skinny_chunk(q0, c);
-        if (rem > 1) skinny_chunk(q1, c);
+        const int rem = chunks - t - 3;                                  // 0 .. 2 chunks not yet loaded; q0 is fixed and split
+        skinny_chunk(q0, q1, a0, c); if (rem > 0) cur.load(p, m, nrow, h, q0);
+        skinny_chunk(q1, q2, a0, c); if (rem > 1) cur.load(p, m, nrow, h, q1);
+        if (rem > 0) {
+            skinny_chunk(q2, q0, a0, c);
+            if (rem > 1) { skinny_chunk(q0, q1, a0, c); skinny_chunk_last(q1, a0, c); }
+            else skinny_chunk_last(q0, a0, c);
+        } else skinny_chunk_last(q2, a0, c);
     } else {
         if (chunks > 0) cur.load(p, m, nrow, h, q0);
         if (chunks > 1) cur.load(p, m, nrow, h, q1);
-        if (chunks > 0) skinny_chunk(q0, c);
-        if (chunks > 1) skinny_chunk(q1, c);
+        if (chunks > 0) { skinny_fix(q0); split_frag(q0.a[0], q0.a[1], a0); }
+        if (chunks > 1) { skinny_chunk(q0, q1, a0, c); skinny_chunk_last(q1, a0, c); }
+        else if (chunks > 0) skinny_chunk_last(q0, a0, c);
     }
     // ---- epilogues: lane <-> row m, registers 4g..4g+3 <-> four consecutive columns nb0 + 8g + 4h (gemm_common.h,
     // gemm_epilogue_t_at: the same arithmetic in the same order)
