@@ -43,6 +43,7 @@
 //       sinks it to the end of the loop body, behind every MFMA);
 //   (3) __builtin_bit_cast applied directly to a vector-element expression reads element 0: copy the element out first.
 #include "dvq_internal.h"
+#include "vq_pack.h"
 #include <type_traits>
 
 namespace {
@@ -76,27 +77,6 @@ constexpr int L_DBG = L_CNT + 64;                          // [8 waves][32] u32 
 constexpr int LDS_BYTES = L_DBG + NWV * 32 * 4;
 constexpr int DBG_WG_BYTES = 64 + NWV * 32 * 4;            // per-workgroup debug record in the workspace
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-
-struct PackHeader {
-    float emax;        // upper bound of max_k |e_k|_2 (inf if the codebook is not finite)
-    int sexp;          // codebook scale sE = 2^sexp
-    int valid;         // 0: codebook magnitudes outside the filter's range -> every row takes the exact path
-    int K, D;
-    float demax;       // upper bound of max_k |e_k - image_k / (-2 sE)|_2: the image's MEASURED fp16 rounding error
-    int layout;        // 3: image in MFMA-fragment order (below)
-};
-constexpr size_t PK_OFF_EE = 256;                          // [K] f32 canonical |e_k|^2
-constexpr size_t PK_OFF_IMG = PK_OFF_EE + (size_t)K * 4;   // fp16 image, fragment order
-constexpr size_t PK_BYTES = PK_OFF_IMG + (size_t)K * D * 2;
-
-__device__ __forceinline__ float pow2f(int e) { return __int_as_float((e + 127) << 23); }   // e in [-126, 127]
-
-// image position (in fp16 elements) of dim j of entry k: fragment f = ((w*2 + jn)*16 + s), lane = 32 h + r, element e
-//   k = 64 w + 32 jn + r,  j = 16 s + 8 h + e      (lane l of wave w loads 16 B at f*1024 + 16 l: coalesced)
-__host__ __device__ __forceinline__ int img_pos(int k, int j) {
-    const int w = k >> 6, jn = (k >> 5) & 1, r = k & 31, s = j >> 4, h = (j >> 3) & 1, e = j & 7;
-    return ((((w * 2 + jn) * 16 + s) * 64 + (h * 32 + r)) << 3) + e;
-}
 
 // ------------------------------------------------------------------------------------------------ pack
 __global__ void vq_pack_norm_kernel(const float* __restrict__ E, float* __restrict__ ee, PackHeader* hdr) {
@@ -934,6 +914,18 @@ extern "C" int dvq_vq_argmin_fast(const float* z, const float* E, const void* pa
         }
     }
     const char* pk = (const char*)packed;
+    // default: the four-wave kernel (vq_stream4.hip: one wave per SIMD, codebook in the accumulator registers); DVQ_VQ_KERNEL=8
+    // keeps this file's eight-wave kernel (and the diagnostics build's stamps / ablations, which exist for it only)
+    bool four = dvq_knobs().vq_kernel != 8;
+    unsigned long long* dbg4 = nullptr;
+#ifdef DVQ_DIAG
+    if (getenv("DVQ_VQ_DBG") || getenv("DVQ_VQ_ABL")) four = false;
+    if (getenv("DVQ_VQ4_DBG")) dbg4 = (unsigned long long*)workspace;            // 1024 x 64 B fit the debug workspace
+#endif
+    if (four) {
+        DVQ_PROF("vq_argmin_fast", 2.0 * M * K * D, (double)M * D * 4 + (double)K * D * 4 + (double)M * 8, st);
+        return dvq_launch_vq_stream4(z, E, packed, (long)M, idx, slow_rows, dbg4, st);
+    }
     const int cus = device_cus();
     const long tiles = (M + TILE - 1) / TILE;
     const long per_launch = (long)cus * MAX_TILES;                 // one workgroup per CU, <= MAX_TILES tiles each
