@@ -42,14 +42,17 @@ constexpr int MS_BUF = TILE * MS_ROW;
 constexpr int PAIR_CAP = 2048;
 
 constexpr int L_Z16 = 0;                                   // 2 x fp16 tile
-constexpr int L_MS = L_Z16 + 2 * Z16_BUF;                  // 3 x merge slots (tile % 3)
-constexpr int L_RS = L_MS + 3 * MS_BUF;                    // 4 x [32] {eps sE, flag}
+constexpr int L_MS = L_Z16 + 2 * Z16_BUF;                  // (MAX_TILES + 1) x merge slots: local tiles -1 .. 7, kept until the tail
+constexpr int L_RS = L_MS + (MAX_TILES + 1) * MS_BUF;      // 4 x [32] {eps sE, flag}
 constexpr int L_EES = L_RS + 4 * TILE * 8;                 // [K] f32: sE |e_k|^2 (accumulator start values)
 constexpr int L_RES = L_EES + K * 4;                       // [MAX_TILES*32] u64 row results (ordered distance bits : entry)
 constexpr int L_PAIR = L_RES + MAX_TILES * TILE * 8;       // [PAIR_CAP] u32 (rowslot << 16 | entry)
 constexpr int L_SLOW = L_PAIR + PAIR_CAP * 4;              // [MAX_TILES*32] u16 rowslots for the all-entries path
-constexpr int L_CNT = L_SLOW + MAX_TILES * TILE * 2;       // [0] pairs, [1] rows for the all-entries path, [2] rows with >= 32 pairs
-constexpr int LDS_BYTES = L_CNT + 64;
+constexpr int L_CNT = L_SLOW + MAX_TILES * TILE * 2;       // [0] pairs, [1] rows for the all-entries path, [2] rows with >= 32 pairs,
+                                                           // [4 + w] undecided rows of wave w
+constexpr int L_REC = L_CNT + 64;                          // [MAX_TILES*32] {threshold, flags} of every row (merge -> tail)
+constexpr int L_UND = L_REC + MAX_TILES * TILE * 8;        // [NWV][64] u16 rowslots of the rows the merge could not decide
+constexpr int LDS_BYTES = L_UND + NWV * 64 * 2;
 static_assert(LDS_BYTES <= 160 * 1024 && L_MS % 16 == 0 && L_RS % 16 == 0 && L_EES % 16 == 0, "LDS layout");
 
 // ------------------------------------------------------------------------------------------------ LDS access by hand
@@ -197,6 +200,9 @@ __device__ __forceinline__ void chain_pair(const float* __restrict__ zr, const f
 }
 
 // ------------------------------------------------------------------------------------------------ the kernel's pieces
+// Everything below is cut into pieces of a few vector instructions: the generated tile body puts ONE piece into an MFMA gap
+// (a gap hides ~6 vector instructions; a 40-instruction piece in one gap is 150 exposed cycles).  Lane-constant parts of every
+// address are computed once before the loop.
 struct Ctx {
     const float* z;
     long M;
@@ -206,16 +212,56 @@ struct Ctx {
     unsigned lds0;
     float emax, demax, sEf;
     bool e_valid;
+    // lane-constant address parts
+    unsigned zw[2];        // fp16 image, buffer 0: this lane's 8 bytes of row 8 wave + 4 pass + g   (+ 128 Q, + buffer)
+    unsigned rsw[2];       // row statistics of that row, table 0                                      (+ table)
+    unsigned slotw;        // merge slots of row lane % 32, slot group (wave, lane half), buffer 0   (+ 8 block, + buffer)
+    unsigned mrd, rsr;     // merge: the lane's four slots of row 8 wave + lane / 8, buffer 0; that row's statistics, table 0
+    const float* rp[2];    // next rows to load (pass 0 / 1): advanced by one tile stride per load
+    long rstride;          // floats between a workgroup's consecutive tiles
 };
 
-// rows 8 wave + 4 pass + g of local tile j, HBM -> registers: lane (g = lane / 16, i = lane % 16) takes floats 4 (i + 16 q) .. +3
-__device__ __forceinline__ void load_rows(const Ctx& c, int j, int pass, f32x4 (&x)[4]) {
+// scalar (wave-uniform) per-tile offsets
+__device__ __forceinline__ unsigned ms_buf(int t) { return (unsigned)((t + 1) * MS_BUF); }
+__device__ __forceinline__ unsigned rs_tab(int t) { return (unsigned)((t & 3) * (TILE * 8)); }
+
+// rows 8 wave + 4 pass + g of the workgroup's NEXT tile to load, HBM -> registers (lane (g, i): floats 4 (i + 16 q) .. +3);
+// `full`: the tile lies inside the data (wave-uniform); otherwise rows behind the end repeat the last row
+__device__ __forceinline__ void load_rows(Ctx& c, int pass, int j, f32x4 (&x)[4]) {
     const long tile = c.tile0 + (long)blockIdx.x + (long)j * c.G;
-    long gr = tile * TILE + c.wave * 8 + pass * 4 + (c.lane >> 4);
-    if (gr >= c.M) gr = c.M - 1;
-    const f32x4* p = reinterpret_cast<const f32x4*>(c.z + gr * D) + (c.lane & 15);
+    const bool full = (tile + 1) * TILE <= c.M;
+    const f32x4* p = reinterpret_cast<const f32x4*>(c.rp[pass]);
+    if (!full) {
+        long gr = tile * TILE + c.wave * 8 + pass * 4 + (c.lane >> 4);
+        if (gr >= c.M) gr = c.M - 1;
+        p = reinterpret_cast<const f32x4*>(c.z + gr * D) + (c.lane & 15);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) x[q] = __builtin_nontemporal_load(p + 16 * q);
+    c.rp[pass] += c.rstride;
+}
+
+// The same inside the tile loop, hand-issued: the compiler's own wait for a row loaded a tile earlier is vmcnt(3) / vmcnt(0) --
+// it also waits for the OTHER pass's younger loads, issued a third of a tile ago -- so these loads are asm and the generated
+// body waits with the counts of the loads' program order.  Rule: the destination registers are pinned ("+v") by the wait.
+template <int OFF>
+__device__ __forceinline__ void gld128(f32x4& d, const f32x4* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(d) : "v"(p), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void load_rows_asm(Ctx& c, int pass, int j, f32x4 (&x)[4]) {
+    const long tile = c.tile0 + (long)blockIdx.x + (long)j * c.G;
+    const bool full = (tile + 1) * TILE <= c.M;
+    const f32x4* p = reinterpret_cast<const f32x4*>(c.rp[pass]);
+    if (!full) {
+        long gr = tile * TILE + c.wave * 8 + pass * 4 + (c.lane >> 4);
+        if (gr >= c.M) gr = c.M - 1;
+        p = reinterpret_cast<const f32x4*>(c.z + gr * D) + (c.lane & 15);
+    }
+    gld128<0>(x[0], p);
+    gld128<256>(x[1], p);
+    gld128<512>(x[2], p);
+    gld128<768>(x[3], p);
+    c.rp[pass] += c.rstride;
 }
 
 // scores of accumulator registers [B, E): register index in the low 5 mantissa bits, lane-local top-2 update
@@ -234,7 +280,7 @@ __device__ __forceinline__ void write_slot(const Ctx& c, int t, float m1, float 
     f32x2 v;
     v[0] = m1;
     v[1] = m2;
-    ds_wr64<8 * BLK>(c.lds0 + L_MS + ((t + 3) % 3) * MS_BUF + (c.lane & 31) * MS_ROW + (2 * c.wave + (c.lane >> 5)) * 32, v);
+    ds_wr64<8 * BLK>(c.slotw + ms_buf(t), v);
 }
 
 template <int HI>
@@ -248,14 +294,18 @@ __device__ __forceinline__ float mix_diff(float hp, float x) {
 #ifndef DVQ_MEASURE_DZ
 #define DVQ_MEASURE_DZ 1   // 1: |z - h(z)| measured element by element; 0: half-ulp bound (fewer vector instructions, ~1.5x the pairs)
 #endif
-// fp32 -> fp16 conversion of 4 of the wave's rows (one pass) in pieces: one piece per MFMA gap
+// fp32 -> fp16 conversion of 4 of the wave's rows (one pass), staged
 struct Convert {
-    float hh, dsq;
+    float hh, dsq, hn, dzn, eps;
     f32x2 pk;
-    __device__ __forceinline__ void start() { hh = 0.f; dsq = 0.f; }
+    unsigned za;                                                          // image address of this pass in the tile being written
+    __device__ __forceinline__ void start(const Ctx& c, int j, int pass) {
+        hh = 0.f;
+        dsq = 0.f;
+        za = c.zw[pass] + (unsigned)((j & 1) * Z16_BUF);
+    }
     template <int Q>
-    __device__ __forceinline__ void cvt(const Ctx& c, int j, int pass, const f32x4 (&x)[4]) {
-        const int g = c.lane >> 4, i = c.lane & 15;
+    __device__ __forceinline__ void cvt(const f32x4 (&x)[4]) {
         f32x2 a, b;
         a[0] = x[Q][0]; a[1] = x[Q][1]; b[0] = x[Q][2]; b[1] = x[Q][3];
         const f16x2 lo = __builtin_convertvector(a, f16x2), hi = __builtin_convertvector(b, f16x2);
@@ -263,79 +313,128 @@ struct Convert {
         hh = __builtin_amdgcn_fdot2(hi, hi, hh, false);
         pk[0] = __builtin_bit_cast(float, lo);
         pk[1] = __builtin_bit_cast(float, hi);
-        ds_wr64<128 * Q>(c.lds0 + L_Z16 + (j & 1) * Z16_BUF + (c.wave * 8 + pass * 4 + g) * Z16_ROW + 8 * i, pk);
+        ds_wr64<128 * Q>(za, pk);
     }
-    template <int Q>
-    __device__ __forceinline__ void err(float lo_hi0, float lo_hi1, const f32x4 (&x)[4]) {
+    template <int Q, int HALF>
+    __device__ __forceinline__ void err(const f32x2& p, const f32x4 (&x)[4]) {     // rounding error of two of quad Q's four elements
         if (DVQ_MEASURE_DZ) {
-            const float d0 = mix_diff<0>(lo_hi0, x[Q][0]), d1 = mix_diff<1>(lo_hi0, x[Q][1]);
-            const float d2 = mix_diff<0>(lo_hi1, x[Q][2]), d3 = mix_diff<1>(lo_hi1, x[Q][3]);
-            dsq = fmaf(d0, d0, dsq); dsq = fmaf(d1, d1, dsq); dsq = fmaf(d2, d2, dsq); dsq = fmaf(d3, d3, dsq);
+            const float d0 = mix_diff<0>(p[HALF], x[Q][2 * HALF]), d1 = mix_diff<1>(p[HALF], x[Q][2 * HALF + 1]);
+            dsq = fmaf(d0, d0, dsq);
+            dsq = fmaf(d1, d1, dsq);
         }
     }
-    __device__ __forceinline__ void finish(const Ctx& c, int j, int pass) {      // hh, dsq already reduced over the row's 16 lanes
-        const int g = c.lane >> 4, i = c.lane & 15;
-        const float hn = __builtin_amdgcn_sqrtf(hh);
-        const float dzn = DVQ_MEASURE_DZ ? __builtin_amdgcn_sqrtf(dsq) * 1.0001f : hn * 4.8877e-4f + 4.8e-7f;
-        const float zn = (hn + dzn) * 1.0001f;
-        const float eps = 4.004f * (dzn * c.emax + zn * c.demax + dzn * c.demax) + 1.01e-4f * (zn + c.emax) * (zn + c.emax);
+    __device__ __forceinline__ void sum_hh() { hh = row16_sum(hh); }
+    __device__ __forceinline__ void sum_dsq() { if (DVQ_MEASURE_DZ) dsq = row16_sum(dsq); }
+    __device__ __forceinline__ void fin_a() {
+        hn = __builtin_amdgcn_sqrtf(hh);
+        // |z - h(z)|: measured, or a priori (half an ulp of a normal fp16 is at most 2^-11 |h|, of a subnormal one 2^-25)
+        dzn = DVQ_MEASURE_DZ ? __builtin_amdgcn_sqrtf(dsq) * 1.0001f : hn * 4.8877e-4f + 4.8e-7f;
+    }
+    __device__ __forceinline__ void fin_b(const Ctx& c) {
+        const float zn = (hn + dzn) * 1.0001f;                          // |z| <= |h(z)| + |z - h(z)|
+        const float u = zn + c.emax;
+        eps = 4.004f * (dzn * c.emax + zn * c.demax + dzn * c.demax) + 1.01e-4f * u * u;
+    }
+    __device__ __forceinline__ void fin_c(const Ctx& c, int j, int pass) {
         const float epsS = eps * c.sEf;
-        const bool bad = !c.e_valid || !(hh <= 3.0e38f) || !(dsq <= 3.0e38f) || !(epsS <= 3.0e38f);
-        if (i == 0) {
+        const bool bad = !c.e_valid || !(hh <= 3.0e38f) || !(dsq <= 3.0e38f) || !(epsS <= 3.0e38f);   // NaN/Inf, fp16 overflow
+        if ((c.lane & 15) == 0) {
             f32x2 rs;
             rs[0] = epsS;
             rs[1] = __uint_as_float(bad ? 1u : 0u);
-            ds_wr64<0>(c.lds0 + L_RS + (j & 3) * (TILE * 8) + (c.wave * 8 + pass * 4 + g) * 8, rs);
+            ds_wr64<0>(c.rsw[pass] + rs_tab(j), rs);
         }
     }
 };
 
-// merge of a tile: this wave's rows 8 wave + g (g = lane / 8), 8 lanes per row; lane i looks at the four slots (blocks 0..3) of
-// (source wave i / 2, lane half i % 2), i.e. at 4 x 16 codebook entries
+// merge of a tile, staged: this wave's rows 8 wave + g (g = lane / 8), 8 lanes per row; lane i looks at the four slots (blocks
+// 0..3) of (source wave i / 2, lane half i % 2), i.e. at 4 x 16 codebook entries
 struct Merge {
     f32x4 s0, s1;                                                       // (m1, m2) of blocks 0, 1 | blocks 2, 3
     f32x2 rs;
     float thr;
+    int c1, c2, n1, n2;
     __device__ __forceinline__ void read(const Ctx& c, int tm) {
-        const int r = 8 * c.wave + (c.lane >> 3), i = c.lane & 7;
-        const unsigned a = c.lds0 + L_MS + ((tm + 3) % 3) * MS_BUF + r * MS_ROW + i * 32;
+        const unsigned a = c.mrd + ms_buf(tm);
         ds_rd128<0>(s0, a);
         ds_rd128<16>(s1, a);
-        ds_rd64<0>(rs, c.lds0 + L_RS + (tm & 3) * (TILE * 8) + r * 8);
+        ds_rd64<0>(rs, c.rsr + rs_tab(tm));
     }
     __device__ __forceinline__ void min_a() {                            // after the wait that pins s0, s1, rs
         thr = min_nc(min_nc(s0[0], s0[2]), min_nc(s1[0], s1[2]));
         thr = min_nc(thr, dpp_f<0xB1>(thr));
-        thr = min_nc(thr, dpp_f<0x4E>(thr));
     }
     __device__ __forceinline__ void min_b() {
+        thr = min_nc(thr, dpp_f<0x4E>(thr));
         thr = min_nc(thr, dpp_f<0x141>(thr));
         thr = thr + rs[0];
     }
-    __device__ __forceinline__ void act(const Ctx& c, int tm) {
-        const int g = c.lane >> 3, i = c.lane & 7;
-        const int r = 8 * c.wave + g;
-        const bool a0 = s0[0] <= thr, b0 = s0[1] <= thr, a1 = s0[2] <= thr, b1 = s0[3] <= thr;
-        const bool a2 = s1[0] <= thr, b2 = s1[1] <= thr, a3 = s1[2] <= thr, b3 = s1[3] <= thr;
-        const int c1 = (int)a0 + (int)a1 + (int)a2 + (int)a3, c2 = (int)b0 + (int)b1 + (int)b2 + (int)b3;
-        const int n1 = row8_sum(c1), n2 = row8_sum(c2);
+    __device__ __forceinline__ void count_a() { c1 = (int)(s0[0] <= thr) + (int)(s0[2] <= thr) + (int)(s1[0] <= thr) + (int)(s1[2] <= thr); }
+    __device__ __forceinline__ void count_b() { c2 = (int)(s0[1] <= thr) + (int)(s0[3] <= thr) + (int)(s1[1] <= thr) + (int)(s1[3] <= thr); }
+    __device__ __forceinline__ void sum_a() { n1 = row8_sum(c1); }
+    __device__ __forceinline__ void sum_b() { n2 = row8_sum(c2); }
+    // decisions; `rows` = rows of tile tm that exist (wave-uniform: 32 except behind the end of the data, <= 0 for "tiles" -2, -1)
+    unsigned flags;                                                     // bit 0 live, 1 slow, 2 unique, 3 ambiguous
+    unsigned rowslot;
+    __device__ __forceinline__ void act_a(const Ctx& c, int tm, int rows) {
+        const int r = 8 * c.wave + (c.lane >> 3);
         const bool bad = __float_as_uint(rs[1]) != 0u;
-        const long grow = (c.tile0 + (long)blockIdx.x + (long)tm * c.G) * TILE + r;
-        const bool live = grow < c.M && tm >= 0;                        // (the pipelined loop also merges "tiles" -2, -1)
-        const unsigned rowslot = (unsigned)(tm * TILE + r);
-        const int w_src = i >> 1, h_src = i & 1;
+        const bool live = r < rows;
         const bool slow = bad || n1 == 0;
         const bool unique = !slow && n1 == 1 && n2 == 0;
         const bool amb = live && !slow && !unique;
-        if (live && unique && c1) {
+        flags = (live ? 1u : 0u) | (slow ? 2u : 0u) | (unique ? 4u : 0u) | (amb ? 8u : 0u);
+        rowslot = (unsigned)(tm * TILE + r);
+    }
+    __device__ __forceinline__ void act_b(const Ctx& c) {               // the decided rows: the winner lane writes the entry
+        const int i = c.lane & 7;
+        if ((flags & 5u) == 5u && c1) {
+            const bool a0 = s0[0] <= thr, a1 = s0[2] <= thr, a2 = s1[0] <= thr;
             const int j = a0 ? 0 : (a1 ? 1 : (a2 ? 2 : 3));
             const float best = a0 ? s0[0] : (a1 ? s0[2] : (a2 ? s1[0] : s1[2]));
             f32x2 kv;
-            kv[0] = __uint_as_float((unsigned)entry_of(w_src, j, (int)(__float_as_uint(best) & 15u), h_src));
+            kv[0] = __uint_as_float((unsigned)entry_of(i >> 1, j, (int)(__float_as_uint(best) & 15u), i & 1));
             kv[1] = __uint_as_float(0u);
             ds_wr64<0>(c.lds0 + L_RES + rowslot * 8, kv);
         }
-        if (__ballot(live && !unique) == 0ull) return;                  // common case: every row of the wave decided
+    }
+    // every row's threshold and flags go to the row record; the rows the merge could not decide (ambiguous, or all-entries) are
+    // appended to the WAVE's own list (no atomics, no branch: the tail expands them into candidate pairs)
+    __device__ __forceinline__ void act_c(const Ctx& c, int& und) {
+        const bool lead = (c.lane & 7) == 0;
+        if (lead && (flags & 1u)) {                                      // live rows only: "tiles" -2, -1 have no record
+            f32x2 rec;
+            rec[0] = thr;
+            rec[1] = __uint_as_float(flags);
+            ds_wr64<0>(c.lds0 + L_REC + rowslot * 8, rec);
+        }
+        const bool put = lead && (flags & 1u) && !(flags & 4u);          // live and not decided
+        const unsigned long long m = __ballot(put);
+        const int pos = und + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (put && pos < 64) ds_wr16(c.lds0 + L_UND + (c.wave * 64 + pos) * 2, rowslot);
+        und += __popcll(m);
+    }
+    // tail: the undecided row `rowslot_` (8 lanes per row, as in the merge): candidate pairs / all-entries list
+    __device__ __forceinline__ void expand(const Ctx& c, unsigned rowslot_, bool valid) {
+        const int i = c.lane & 7;
+        const int tm = (int)(rowslot_ >> 5), r = (int)(rowslot_ & 31);
+        const unsigned a = c.lds0 + L_MS + ms_buf(tm) + r * MS_ROW + i * 32;
+        f32x2 rec;
+        ds_rd128<0>(s0, a);
+        ds_rd128<16>(s1, a);
+        ds_rd64<0>(rec, c.lds0 + L_REC + rowslot_ * 8);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s0), "+v"(s1), "+v"(rec));
+        thr = rec[0];
+        flags = valid ? __float_as_uint(rec[1]) : 0u;
+        rowslot = rowslot_;
+        const bool live = flags & 1u, slow = flags & 2u, amb = flags & 8u;
+        const int w_src = i >> 1, h_src = i & 1;
+        const bool a0 = s0[0] <= thr, b0 = s0[1] <= thr, a1 = s0[2] <= thr, b1 = s0[3] <= thr;
+        const bool a2 = s1[0] <= thr, b2 = s1[1] <= thr, a3 = s1[2] <= thr, b3 = s1[3] <= thr;
+        c1 = (int)a0 + (int)a1 + (int)a2 + (int)a3;
+        c2 = (int)b0 + (int)b1 + (int)b2 + (int)b3;
+        n1 = row8_sum(c1);
+        n2 = row8_sum(c2);
         // one reservation per ambiguous row (leader lane i == 0): a slot with one score within eps takes one pair, a slot whose
         // second score is within eps too (it may hide a third) takes all its 16 entries
         const int need = (n1 - n2) + 16 * n2;
@@ -344,8 +443,7 @@ struct Merge {
         pos = (unsigned)__shfl((int)pos, c.lane & ~7);
         const bool fits = pos + (unsigned)need <= (unsigned)PAIR_CAP;
         if (amb && i == 0 && fits && need >= 32) asm volatile("ds_add_u32 %0, %1" ::"v"(c.lds0 + L_CNT + 8), "v"(1u) : "memory");
-        // exclusive prefix of the lanes' pair counts within the row
-        const int mine = (c1 - c2) + 16 * c2;
+        const int mine = (c1 - c2) + 16 * c2;                            // exclusive prefix of the lanes' pair counts within the row
         int incl = mine;
 #pragma unroll
         for (int d = 1; d < 8; d <<= 1) {
@@ -373,7 +471,18 @@ struct Merge {
             ds_wr16(c.lds0 + L_SLOW + sp * 2, rowslot);
         }
     }
+    __device__ __forceinline__ void all(const Ctx& c, int tm, int rows, int& und) {   // unstaged (after the loop)
+        min_a(); min_b(); count_a(); count_b(); sum_a(); sum_b(); act_a(c, tm, rows); act_b(c); act_c(c, und);
+    }
 };
+
+// rows of local tile j that exist (wave-uniform): 32 inside the data, fewer in the last tile, <= 0 for j < 0
+__device__ __forceinline__ int rows_of(const Ctx& c, int j) {
+    if (j < 0) return 0;
+    const long first = (c.tile0 + (long)blockIdx.x + (long)j * c.G) * TILE;
+    const long left = c.M - first;
+    return left >= TILE ? TILE : (int)(left > 0 ? left : 0);
+}
 
 template <int ABL>
 __global__ __launch_bounds__(NT, 1) void vq_stream4_kernel(const float* __restrict__ z, const float* __restrict__ E, long M, long tile0,
@@ -408,9 +517,22 @@ __global__ __launch_bounds__(NT, 1) void vq_stream4_kernel(const float* __restri
     c.demax = hdr->demax;
     c.e_valid = hdr->valid != 0;
     c.sEf = c.e_valid ? pow2f(hdr->sexp) : 1.0f;
+    {
+        const int g4 = c.lane >> 4, i16 = c.lane & 15, g8 = c.lane >> 3, i8 = c.lane & 7;
+        for (int p = 0; p < 2; ++p) {
+            const int row = c.wave * 8 + p * 4 + g4;
+            c.zw[p] = c.lds0 + L_Z16 + row * Z16_ROW + 8 * i16;
+            c.rsw[p] = c.lds0 + L_RS + row * 8;
+            c.rp[p] = z + ((tile0 + (long)blockIdx.x) * TILE + row) * D + 4 * i16;
+        }
+        c.slotw = c.lds0 + L_MS + (c.lane & 31) * MS_ROW + (2 * c.wave + (c.lane >> 5)) * 32;
+        c.mrd = c.lds0 + L_MS + (8 * c.wave + g8) * MS_ROW + i8 * 32;
+        c.rsr = c.lds0 + L_RS + (8 * c.wave + g8) * 8;
+        c.rstride = (long)c.G * TILE * D;
+    }
     f32x4 x0[4], x1[4];                                                  // fp32 rows in flight: pass 0 (rows 8w..8w+3), pass 1 (8w+4..8w+7)
     load_rows(c, 0, 0, x0);
-    load_rows(c, 0, 1, x1);
+    load_rows(c, 1, 0, x1);
     for (int u = tid; u < MAX_TILES * TILE; u += NT) reinterpret_cast<unsigned long long*>(lds + L_RES)[u] = ~0ull;
     for (int u = tid; u < PAIR_CAP; u += NT) reinterpret_cast<unsigned*>(lds + L_PAIR)[u] = ~0u;
     if (tid < 3) reinterpret_cast<unsigned*>(lds + L_CNT)[tid] = 0u;
@@ -418,22 +540,19 @@ __global__ __launch_bounds__(NT, 1) void vq_stream4_kernel(const float* __restri
     reinterpret_cast<float*>(lds + L_EES)[tid + NT] = ee_g[tid + NT] * c.sEf;
     Convert cv;
     {
-        cv.start();
-        cv.cvt<0>(c, 0, 0, x0); const f32x2 p0 = cv.pk; cv.cvt<1>(c, 0, 0, x0); const f32x2 p1 = cv.pk;
-        cv.cvt<2>(c, 0, 0, x0); const f32x2 p2 = cv.pk; cv.cvt<3>(c, 0, 0, x0); const f32x2 p3 = cv.pk;
-        cv.err<0>(p0[0], p0[1], x0); cv.err<1>(p1[0], p1[1], x0); cv.err<2>(p2[0], p2[1], x0); cv.err<3>(p3[0], p3[1], x0);
-        cv.hh = row16_sum(cv.hh);
-        cv.dsq = row16_sum(cv.dsq);
-        cv.finish(c, 0, 0);
-        if (c.ntl > 1) load_rows(c, 1, 0, x0);
-        cv.start();
-        cv.cvt<0>(c, 0, 1, x1); const f32x2 r0 = cv.pk; cv.cvt<1>(c, 0, 1, x1); const f32x2 r1 = cv.pk;
-        cv.cvt<2>(c, 0, 1, x1); const f32x2 r2 = cv.pk; cv.cvt<3>(c, 0, 1, x1); const f32x2 r3 = cv.pk;
-        cv.err<0>(r0[0], r0[1], x1); cv.err<1>(r1[0], r1[1], x1); cv.err<2>(r2[0], r2[1], x1); cv.err<3>(r3[0], r3[1], x1);
-        cv.hh = row16_sum(cv.hh);
-        cv.dsq = row16_sum(cv.dsq);
-        cv.finish(c, 0, 1);
-        if (c.ntl > 1) load_rows(c, 1, 1, x1);
+        f32x2 p0, p1, p2, p3;
+        cv.start(c, 0, 0);
+        cv.cvt<0>(x0); p0 = cv.pk; cv.cvt<1>(x0); p1 = cv.pk; cv.cvt<2>(x0); p2 = cv.pk; cv.cvt<3>(x0); p3 = cv.pk;
+        cv.err<0, 0>(p0, x0); cv.err<0, 1>(p0, x0); cv.err<1, 0>(p1, x0); cv.err<1, 1>(p1, x0);
+        cv.err<2, 0>(p2, x0); cv.err<2, 1>(p2, x0); cv.err<3, 0>(p3, x0); cv.err<3, 1>(p3, x0);
+        cv.sum_hh(); cv.sum_dsq(); cv.fin_a(); cv.fin_b(c); cv.fin_c(c, 0, 0);
+        cv.start(c, 0, 1);
+        cv.cvt<0>(x1); p0 = cv.pk; cv.cvt<1>(x1); p1 = cv.pk; cv.cvt<2>(x1); p2 = cv.pk; cv.cvt<3>(x1); p3 = cv.pk;
+        cv.err<0, 0>(p0, x1); cv.err<0, 1>(p0, x1); cv.err<1, 0>(p1, x1); cv.err<1, 1>(p1, x1);
+        cv.err<2, 0>(p2, x1); cv.err<2, 1>(p2, x1); cv.err<3, 0>(p3, x1); cv.err<3, 1>(p3, x1);
+        cv.sum_hh(); cv.sum_dsq(); cv.fin_a(); cv.fin_b(c); cv.fin_c(c, 0, 1);
+        // tile 1's rows, hand-issued as in the loop: pass 0 first, then pass 1 (the loop's waits count on this order)
+        if (c.ntl > 1) { load_rows_asm(c, 0, 1, x0); load_rows_asm(c, 1, 1, x1); }
     }
     // the rows of tile 0 are YOUNGER than the codebook loads and loads return in order: once they have been used, a[0:255] is
     // complete.  (The wait the compiler placed before the first use of x0 therefore covered the codebook slice as well.)
@@ -448,6 +567,7 @@ __global__ __launch_bounds__(NT, 1) void vq_stream4_kernel(const float* __restri
     const unsigned ea = c.lds0 + L_EES + (128 * c.wave + 4 * h_l) * 4;
     const unsigned zbase = c.lds0 + L_Z16 + r_l * Z16_ROW + 16 * h_l;
     Merge mg;
+    int und = 0;                                                         // rows this wave's merges left undecided (wave-uniform)
 #if DVQ_DIAG_ON
     // per-wave sums of the shader-clock time between stamps (tile top -> barrier passed -> end of block 0, 1, 2, 3 -> next tile top)
     unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, last = __builtin_amdgcn_s_memtime();
@@ -471,6 +591,7 @@ __global__ __launch_bounds__(NT, 1) void vq_stream4_kernel(const float* __restri
     // <<< GENERATED by tools/gen_vq4_tile.py
         const bool do_load = t + 2 < c.ntl && !(abl & 1);
         const unsigned za = zbase + (t & 1) * Z16_BUF;
+        const int rows_m2 = rows_of(c, t - 2);
         DVQ_STAMP(0);
         if (abl & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -490,29 +611,33 @@ __global__ __launch_bounds__(NT, 1) void vq_stream4_kernel(const float* __restri
         DVQ_SB();
         DVQ_GSTAMP(0);
         // gap 1: block 0, k-step 1
-        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(mg.s0), "+v"(mg.s1), "+v"(mg.rs));
-        { mg.min_a(); mg.min_b(); asm volatile("" : "+v"(mg.thr)); }
-        asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(bf[1]));
+        asm volatile("s_waitcnt vmcnt(7)" : "+v"(x0[0]));
+        { cv.start(c, t + 1, 0); cv.template cvt<0>(x0); pk0 = cv.pk; DVQ_PIN2(cv.hh, pk0); }
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(bf[1]));
         if (!(abl & 32)) mfma_a<1>(accP, bf[1]);
         DVQ_RDF(4);
         DVQ_SB();
         DVQ_GSTAMP(1);
         // gap 2: block 0, k-step 2
         if (!(abl & 8)) DVQ_SCORE(accQ, 0, 2)
-        asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(bf[2]));
+        if (!(abl & 4)) { cv.template err<0, 0>(pk0, x0); DVQ_PIN2(cv.hh, cv.dsq); }
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(bf[2]));
         if (!(abl & 32)) mfma_a<2>(accP, bf[2]);
         DVQ_RDF(5);
         DVQ_SB();
         DVQ_GSTAMP(2);
         // gap 3: block 0, k-step 3
         if (!(abl & 8)) DVQ_SCORE(accQ, 2, 4)
-        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[3]));
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(mg.s0), "+v"(mg.s1), "+v"(mg.rs));
+        if (!(abl & 2)) { mg.min_a(); asm volatile("" : "+v"(mg.thr)); }
+        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(bf[3]));
         if (!(abl & 32)) mfma_a<3>(accP, bf[3]);
         DVQ_RDF(6);
         DVQ_SB();
         DVQ_GSTAMP(3);
         // gap 4: block 0, k-step 4
         if (!(abl & 8)) DVQ_SCORE(accQ, 4, 6)
+        if (!(abl & 2)) { mg.min_b(); asm volatile("" : "+v"(mg.thr)); }
         asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[4]));
         if (!(abl & 32)) mfma_a<4>(accP, bf[4]);
         DVQ_RDF(7);
@@ -520,6 +645,7 @@ __global__ __launch_bounds__(NT, 1) void vq_stream4_kernel(const float* __restri
         DVQ_GSTAMP(4);
         // gap 5: block 0, k-step 5
         if (!(abl & 8)) DVQ_SCORE(accQ, 6, 8)
+        if (!(abl & 2)) { mg.count_a(); asm volatile("" : "+v"(mg.c1)); }
         asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[5]));
         if (!(abl & 32)) mfma_a<5>(accP, bf[5]);
         DVQ_RDF(8);
@@ -527,6 +653,7 @@ __global__ __launch_bounds__(NT, 1) void vq_stream4_kernel(const float* __restri
         DVQ_GSTAMP(5);
         // gap 6: block 0, k-step 6
         if (!(abl & 8)) DVQ_SCORE(accQ, 8, 10)
+        if (!(abl & 2)) { mg.count_b(); asm volatile("" : "+v"(mg.c2)); }
         asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[6]));
         if (!(abl & 32)) mfma_a<6>(accP, bf[6]);
         DVQ_RDF(9);
@@ -534,6 +661,7 @@ __global__ __launch_bounds__(NT, 1) void vq_stream4_kernel(const float* __restri
         DVQ_GSTAMP(6);
         // gap 7: block 0, k-step 7
         if (!(abl & 8)) DVQ_SCORE(accQ, 10, 12)
+        if (!(abl & 2)) { mg.sum_a(); asm volatile("" : "+v"(mg.n1)); }
         asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[7]));
         if (!(abl & 32)) mfma_a<7>(accP, bf[7]);
         DVQ_RDF(10);
@@ -541,6 +669,7 @@ __global__ __launch_bounds__(NT, 1) void vq_stream4_kernel(const float* __restri
         DVQ_GSTAMP(7);
         // gap 8: block 0, k-step 8
         if (!(abl & 8)) DVQ_SCORE(accQ, 12, 14)
+        if (!(abl & 2)) { mg.sum_b(); asm volatile("" : "+v"(mg.n2)); }
         asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[8]));
         if (!(abl & 32)) mfma_a<8>(accP, bf[8]);
         DVQ_RDF(11);
@@ -548,6 +677,7 @@ __global__ __launch_bounds__(NT, 1) void vq_stream4_kernel(const float* __restri
         DVQ_GSTAMP(8);
         // gap 9: block 0, k-step 9
         if (!(abl & 8)) DVQ_SCORE(accQ, 14, 16)
+        if (!(abl & 4)) { cv.template err<0, 1>(pk0, x0); DVQ_PIN2(cv.hh, cv.dsq); }
         asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[9]));
         if (!(abl & 32)) mfma_a<9>(accP, bf[9]);
         DVQ_RDF(12);
@@ -555,13 +685,14 @@ __global__ __launch_bounds__(NT, 1) void vq_stream4_kernel(const float* __restri
         DVQ_GSTAMP(9);
         // gap 10: block 0, k-step 10
         write_slot<3>(c, t - 1, m1, m2);
+        if (!(abl & 2)) { mg.act_a(c, t - 2, rows_m2); asm volatile("" : "+v"(mg.flags), "+v"(mg.rowslot)); }
         asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(bf[10]));
         if (!(abl & 32)) mfma_a<10>(accP, bf[10]);
         DVQ_RDF(13);
         DVQ_SB();
         DVQ_GSTAMP(10);
         // gap 11: block 0, k-step 11
-        if (!(abl & 2)) mg.act(c, t - 2);
+        if (!(abl & 2)) mg.act_b(c);
         asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(bf[11]));
         if (!(abl & 32)) mfma_a<11>(accP, bf[11]);
         DVQ_RDF(14);
@@ -569,55 +700,66 @@ __global__ __launch_bounds__(NT, 1) void vq_stream4_kernel(const float* __restri
         DVQ_SB();
         DVQ_GSTAMP(11);
         // gap 12: block 0, k-step 12
-        { cv.start(); cv.template cvt<0>(c, t + 1, 0, x0); pk0 = cv.pk; DVQ_PIN2(cv.hh, pk0); }
+        if (!(abl & 2)) mg.act_c(c, und);
         asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(bf[12]));
         if (!(abl & 32)) mfma_a<12>(accP, bf[12]);
         DVQ_RDF(15);
         DVQ_SB();
         DVQ_GSTAMP(12);
         // gap 13: block 0, k-step 13
-        if (!(abl & 4)) { cv.template err<0>(pk0[0], pk0[1], x0); DVQ_PIN2(cv.hh, cv.dsq); }
-        asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(bf[13]));
+        asm volatile("s_waitcnt vmcnt(6)" : "+v"(x0[1]));
+        { cv.template cvt<1>(x0); pk1 = cv.pk; DVQ_PIN2(cv.hh, pk1); }
+        if (!(abl & 4)) { cv.template err<1, 0>(pk1, x0); DVQ_PIN2(cv.hh, cv.dsq); }
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(bf[13]));
         if (!(abl & 32)) mfma_a<13>(accP, bf[13]);
         DVQ_SB();
         DVQ_GSTAMP(13);
         // gap 14: block 0, k-step 14
-        { cv.template cvt<1>(c, t + 1, 0, x0); pk1 = cv.pk; DVQ_PIN2(cv.hh, pk1); }
-        asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(bf[14]));
+        if (!(abl & 4)) { cv.template err<1, 1>(pk1, x0); DVQ_PIN2(cv.hh, cv.dsq); }
+        asm volatile("s_waitcnt vmcnt(5)" : "+v"(x0[2]));
+        { cv.template cvt<2>(x0); pk2 = cv.pk; DVQ_PIN2(cv.hh, pk2); }
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(bf[14]));
         if (!(abl & 32)) mfma_a<14>(accP, bf[14]);
         DVQ_SB();
         DVQ_GSTAMP(14);
         // gap 15: block 0, k-step 15
-        if (!(abl & 4)) { cv.template err<1>(pk1[0], pk1[1], x0); DVQ_PIN2(cv.hh, cv.dsq); }
-        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bf[15]));
+        if (!(abl & 4)) { cv.template err<2, 0>(pk2, x0); DVQ_PIN2(cv.hh, cv.dsq); }
+        if (!(abl & 4)) { cv.template err<2, 1>(pk2, x0); DVQ_PIN2(cv.hh, cv.dsq); }
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bf[15]));
         if (!(abl & 32)) mfma_a<15>(accP, bf[15]);
         DVQ_SB();
         DVQ_GSTAMP(15);
         DVQ_STAMP(2);
         // gap 16: block 1, k-step 0
         m1 = INFINITY; m2 = INFINITY;
-        { cv.template cvt<2>(c, t + 1, 0, x0); pk2 = cv.pk; DVQ_PIN2(cv.hh, pk2); }
-        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ci[0]), "+v"(ci[1]), "+v"(ci[2]), "+v"(ci[3]));
+        asm volatile("s_waitcnt vmcnt(4)" : "+v"(x0[3]));
+        { cv.template cvt<3>(x0); pk3 = cv.pk; DVQ_PIN2(cv.hh, pk3); }
+        if (!(abl & 4)) { cv.template err<3, 0>(pk3, x0); DVQ_PIN2(cv.hh, cv.dsq); }
+        asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(ci[0]), "+v"(ci[1]), "+v"(ci[2]), "+v"(ci[3]));
         { f32x16 st; DVQ_START(st) if (abl & 32) accQ = st; else mfma_ac<16>(accQ, bf[0], st); }
         DVQ_SB();
         DVQ_GSTAMP(16);
         // gap 17: block 1, k-step 1
-        if (!(abl & 4)) { cv.template err<2>(pk2[0], pk2[1], x0); DVQ_PIN2(cv.hh, cv.dsq); }
+        if (!(abl & 4)) { cv.template err<3, 1>(pk3, x0); DVQ_PIN2(cv.hh, cv.dsq); }
+        { cv.sum_hh(); DVQ_PIN2(cv.hh, cv.dsq); }
         if (!(abl & 32)) mfma_a<17>(accQ, bf[1]);
         DVQ_SB();
         DVQ_GSTAMP(17);
         // gap 18: block 1, k-step 2
         if (!(abl & 8)) DVQ_SCORE(accP, 0, 2)
+        { cv.sum_dsq(); DVQ_PIN2(cv.hh, cv.dsq); }
         if (!(abl & 32)) mfma_a<18>(accQ, bf[2]);
         DVQ_SB();
         DVQ_GSTAMP(18);
         // gap 19: block 1, k-step 3
         if (!(abl & 8)) DVQ_SCORE(accP, 2, 4)
+        { cv.fin_a(); DVQ_PIN2(cv.hn, cv.dzn); }
         if (!(abl & 32)) mfma_a<19>(accQ, bf[3]);
         DVQ_SB();
         DVQ_GSTAMP(19);
         // gap 20: block 1, k-step 4
         if (!(abl & 8)) DVQ_SCORE(accP, 4, 6)
+        { cv.fin_b(c); asm volatile("" : "+v"(cv.eps)); }
         if (!(abl & 32)) mfma_a<20>(accQ, bf[4]);
         DVQ_SB();
         DVQ_GSTAMP(20);
@@ -648,70 +790,85 @@ __global__ __launch_bounds__(NT, 1) void vq_stream4_kernel(const float* __restri
         DVQ_GSTAMP(25);
         // gap 26: block 1, k-step 10
         write_slot<0>(c, t, m1, m2);
+        cv.fin_c(c, t + 1, 0);
         if (!(abl & 32)) mfma_a<26>(accQ, bf[10]);
         DVQ_SB();
         DVQ_GSTAMP(26);
         // gap 27: block 1, k-step 11
-        { cv.template cvt<3>(c, t + 1, 0, x0); pk3 = cv.pk; DVQ_PIN2(cv.hh, pk3); }
+        if (do_load) load_rows_asm(c, 0, t + 2, x0);
         if (!(abl & 32)) mfma_a<27>(accQ, bf[11]);
         DVQ_RDCI(2)
         DVQ_SB();
         DVQ_GSTAMP(27);
         // gap 28: block 1, k-step 12
-        if (!(abl & 4)) { cv.template err<3>(pk3[0], pk3[1], x0); DVQ_PIN2(cv.hh, cv.dsq); }
+        asm volatile("s_waitcnt vmcnt(7)" : "+v"(x1[0]));
+        { cv.start(c, t + 1, 1); cv.template cvt<0>(x1); pk0 = cv.pk; DVQ_PIN2(cv.hh, pk0); }
         if (!(abl & 32)) mfma_a<28>(accQ, bf[12]);
         DVQ_SB();
         DVQ_GSTAMP(28);
         // gap 29: block 1, k-step 13
-        { cv.hh = row16_sum(cv.hh); cv.dsq = row16_sum(cv.dsq); DVQ_PIN2(cv.hh, cv.dsq); }
+        if (!(abl & 4)) { cv.template err<0, 0>(pk0, x1); DVQ_PIN2(cv.hh, cv.dsq); }
+        if (!(abl & 4)) { cv.template err<0, 1>(pk0, x1); DVQ_PIN2(cv.hh, cv.dsq); }
         if (!(abl & 32)) mfma_a<29>(accQ, bf[13]);
         DVQ_SB();
         DVQ_GSTAMP(29);
         // gap 30: block 1, k-step 14
-        cv.finish(c, t + 1, 0);
+        asm volatile("s_waitcnt vmcnt(6)" : "+v"(x1[1]));
+        { cv.template cvt<1>(x1); pk1 = cv.pk; DVQ_PIN2(cv.hh, pk1); }
+        if (!(abl & 4)) { cv.template err<1, 0>(pk1, x1); DVQ_PIN2(cv.hh, cv.dsq); }
         if (!(abl & 32)) mfma_a<30>(accQ, bf[14]);
         DVQ_SB();
         DVQ_GSTAMP(30);
         // gap 31: block 1, k-step 15
-        if (do_load) load_rows(c, t + 2, 0, x0);
+        if (!(abl & 4)) { cv.template err<1, 1>(pk1, x1); DVQ_PIN2(cv.hh, cv.dsq); }
+        asm volatile("s_waitcnt vmcnt(5)" : "+v"(x1[2]));
+        { cv.template cvt<2>(x1); pk2 = cv.pk; DVQ_PIN2(cv.hh, pk2); }
         if (!(abl & 32)) mfma_a<31>(accQ, bf[15]);
         DVQ_SB();
         DVQ_GSTAMP(31);
         DVQ_STAMP(3);
         // gap 32: block 2, k-step 0
         m1 = INFINITY; m2 = INFINITY;
-        { cv.start(); cv.template cvt<0>(c, t + 1, 1, x1); pk0 = cv.pk; DVQ_PIN2(cv.hh, pk0); }
-        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ci[0]), "+v"(ci[1]), "+v"(ci[2]), "+v"(ci[3]));
+        if (!(abl & 4)) { cv.template err<2, 0>(pk2, x1); DVQ_PIN2(cv.hh, cv.dsq); }
+        if (!(abl & 4)) { cv.template err<2, 1>(pk2, x1); DVQ_PIN2(cv.hh, cv.dsq); }
+        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(ci[0]), "+v"(ci[1]), "+v"(ci[2]), "+v"(ci[3]));
         { f32x16 st; DVQ_START(st) if (abl & 32) accP = st; else mfma_ac<32>(accP, bf[0], st); }
         DVQ_SB();
         DVQ_GSTAMP(32);
         // gap 33: block 2, k-step 1
-        if (!(abl & 4)) { cv.template err<0>(pk0[0], pk0[1], x1); DVQ_PIN2(cv.hh, cv.dsq); }
+        asm volatile("s_waitcnt vmcnt(4)" : "+v"(x1[3]));
+        { cv.template cvt<3>(x1); pk3 = cv.pk; DVQ_PIN2(cv.hh, pk3); }
+        if (!(abl & 4)) { cv.template err<3, 0>(pk3, x1); DVQ_PIN2(cv.hh, cv.dsq); }
         if (!(abl & 32)) mfma_a<33>(accP, bf[1]);
         DVQ_SB();
         DVQ_GSTAMP(33);
         // gap 34: block 2, k-step 2
         if (!(abl & 8)) DVQ_SCORE(accQ, 0, 2)
+        if (!(abl & 4)) { cv.template err<3, 1>(pk3, x1); DVQ_PIN2(cv.hh, cv.dsq); }
         if (!(abl & 32)) mfma_a<34>(accP, bf[2]);
         DVQ_SB();
         DVQ_GSTAMP(34);
         // gap 35: block 2, k-step 3
         if (!(abl & 8)) DVQ_SCORE(accQ, 2, 4)
+        { cv.sum_hh(); DVQ_PIN2(cv.hh, cv.dsq); }
         if (!(abl & 32)) mfma_a<35>(accP, bf[3]);
         DVQ_SB();
         DVQ_GSTAMP(35);
         // gap 36: block 2, k-step 4
         if (!(abl & 8)) DVQ_SCORE(accQ, 4, 6)
+        { cv.sum_dsq(); DVQ_PIN2(cv.hh, cv.dsq); }
         if (!(abl & 32)) mfma_a<36>(accP, bf[4]);
         DVQ_SB();
         DVQ_GSTAMP(36);
         // gap 37: block 2, k-step 5
         if (!(abl & 8)) DVQ_SCORE(accQ, 6, 8)
+        { cv.fin_a(); DVQ_PIN2(cv.hn, cv.dzn); }
         if (!(abl & 32)) mfma_a<37>(accP, bf[5]);
         DVQ_SB();
         DVQ_GSTAMP(37);
         // gap 38: block 2, k-step 6
         if (!(abl & 8)) DVQ_SCORE(accQ, 8, 10)
+        { cv.fin_b(c); asm volatile("" : "+v"(cv.eps)); }
         if (!(abl & 32)) mfma_a<38>(accP, bf[6]);
         DVQ_SB();
         DVQ_GSTAMP(38);
@@ -732,45 +889,40 @@ __global__ __launch_bounds__(NT, 1) void vq_stream4_kernel(const float* __restri
         DVQ_GSTAMP(41);
         // gap 42: block 2, k-step 10
         write_slot<1>(c, t, m1, m2);
+        cv.fin_c(c, t + 1, 1);
         if (!(abl & 32)) mfma_a<42>(accP, bf[10]);
         DVQ_SB();
         DVQ_GSTAMP(42);
         // gap 43: block 2, k-step 11
-        { cv.template cvt<1>(c, t + 1, 1, x1); pk1 = cv.pk; DVQ_PIN2(cv.hh, pk1); }
+        if (do_load) load_rows_asm(c, 1, t + 2, x1);
         if (!(abl & 32)) mfma_a<43>(accP, bf[11]);
         DVQ_RDCI(3)
         DVQ_SB();
         DVQ_GSTAMP(43);
         // gap 44: block 2, k-step 12
-        if (!(abl & 4)) { cv.template err<1>(pk1[0], pk1[1], x1); DVQ_PIN2(cv.hh, cv.dsq); }
         if (!(abl & 32)) mfma_a<44>(accP, bf[12]);
         DVQ_SB();
         DVQ_GSTAMP(44);
         // gap 45: block 2, k-step 13
-        { cv.template cvt<2>(c, t + 1, 1, x1); pk2 = cv.pk; DVQ_PIN2(cv.hh, pk2); }
         if (!(abl & 32)) mfma_a<45>(accP, bf[13]);
         DVQ_SB();
         DVQ_GSTAMP(45);
         // gap 46: block 2, k-step 14
-        if (!(abl & 4)) { cv.template err<2>(pk2[0], pk2[1], x1); DVQ_PIN2(cv.hh, cv.dsq); }
         if (!(abl & 32)) mfma_a<46>(accP, bf[14]);
         DVQ_SB();
         DVQ_GSTAMP(46);
         // gap 47: block 2, k-step 15
-        { cv.template cvt<3>(c, t + 1, 1, x1); pk3 = cv.pk; DVQ_PIN2(cv.hh, pk3); }
         if (!(abl & 32)) mfma_a<47>(accP, bf[15]);
         DVQ_SB();
         DVQ_GSTAMP(47);
         DVQ_STAMP(4);
         // gap 48: block 3, k-step 0
         m1 = INFINITY; m2 = INFINITY;
-        if (!(abl & 4)) { cv.template err<3>(pk3[0], pk3[1], x1); DVQ_PIN2(cv.hh, cv.dsq); }
-        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ci[0]), "+v"(ci[1]), "+v"(ci[2]), "+v"(ci[3]));
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ci[0]), "+v"(ci[1]), "+v"(ci[2]), "+v"(ci[3]));
         { f32x16 st; DVQ_START(st) if (abl & 32) accQ = st; else mfma_ac<48>(accQ, bf[0], st); }
         DVQ_SB();
         DVQ_GSTAMP(48);
         // gap 49: block 3, k-step 1
-        { cv.hh = row16_sum(cv.hh); cv.dsq = row16_sum(cv.dsq); DVQ_PIN2(cv.hh, cv.dsq); }
         if (!(abl & 32)) mfma_a<49>(accQ, bf[1]);
         DVQ_SB();
         DVQ_GSTAMP(49);
@@ -820,12 +972,10 @@ __global__ __launch_bounds__(NT, 1) void vq_stream4_kernel(const float* __restri
         DVQ_SB();
         DVQ_GSTAMP(58);
         // gap 59: block 3, k-step 11
-        cv.finish(c, t + 1, 1);
         if (!(abl & 32)) mfma_a<59>(accQ, bf[11]);
         DVQ_SB();
         DVQ_GSTAMP(59);
         // gap 60: block 3, k-step 12
-        if (do_load) load_rows(c, t + 2, 1, x1);
         if (!(abl & 32)) mfma_a<60>(accQ, bf[12]);
         DVQ_SB();
         DVQ_GSTAMP(60);
@@ -856,13 +1006,32 @@ __global__ __launch_bounds__(NT, 1) void vq_stream4_kernel(const float* __restri
     if (c.ntl >= 2) {
         mg.read(c, c.ntl - 2);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mg.s0), "+v"(mg.s1), "+v"(mg.rs));
-        mg.min_a(); mg.min_b(); mg.act(c, c.ntl - 2);
+        mg.all(c, c.ntl - 2, rows_of(c, c.ntl - 2), und);
     }
     wg_barrier();
     mg.read(c, c.ntl - 1);
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mg.s0), "+v"(mg.s1), "+v"(mg.rs));
-    mg.min_a(); mg.min_b(); mg.act(c, c.ntl - 1);
+    mg.all(c, c.ntl - 1, rows_of(c, c.ntl - 1), und);
+    if (c.lane == 0) reinterpret_cast<unsigned*>(lds + L_CNT)[4 + c.wave] = (unsigned)und;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- the undecided rows of all four lists -> candidate pairs / the all-entries list: 8 lanes per row, 32 rows per pass
+    {
+        const unsigned* cnt4 = reinterpret_cast<const unsigned*>(lds + L_CNT) + 4;
+        const int n0 = (int)min(cnt4[0], 64u), n1_ = (int)min(cnt4[1], 64u), n2_ = (int)min(cnt4[2], 64u), n3_ = (int)min(cnt4[3], 64u);
+        const int n_und = n0 + n1_ + n2_ + n3_;
+        const bool overflow = cnt4[0] > 64u || cnt4[1] > 64u || cnt4[2] > 64u || cnt4[3] > 64u;   // a wave with > 64 undecided rows of its 64:
+        (void)overflow;                                                                            // impossible (8 rows x 8 tiles), kept as a bound
+        const uint16_t* ul = reinterpret_cast<const uint16_t*>(lds + L_UND);
+        for (int base = 0; base < n_und; base += NT / 8) {
+            const int k = base + (tid >> 3);
+            const bool valid = k < n_und;
+            int w = 0, kk = valid ? k : 0;
+            if (kk >= n0) { kk -= n0; w = 1; if (kk >= n1_) { kk -= n1_; w = 2; if (kk >= n2_) { kk -= n2_; w = 3; } } }
+            mg.expand(c, (unsigned)ul[w * 64 + kk], valid);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     DVQ_T(t_merge);
 

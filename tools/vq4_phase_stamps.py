@@ -7,7 +7,8 @@ import numpy as np, torch
 import dvqvae_amd
 from dvqvae_amd import ops
 dev = "cuda:0"
-if len(sys.argv) > 1: os.environ["DVQ_VQ4_ABL"] = sys.argv[1]
+if len(sys.argv) > 2: os.environ["DVQ_VQ16_ABL"] = sys.argv[2]          # usage: vq4_phase_stamps.py 16 <abl>  |  vq4_phase_stamps.py <abl of the four-wave kernel>
+elif len(sys.argv) > 1: os.environ["DVQ_VQ4_ABL"] = sys.argv[1]
 M, D, K = 65536, 256, 512
 zs = [torch.randn(M, D, device=dev) for _ in range(6)]
 E = torch.randn(K, D, device=dev)
