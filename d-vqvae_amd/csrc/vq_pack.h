@@ -1,5 +1,5 @@
 // Packed codebook image of the streaming VQ kernels (built by dvq_vq_pack in vq_stream.hip, consumed by vq_stream.hip and
-// vq_stream4.hip): header, canonical |e_k|^2, fp16 image of -2 sE E in MFMA-fragment order.
+// vq_stream16.hip): header, canonical |e_k|^2, fp16 image of -2 sE E in MFMA-fragment order.
 #pragma once
 #include "dvq_internal.h"
 

@@ -914,19 +914,18 @@ extern "C" int dvq_vq_argmin_fast(const float* z, const float* E, const void* pa
         }
     }
     const char* pk = (const char*)packed;
-    // default: the sixteen-wave kernel (vq_stream16.hip: four waves per SIMD, 32 entries each); DVQ_VQ_KERNEL=4: the four-wave
-    // kernel (vq_stream4.hip: one wave per SIMD, codebook in the accumulator registers); =8: this file's eight-wave kernel
+    // default: this file's eight-wave kernel; DVQ_VQ_KERNEL=16: the sixteen-wave kernel (vq_stream16.hip: four waves per SIMD, 32
+    // entries each, plain code).  Same indices, same speed within the run-to-run spread (tools/vq_kernel_ab.py: 36.4 us both).
     int which = dvq_knobs().vq_kernel;
-    unsigned long long* dbg4 = nullptr;
+    unsigned long long* dbg16 = nullptr;
 #ifdef DVQ_DIAG
     if (getenv("DVQ_VQ_DBG") || getenv("DVQ_VQ_ABL")) which = 8;                 // stamps / ablations of the eight-wave kernel
-    if (getenv("DVQ_VQ4_ABL")) which = 4;
-    if (getenv("DVQ_VQ4_DBG")) dbg4 = (unsigned long long*)workspace;            // phase stamps of the four- / sixteen-wave kernels
+    if (getenv("DVQ_VQ16_DBG") || getenv("DVQ_VQ16_ABL")) which = 16;
+    if (getenv("DVQ_VQ16_DBG")) dbg16 = (unsigned long long*)workspace;          // phase stamps of the sixteen-wave kernel
 #endif
-    if (which != 8) {
+    if (which == 16) {
         DVQ_PROF("vq_argmin_fast", 2.0 * M * K * D, (double)M * D * 4 + (double)K * D * 4 + (double)M * 8, st);
-        if (which == 4) return dvq_launch_vq_stream4(z, E, packed, (long)M, idx, slow_rows, dbg4, st);
-        return dvq_launch_vq_stream16(z, E, packed, (long)M, idx, slow_rows, dbg4, st);
+        return dvq_launch_vq_stream16(z, E, packed, (long)M, idx, slow_rows, dbg16, st);
     }
     const int cus = device_cus();
     const long tiles = (M + TILE - 1) / TILE;

@@ -1,24 +1,36 @@
-// Fast VQ nearest-codebook-entry for the headline shape (K = 512, D = 256), third structure: SIXTEEN waves per workgroup, four
-// per SIMD, each holding 32 codebook entries.  Same result as vq_stream.hip / vq.hip / oracle/vq_canonical.c, bit for bit.
-// Reference: VectorQuantizer.forward(z, istrain=False), network/vqvae/quantizer.py:46-49.
+// Fast VQ nearest-codebook-entry for the headline shape (K = 512, D = 256), second structure (DVQ_VQ_KERNEL=16): SIXTEEN waves per
+// workgroup, four per SIMD, each holding 32 codebook entries; plain straight-line code, no generated gap tables.  Same result
+// as vq_stream.hip / vq.hip / oracle/vq_canonical.c, bit for bit.  Reference: VectorQuantizer.forward(z, istrain=False),
+// network/vqvae/quantizer.py:46-49.
 //
-// Why.  The filter needs ~2 600 vector instructions per 32-row tile and CU beside 256 MFMAs (conversion with measured rounding
-// error, id packing + lane-local top-2 per score, merge).  A SIMD issues a wave's vector instruction every 4 cycles but TWO
-// waves' every 2: with one wave per SIMD (vq_stream4.hip: codebook in the accumulator registers, hand-placed 64-gap body) the
-// loop is bound by the single wave's issue rate and dependent-instruction latency -- 21 us, SQ counters: 29 % of the wave cycles
-// issuing vector instructions, no overlap with the matrix pipe left to win; with two waves per SIMD in lock step at one barrier
-// per tile (vq_stream.hip) each waits for its partner 47 % of the time -- 23 us.  Here every SIMD has FOUR waves, each with a
-// quarter of the work of vq_stream4's wave: 16 MFMAs, 16 scores per lane, 2 rows to convert, 2 rows to merge per tile, written as
-// plain straight-line code; the hardware interleaves the four instruction streams (vector work of one under the MFMAs, LDS
-// and HBM latencies of the others), which is what the generated gap tables of the other two kernels emulate by hand.
-//   * wave w keeps entries [32w, 32w+32) -- fp16 of -2 sE e_k, all 256 dims -- as the MFMA A operand in 64 VGPRs, and the
-//     accumulator start values sE |e_k|^2 of its 32 x 32 block in 16 more (<= 128 VGPRs: four waves per SIMD);
-//   * per tile: one s_barrier (the fp16 image of tile t is complete), 16 fragment reads + 16 MFMAs, scores -> the wave's slot
-//     (min, second) per row, conversion of its 2 rows of tile t+1 (32 lanes per row, loaded a tile earlier), loads of tile t+2,
-//     merge of its 2 rows of tile t-1 (32 lanes per row = the row's 32 slots);
-//   * decided rows write their entry; every row leaves a record {threshold, flags}; undecided rows go to the wave's own list
-//     and are expanded into candidate pairs after the loop (all slots stay in the LDS: 9 x 8.7 KB), then the canonical fp32
-//     refine of vq_stream.hip (see its header for the error bound).
+// Why it exists (round 3; every number: MI355X, M = 65 536, six rotating inputs, tools/vq_kernel_ab.py, tools/vq16_phase_stamps.py,
+// tools/vq_pmc.sh).  Three structures were built to get the 36 us of vq_stream.hip (eight waves, two per SIMD) to the 21.3 us the
+// task asks for:
+//   (a) FOUR waves, one per SIMD, the codebook as the MFMA A operand in a[0:255] (inline asm; microbenchmark
+//       tools/microbench/mfma_agpr_operand.hip: 32.1 cycles per dependent MFMA, 4-5 placed vector instructions per gap free),
+//       64-gap generated body: 37-43 us.  A single in-order wave per SIMD pays the dependent-issue latency of every vector
+//       chain (SQ counters: 29 % of the wave cycles issuing vector instructions, 44 % waiting, MFMA busy 23 %); compile-time
+//       ablations were ADDITIVE (no MFMA -8.5 us of 22.3, no scoring -2.4, no merge decisions -3.7, no barrier -1.3, no row
+//       loads 0): nothing overlapped.  Removed from the tree (history: "VQ: four-wave streaming kernel").
+//   (b) THIS kernel: 36.4 us = vq_stream.hip.  Ablations of its loop (21-24 us): no conversion -7.4, no MFMA -9.9, no merge -2.7,
+//       no scoring -2.5, no barrier -2.1, no row loads -2.0: additive again although a matrix-only wave and a vector-only wave on one
+//       SIMD do run concurrently (tools/microbench/mfma_valu_two_waves.hip: 520 vs 512 cycles per 16 MFMAs, vector chain +9 %).
+//       SQ counters: 8.2 M vector instructions per launch at 4.0 cycles of SIMD issue each = 15 us of pure vector issue per SIMD;
+//       dealing the vector work by role (below) took 4 000 -> 2 200 instructions per tile and CU and the loop 24.4 -> 21.3 us.
+//   (c) 64-row tiles (half the barriers): 24.4 us, 17 spilled registers: not kept.
+// What the three have in common is ~6 000 cycles per 32-row tile and CU against 2 048 of matrix work and ~2 200 of vector issue:
+// the per-tile dependency chain (barrier -> fragment reads -> 16 dependent MFMAs -> 16-step top-2 chain -> slot -> barrier, and
+// beside it load -> convert -> row reduction -> LDS) is executed by too few independent instruction streams to fill either pipe.
+//
+//   * wave w keeps entries [32w, 32w+32) -- fp16 of -2 sE e_k, all 256 dims -- as the MFMA A operand in 64 VGPRs (<= 128 VGPRs:
+//     four waves per SIMD); the accumulator start values sE |e_k|^2 come from the LDS each tile;
+//   * per tile: one s_barrier (the fp16 image of tile t and the slots of tile t-1 are complete), 16 fragment reads + 16 MFMAs,
+//     scores -> the wave's slot (min, second) per row; waves 0-7 convert 4 rows of tile t+1 each (16 lanes per row, loaded a
+//     tile earlier) and load tile t+2; waves 8-11 merge 8 rows of tile t-1 each (8 lanes per row, 4 slots per lane); waves 4-11
+//     do that vector work BEFORE their MFMAs, the others after (the four waves of a SIMD leave the barrier together);
+//   * decided rows write their entry; every row leaves a record {threshold, flags}; undecided rows go to the merging wave's own
+//     list (no atomics, no branch in the loop) and are expanded into candidate pairs after the loop (all slots stay in the LDS:
+//     9 x 8.7 KB), then the canonical fp32 refine of vq_stream.hip (see its header for the error bound), eight lanes per chain.
 #include "dvq_internal.h"
 #include "vq_pack.h"
 

@@ -934,3 +934,25 @@ def test_skinny_gemm_equals_tiled_kernels_bitwise():
     for k in a:
         assert torch.equal(a[k], b[k]), f"{k}: skinny kernel != tiled kernel"
     assert torch.equal(a["logits"][3:4], a["logits_row3"])
+
+
+def test_vq_kernel_variants_agree():
+    """The sixteen-wave streaming kernel (DVQ_VQ_KERNEL=16) returns the eight-wave kernel's indices on random rows, ragged
+    sizes, ties, near-ties, non-finite and out-of-range rows."""
+    torch.manual_seed(11)
+    E = gpu(torch.randn(512, 256))
+    cases = [gpu(torch.randn(M, 256)) for M in (1, 31, 33, 1000, 8192 + 5, 65536)]
+    z = torch.randn(300, 256)
+    z[0] = E[7].cpu(); z[1] = 0.5 * (E[3] + E[9]).cpu(); z[2, 5] = float("nan"); z[3, 9] = float("inf"); z[4] = 0.0
+    z[5] = 7.0e4; z[6] = 1e-6 * z[6]; z[10:40] = E[100:130].cpu() + 1e-4 * torch.randn(30, 256)
+    cases.append(gpu(z))
+    Et = gpu((torch.rand(512, 256) * 2 - 1) / 512)                    # the reference's initial codebook: tie-prone
+    pk, pkt = ops.vq_pack(E), ops.vq_pack(Et)
+
+    def run():
+        return [ops.vq_argmin(c_, E, packed=pk, fast=True) for c_ in cases] + [ops.vq_argmin(cases[3], Et, packed=pkt, fast=True)]
+    a = run()
+    b = _with_env("DVQ_VQ_KERNEL", "16", run)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert torch.equal(a[3], ops.vq_argmin(cases[3], E, fast=False))

@@ -1,5 +1,5 @@
-"""A/B of the three streaming VQ kernels in ONE process (GPU box): interleaved rounds, six rotating 64 MiB inputs, one HIP-event
-pair around a train of 30 calls; all three must return the same indices."""
+"""A/B of the two streaming VQ kernels in ONE process (GPU box): interleaved rounds, six rotating 64 MiB inputs, one HIP-event
+pair around a train of 30 calls; both must return the same indices."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,9 +12,9 @@ zs = [torch.randn(M, D, device=dev) for _ in range(6)]
 E = torch.randn(K, D, device=dev)
 pk = ops.vq_pack(E)
 ref = None
-res = {k: [] for k in ("16", "4", "8")}
+res = {k: [] for k in ("16", "8")}
 for rnd in range(5):
-    for kern in ("16", "4", "8"):
+    for kern in ("16", "8"):
         os.environ["DVQ_VQ_KERNEL"] = kern; lib.dvq_reload_env()
         for i in range(6): idx = ops.vq_argmin(zs[i], E, packed=pk)
         torch.cuda.synchronize()
