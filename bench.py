@@ -424,8 +424,7 @@ def main():
                                       f"the step, synthetic weights",
                           "global_batch": B_global, "points": N, "codebook": K, "parallelism": f"batch-shard x{world}",
                           "allgather_bytes_per_rank": B * 61 * 4,
-                          "collective": (f"torch.distributed {torch.distributed.get_backend()} all_gather_into_tensor"
-                                         if torch.distributed.is_initialized() else "none (single process)")}}
+                          "collective": dist.collective_used}}
         if kernels:
             # MFMA kernels: the fused PointNet trunk and the GEMMs (exact VQ argmin excluded: it runs the fp32 chain)
             pe_ms = prof_elapsed * 1e3

@@ -105,6 +105,10 @@ SIGNATURES = {
     "dvq_nn_points": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int64, c_f32p, C.c_int64, C.c_int64, C.c_int64,
                                 C.c_int64, C.c_int, C.c_int, c_f32p, c_i64p, c_stream]),
     "dvq_vertex_normals": (C.c_int, [c_f32p, C.c_int64, C.c_int, c_i32p, c_i32p, c_i32p, c_f32p, c_stream]),
+    "dvq_comm_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "dvq_comm_init": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "dvq_allgather_params": (C.c_int, [C.c_void_p, c_f32p, C.c_int64, C.c_int, c_f32p, c_stream]),
+    "dvq_comm_destroy": (C.c_int, [C.c_void_p]),
     "dvq_interior": (C.c_int, [c_f32p, c_f32p, C.c_int, c_f32p, C.c_int64, C.c_int64, C.c_int64, c_i64p, C.c_int64,
                                C.c_int, C.c_void_p, c_stream]),
 }

@@ -55,6 +55,52 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+_comms = {}          # device index -> communicator handle of the C ABI (dvq_comm_init)
+collective_used = "none (single process)"       # what the last data collective went through (bench.py reports it)
+
+
+def _abi_comm(device: torch.device):
+    """This process' RCCL communicator behind the C ABI (include/dvq.h: dvq_comm_*), created at first use: rank 0 makes the
+    unique id, the process group carries it to the other ranks."""
+    import ctypes as C
+    from . import _lib
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx in _comms:
+        return _comms[idx]
+    lib = _lib.load()
+    world, rank = dist.get_world_size(), dist.get_rank()
+    uid = C.create_string_buffer(128)
+    if rank == 0:
+        _lib.check(lib.dvq_comm_unique_id(uid, 128), "dvq_comm_unique_id")
+    box = [bytes(uid.raw)]
+    dist.broadcast_object_list(box, src=0)
+    handle = C.c_void_p()
+    with torch.cuda.device(idx):
+        _lib.check(lib.dvq_comm_init(box[0], 128, world, rank, C.byref(handle)), "dvq_comm_init")
+    _comms[idx] = handle
+    return handle
+
+
+def _gather_equal(local: torch.Tensor, world: int) -> torch.Tensor:
+    """one all-gather of equal [rows, C] shards straight into the result: through the C ABI's dvq_allgather_params (RCCL on the
+    caller's stream) for float32 device tensors under the "nccl" backend, through torch.distributed otherwise"""
+    global collective_used
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    use_abi = (local.is_cuda and local.dtype == torch.float32 and local.dim() == 2 and dist.get_backend() == "nccl"
+               and os.environ.get("DVQ_ALLGATHER", "abi") != "torch")
+    if use_abi:
+        from . import _lib
+        comm = _abi_comm(local.device)
+        with torch.cuda.device(local.device):
+            _lib.check(_lib.load().dvq_allgather_params(comm, local.data_ptr(), local.shape[0], local.shape[1], out.data_ptr(),
+                                                        torch.cuda.current_stream(local.device).cuda_stream), "dvq_allgather_params")
+        collective_used = "dvq_allgather_params (C ABI -> RCCL ncclAllGather on the caller's stream)"
+    else:
+        dist.all_gather_into_tensor(out, local)
+        collective_used = f"torch.distributed {dist.get_backend()} all_gather_into_tensor"
+    return out
+
+
 def all_gather_rows(local: torch.Tensor, total_rows: Optional[int] = None, verify: bool = True) -> torch.Tensor:
     """Rank-major concatenation of every rank's ``[rows_r, C]`` tensor (ragged shards allowed).
 
@@ -88,13 +134,10 @@ def all_gather_rows(local: torch.Tensor, total_rows: Optional[int] = None, verif
     total = sizes[-1][1]
     pad = max(hi - lo for lo, hi in sizes)
     if all(hi - lo == pad for lo, hi in sizes):               # equal shards: one collective straight into the result
-        out = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local)
-        return out
+        return _gather_equal(local, world)
     buf = torch.zeros((pad,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     buf[: local.shape[0]] = local
-    out = torch.empty((pad * world,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, buf)
+    out = _gather_equal(buf, world)                           # ragged: padded shards, the padding cut out afterwards
     return torch.cat([out[r * pad: r * pad + (hi - lo)] for r, (lo, hi) in enumerate(sizes)])
 
 
@@ -112,5 +155,10 @@ def max_over_ranks(value: float, device) -> float:
 
 
 def shutdown():
+    if _comms:
+        from . import _lib
+        for h in _comms.values():
+            _lib.load().dvq_comm_destroy(h)
+        _comms.clear()
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -252,6 +252,21 @@ int dvq_interior(const float* normals /* [B,V,3] */, const float* hand /* [B,V,3
                  int64_t obj_batch_stride, int64_t obj_point_stride, int64_t obj_coord_stride,
                  const int64_t* nn_idx /* [B,N] */, int64_t B, int N, uint8_t* interior /* [B,N] */, dvq_stream_t stream);
 
+/* ------------------------------------------------------------------ all-gather of the generated MANO parameters (multi-GPU)
+ * The batch of objects shards contiguously over R ranks (one process per GPU); the only exchange of the path is
+ * the all-gather of the [B/R, 61] parameter rows (61-parameter assembly, gen_diverse_grasp_obman.py:243-247) into [B, 61],
+ * rank-major: RCCL over xGMI.  The reference has no distributed code (nothing to replace); the op is new.
+ *   dvq_comm_unique_id : rank 0 makes the 128-byte id; the caller hands it to every rank (any side channel)
+ *   dvq_comm_init      : every rank, on its own device (hipSetDevice first): the communicator
+ *   dvq_allgather_params: out[r * rows_per_rank + i, :] = rank r's local[i, :]; enqueued on `stream`; equal shards only
+ *                        (ragged batches: pad the shard, the host mirror does)
+ * RCCL is resolved at the first call (dlopen); without it these return DVQ_ENODEVICE and the rest of the library is unaffected. */
+int dvq_comm_unique_id(void* id_out, size_t id_bytes /* >= 128 */);
+int dvq_comm_init(const void* id, size_t id_bytes, int world, int rank, void** comm_out);
+int dvq_allgather_params(void* comm, const float* local /* [rows_per_rank, cols] */, int64_t rows_per_rank, int cols /* 61 */,
+                         float* out /* [world * rows_per_rank, cols] */, dvq_stream_t stream);
+int dvq_comm_destroy(void* comm);
+
 /* ------------------------------------------------------------------ optional per-launch timing
  * When enabled, every kernel launch of the library is bracketed by two HIP events on its stream.
  * dvq_prof_read waits for the recorded events and returns per-kernel-kind totals (bench.py's roofline leg). */

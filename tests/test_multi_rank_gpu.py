@@ -4,8 +4,9 @@ Every test starts FRESH child processes (a process that has initialised the GPU 
   (a) ``bench.py --gpus 2 --share-gpu --backend gloo``: the N > 1 code path of the benchmark itself (rendezvous, sharded
       inputs, device noise keyed by the global row, all-gather, barrier + max-over-ranks timing, rank-0 JSON); the gathered
       parameters must equal, bit for bit, those of the --gpus 1 run of the same global batch (strong scaling);
-  (b) ``bench.py --gpus 1 --force-pg --backend nccl``: RCCL itself -- process-group init, all_gather_into_tensor, barrier,
-      all_reduce(MAX) on device tensors -- runs at world size 1 and gives the same bits again;
+  (b) ``bench.py --gpus 1 --force-pg --backend nccl``: RCCL itself -- process-group init, the C ABI's communicator
+      (dvq_comm_unique_id / dvq_comm_init) and dvq_allgather_params, barrier, all_reduce(MAX) on device tensors -- runs at
+      world size 1 and gives the same bits again;
   (c) ``gen_diverse_grasp_ho3d.py`` under two ranks writes the same JSON files as one rank (objects sharded over ranks,
       rotations and noise keyed by the global object index)."""
 import json
@@ -60,7 +61,7 @@ def test_bench_ragged_shards_three_ranks(single):
 
 def test_bench_rccl_world_size_one(single):
     one = _bench(["--gpus", "1", "--force-pg", "--backend", "nccl"])
-    assert "nccl" in one["config"]["collective"], one["config"]["collective"]
+    assert "dvq_allgather_params" in one["config"]["collective"] and "RCCL" in one["config"]["collective"], one["config"]["collective"]
     assert one["gathered_sha256"] == single["gathered_sha256"]
 
 
