@@ -565,13 +565,21 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
         // the first four tiles' entries are loaded once (N <= 1024: all of them), the rest in blocks of four
         const f32x4 f0 = pt[n], f1 = pt[min(1, tiles - 1) * 1024 + n], f2 = pt[min(2, tiles - 1) * 1024 + n],
                     f3 = pt[min(3, tiles - 1) * 1024 + n];
+        // a non-finite bound or top score in ANY tile sends the channel to the "everything" path (fmaxf drops a NaN: tested apart)
+        bool nonfinite = false;
+        auto fold = [&](float e, float top) {
+            nonfinite = nonfinite || !(e < 3.0e38f) || !(fabsf(top) < 3.0e38f);
+            e_all = fmaxf(e_all, e);
+            lb = fmaxf(lb, top - e);
+        };
         {
             const float e0 = bound(0);
             e_all = e0;
             lb = f0[0] - e0;
-            if (tiles > 1) { const float e = bound(1); e_all = fmaxf(e_all, e); lb = fmaxf(lb, f1[0] - e); }
-            if (tiles > 2) { const float e = bound(2); e_all = fmaxf(e_all, e); lb = fmaxf(lb, f2[0] - e); }
-            if (tiles > 3) { const float e = bound(3); e_all = fmaxf(e_all, e); lb = fmaxf(lb, f3[0] - e); }
+            nonfinite = !(e0 < 3.0e38f) || !(fabsf(f0[0]) < 3.0e38f);
+            if (tiles > 1) fold(bound(1), f1[0]);
+            if (tiles > 2) fold(bound(2), f2[0]);
+            if (tiles > 3) fold(bound(3), f3[0]);
         }
         for (int t0 = 4; t0 < tiles; t0 += 4) {
             float top[4];
@@ -579,15 +587,11 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
             for (int u = 0; u < 4; ++u) top[u] = pt[min(t0 + u, tiles - 1) * 1024 + n][0];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (t0 + u < tiles) {
-                    const float et = bound(t0 + u);
-                    e_all = fmaxf(e_all, et);
-                    lb = fmaxf(lb, top[u] - et);
-                }
+                if (t0 + u < tiles) fold(bound(t0 + u), top[u]);
         }
         int cands = 0;
         bool whole = false;
-        const bool all = exhaustive || !(e_all < 3.0e38f) || !(lb > NEG_BIG) || !(lb < 3.0e38f);   // non-finite inputs: evaluate everything
+        const bool all = exhaustive || nonfinite || !(e_all < 3.0e38f) || !(lb > NEG_BIG) || !(lb < 3.0e38f);   // non-finite inputs: evaluate everything
         if (all) {
             all_list[atomicAdd(&all_count, 1)] = (short)n;
             cand_n[n] = 0;

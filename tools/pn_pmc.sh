@@ -21,14 +21,14 @@ for sub in ("a", "b", "c"):
         for row in csv.DictReader(open(p)):
             name = row["Kernel_Name"]
             if "pn_" not in name: continue
-            key = name.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
+            key = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
             a = acc[key][row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
     for p in glob.glob(f"{out}/{sub}/**/*kernel_trace.csv", recursive=True):
         if sub != "a": continue
         for row in csv.DictReader(open(p)):
             name = row["Kernel_Name"]
             if "pn_" not in name: continue
-            key = name.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
+            key = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
             d = dur[key]; d[0] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3; d[1] += 1
 doc = {"command": f"rocprofv3 --kernel-trace --pmc <8 SQ counters> -- python3 tools/pn_filter_bench.py (PN_B={__import__('os').environ.get('PN_B')}, N=1024, C=4), three passes",
        "units": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves; SQ_VALU_MFMA_BUSY_CYCLES and SQ_BUSY_CYCLES count cycles (per SE / XCD sums as rocprofv3 reports them); per launch averages",
