@@ -34,6 +34,10 @@ class GemmSrc(C.Structure):
                 ("K", C.c_int32), ("_pad", C.c_int32), ("wp", C.c_void_p), ("wp_plane", C.c_int64)]
 
 
+class MlpLayer(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("wp", C.c_void_p), ("n_out", C.c_int32), ("k_in", C.c_int32)]
+
+
 class PointnetWeights(C.Structure):
     _fields_ = [("C", C.c_int32), ("_pad", C.c_int32)] + [
         (n, C.c_void_p) for n in (
@@ -70,6 +74,8 @@ SIGNATURES = {
     "dvq_device_count": (C.c_int, []),
     "dvq_reload_env": (C.c_int, []),
     "dvq_linear": (C.c_int, [C.POINTER(GemmSrc), C.c_int, C.c_int64, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int64, c_stream]),
+    "dvq_mlp3_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
+    "dvq_mlp3": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.POINTER(MlpLayer), c_f32p, C.c_int64, C.c_void_p, C.c_size_t, c_stream]),
     "dvq_split_bf16x3": (C.c_int, [c_f32p, C.c_int64, C.c_void_p, c_stream]),
     "dvq_vq_argmin_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "dvq_vq_argmin": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_int, c_i64p, c_f32p, C.c_void_p,

@@ -225,3 +225,41 @@ extern "C" int dvq_linear(const dvq_gemm_src* src, int nsrc, int64_t M, int N, c
     p.relu = act == DVQ_ACT_RELU;
     return dvq_launch_gemm(p, EPI_BIAS, (hipStream_t)stream);
 }
+
+// Decoder / Encoder MLP (three Linear layers, ReLU after the first two: network/DVQVAE.py:145-185) as ONE entry point: the
+// hidden activations live in the caller's workspace, the three GEMMs are enqueued back to back on the stream.
+extern "C" size_t dvq_mlp3_workspace_bytes(int64_t M, int n0, int n1) {
+    return dvq_round_up((size_t)(M > 0 ? M : 0) * (size_t)n0 * 4, 256) + dvq_round_up((size_t)(M > 0 ? M : 0) * (size_t)n1 * 4, 256) + 256;
+}
+
+extern "C" int dvq_mlp3(const float* x, int64_t ldx, int64_t M, const dvq_mlp_layer* L, float* y, int64_t ldy, void* workspace,
+                        size_t workspace_bytes, dvq_stream_t stream) {
+    DVQ_REQUIRE(L && M >= 0, "dvq_mlp3: bad arguments");
+    if (M == 0) return DVQ_OK;
+    DVQ_REQUIRE(x && y && workspace && dvq_aligned16(workspace), "dvq_mlp3: null/unaligned pointer");
+    DVQ_REQUIRE(L[1].k_in == L[0].n_out && L[2].k_in == L[1].n_out, "dvq_mlp3: layer sizes %d->%d, %d->%d, %d->%d do not chain", L[0].k_in,
+                L[0].n_out, L[1].k_in, L[1].n_out, L[2].k_in, L[2].n_out);
+    if (workspace_bytes < dvq_mlp3_workspace_bytes(M, L[0].n_out, L[1].n_out)) {
+        dvq_set_error("dvq_mlp3: workspace %zu < %zu bytes", workspace_bytes, dvq_mlp3_workspace_bytes(M, L[0].n_out, L[1].n_out));
+        return DVQ_EWORKSPACE;
+    }
+    float* h0 = (float*)workspace;
+    float* h1 = (float*)((char*)workspace + dvq_round_up((size_t)M * L[0].n_out * 4, 256));
+    const float* in[3] = {x, h0, h1};
+    const long ldi[3] = {(long)ldx, (long)L[0].n_out, (long)L[1].n_out};
+    float* out[3] = {h0, h1, y};
+    const long ldo[3] = {(long)L[0].n_out, (long)L[1].n_out, (long)ldy};
+    for (int i = 0; i < 3; ++i) {
+        GemmParams p = {};
+        p.src[0] = GemmSrc{in[i], L[i].w, ldi[i], (long)L[i].k_in, L[i].k_in, 0, L[i].wp, (long)L[i].n_out * L[i].k_in};
+        p.nsrc = 1;
+        p.M = M;
+        p.N = L[i].n_out;
+        p.bias = L[i].b;
+        p.out = out[i];
+        p.ldo = ldo[i];
+        p.relu = i < 2;
+        DVQ_PROPAGATE(dvq_launch_gemm(p, EPI_BIAS, (hipStream_t)stream));
+    }
+    return DVQ_OK;
+}

@@ -38,14 +38,14 @@ class _MLP(nn.Module):
         return hit[1]
 
     def _run(self, x, final=None):
-        layers = [m for m in self.MLP if isinstance(m, nn.Linear)]
+        layers = [m for m in self.MLP if isinstance(m, nn.Linear)] + ([final] if final is not None else [])
+        if len(layers) == 3:                                   # Decoder (3 Linear) and Encoder (2 Linear + linear_means): one ABI call
+            return ops.mlp3(x if x.is_contiguous() else x.contiguous(),
+                            [(l.weight.detach(), l.bias.detach(), self._planes(l)) for l in layers])
         n = len(layers)
         for i, lin in enumerate(layers):
-            last = final is None and i + 1 == n
             x = ops.linear(x if x.is_contiguous() else x.contiguous(), lin.weight.detach(), lin.bias.detach(),
-                           relu=not last, planes=self._planes(lin))
-        if final is not None:
-            x = ops.linear(x, final.weight.detach(), final.bias.detach(), planes=self._planes(final))
+                           relu=i + 1 < n, planes=self._planes(lin))
         return x
 
 

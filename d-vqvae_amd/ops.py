@@ -125,6 +125,38 @@ def linear_multi(pairs: Sequence[Tuple[Tensor, Tensor]], bias: Optional[Tensor] 
     return out
 
 
+def mlp3(x: Tensor, layers, out: Optional[Tensor] = None) -> Tensor:
+    """Linear + ReLU, Linear + ReLU, Linear (dvq_mlp3: Decoder / Encoder of network/DVQVAE.py).
+    ``layers`` = three (weight [n_out, k_in], bias or None, planes or None) tuples."""
+    lib = _lib.load()
+    dev = _require_gpu(x, out, *[t for l in layers for t in l])
+    if len(layers) != 3:
+        raise RuntimeError("mlp3: exactly three layers")
+    px, ldx = _rows(_f32(x, "x"), "x")
+    M = x.shape[0]
+    arr = (_lib.MlpLayer * 3)()
+    k = x.shape[1]
+    for i, (w, b, pl) in enumerate(layers):
+        _f32(w, "weight")
+        if not w.is_contiguous() or w.shape[1] != k or (b is not None and (b.numel() != w.shape[0] or not b.is_contiguous())):
+            raise RuntimeError(f"mlp3: layer {i} has weight {tuple(w.shape)} for {k} inputs")
+        if pl is not None and (pl.dtype != torch.int16 or tuple(pl.shape) != (3,) + tuple(w.shape) or not pl.is_contiguous()):
+            raise RuntimeError("mlp3: planes must be the contiguous int16 [3,N,K] split of the weight")
+        arr[i] = _lib.MlpLayer(w.data_ptr(), b.data_ptr() if b is not None else None, pl.data_ptr() if pl is not None else None,
+                               w.shape[0], w.shape[1])
+        k = w.shape[0]
+    if out is None:
+        out = torch.empty(M, k, dtype=torch.float32, device=dev)
+    po, ldo = _rows(_f32(out, "out"), "out")
+    if tuple(out.shape) != (M, k):
+        raise RuntimeError("mlp3: bad output shape")
+    nws = lib.dvq_mlp3_workspace_bytes(M, layers[0][0].shape[0], layers[1][0].shape[0])
+    ws = workspace(nws, dev, tag="mlp3")
+    with torch.cuda.device(dev):
+        check(lib.dvq_mlp3(px, ldx, M, arr, po, ldo, ws.data_ptr(), ws.numel(), _stream(dev)), "dvq_mlp3")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ VQ
 def vq_fast_supported(K: int, D: int) -> bool:
     return bool(_lib.load().dvq_vq_fast_supported(K, D))

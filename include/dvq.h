@@ -69,6 +69,18 @@ typedef struct {
 
 int dvq_linear(const dvq_gemm_src* src_host, int nsrc, int64_t M, int N, const float* bias,
                int act, float* y, int64_t ldy, dvq_stream_t stream);
+/* Decoder.forward / Encoder.forward (network/DVQVAE.py:161-166, 183-185): Linear + ReLU, Linear + ReLU, Linear as one entry
+ * point (SURVEY.md 8b `mlp3`): 2560 -> 1024 -> 256 -> 55, 2048 -> 1024 -> 128 -> 6, 1024 -> 1024 -> 512 -> 256.  Weights [n_out, k_in]
+ * dense row-major (nn.Linear's layout), `wp` optional pre-split planes (dvq_split_bf16x3); hidden sizes % 32 == 0. */
+typedef struct {
+    const float* w;      /* [n_out, k_in] */
+    const float* b;      /* [n_out] or NULL */
+    const uint16_t* wp;  /* optional [3][n_out][k_in] */
+    int32_t n_out, k_in;
+} dvq_mlp_layer;
+size_t dvq_mlp3_workspace_bytes(int64_t M, int n0, int n1);
+int dvq_mlp3(const float* x, int64_t ldx, int64_t M, const dvq_mlp_layer* layers_host /* [3] */, float* y, int64_t ldy,
+             void* workspace, size_t workspace_bytes, dvq_stream_t stream);
 /* planes[p][i] (p = 0,1,2; bf16 bit patterns) with w[i] == planes[0][i] + planes[1][i] + planes[2][i] exactly */
 int dvq_split_bf16x3(const float* w, int64_t n, uint16_t* planes, dvq_stream_t stream);
 

@@ -85,6 +85,24 @@ def test_linear_rejects_bad_inputs():
         ops.linear(torch.zeros(4, 64, device=DEV), torch.zeros(8, 32, device=DEV))       # K mismatch
 
 
+@pytest.mark.parametrize("sizes", [(2560, 1024, 256, 55), (2048, 1024, 128, 6), (1024, 1024, 512, 256)])
+def test_mlp3_equals_three_linears_bitwise(sizes):
+    """dvq_mlp3 (Decoder / Encoder as one entry point) = the same three GEMM launches as three dvq_linear calls."""
+    ws = [gpu(synth.synthetic_normal((sizes[i + 1], sizes[i]), SEED, f"mlp3/w/{i}", sizes[i] ** -0.5)) for i in range(3)]
+    bs = [gpu(synth.synthetic_normal((sizes[i + 1],), SEED, f"mlp3/b/{i}", 0.1)) for i in range(3)]
+    pls = [packing.split_bf16x3(w) for w in ws]
+    for M in (1, 37, 3000):
+        x = gpu(synth.synthetic_normal((M, sizes[0]), SEED, f"mlp3/x/{M}"))
+        h = x
+        for i in range(3):
+            h = ops.linear(h, ws[i], bs[i], relu=i < 2, planes=pls[i])
+        assert torch.equal(ops.mlp3(x, [(ws[i], bs[i], pls[i]) for i in range(3)]), h)
+        assert torch.equal(ops.mlp3(x, [(ws[i], bs[i], None) for i in range(3)]), h)
+    assert ops.mlp3(torch.zeros(0, sizes[0], device=DEV), [(ws[i], bs[i], None) for i in range(3)]).shape == (0, sizes[3])
+    with pytest.raises(RuntimeError):
+        ops.mlp3(torch.zeros(4, sizes[0], device=DEV), [(ws[0], bs[0], None), (ws[2], bs[2], None), (ws[1], bs[1], None)])
+
+
 # ------------------------------------------------------------------------------------------ VQ
 @pytest.mark.parametrize("K,D", [(128, 256), (128, 1024), (512, 256)])
 def test_vq_argmin_golden_and_canonical(golden, K, D):
@@ -229,6 +247,23 @@ def test_pointnet_filter_equals_exhaustive_exact_evaluation(C, N, B):
     feat6, trans6, _ = _with_env("DVQ_PN_FILTER", "0", lambda: net(x))
     assert_close(trans, trans6, atol=TOL, what="filtered trunk vs six-product trunk (trans)")
     assert_close(feat, feat6, atol=TOL, what="filtered trunk vs six-product trunk (feat)")
+
+
+def test_pointnet_filter_full_machine_repeatability():
+    """Regression (round 3): with compiler-formed packed-fp32 instructions pn_trunk_filter_kernel published a wrong
+    top-three record about once per 1e6 (tile, channel) pairs when two workgroups shared a CU -- one feature of one cloud in
+    ~4 % of 65 536-cloud calls (csrc/Makefile).  Two clouds that hit it within a few calls, 4 096 copies each
+    (every CU busy with two workgroups): every copy must give the bits of the exhaustive evaluation, six calls in a row."""
+    net, _ = _gennet()
+    clouds = gpu(synth.synthetic_clouds(2048, 1024, seed=91))
+    for enc in (net.obj_encoder_pos, net.obj_encoder_type):
+        for sample in (1436, 1197):
+            x = clouds[sample:sample + 1].repeat(4096, 1, 1).contiguous()
+            want = _with_env("DVQ_PN_EXHAUSTIVE", "1", lambda: enc(x[:1].contiguous()))[0]
+            for call in range(6):
+                feat = enc(x)[0]
+                bad = int((feat != want).any(1).sum())
+                assert bad == 0, f"cloud {sample}, call {call}: {bad} of 4096 copies differ from the exhaustive evaluation"
 
 
 def test_pointnet_filter_list_overflow_paths():
