@@ -66,14 +66,20 @@ class GenNet(nn.Module):
             ops.vq_lookup(E, flat[:, i * 3 + j], out=z_out[:, 256 * k: 256 * (k + 1)], err=err)
         return self.decoder(z_out).view(B, 55)
 
-    @torch.no_grad()
-    def gen(self, obj, noise=None, return_aux=False, seed=None, row0=None, stream_id=None):
-        """obj [B,4,N] f32 on the GPU -> (recon [B,55], recon_pos [B,6]).
-        ``noise`` [B,9,prior_tokens] ~ Exp(1) fixes the prior's draws (parity runs).  Without it the draws come from the
-        device Philox generator keyed by (seed, stream_id, row0 + b): a batch sharded over ranks (``row0`` = first global
-        row of the shard, same ``seed`` / ``stream_id``) generates exactly what the unsharded call generates (SURVEY 8e).
-        Defaults: seed = set_noise_seed's, else torch.initial_seed(); one stream per call; rows of this rank
-        (ops.default_noise_key), so ranks that name nothing never share noise."""
+    def _draw_noise(self, B, dev, seed, row0, stream_id, out=None):
+        """[B, 9, prior_tokens] Exp(1) variates of the device Philox generator under gen()'s key rules."""
+        n_in = self.GatedPixelCNN.packed().n_in
+        if stream_id is None:
+            stream_id = self._noise_stream
+            self._noise_stream += 1
+        dseed, drow = ops.default_noise_key()
+        if seed is None:
+            seed = dseed if self.noise_seed is None else self.noise_seed
+        flat = out.view(B, 9 * n_in) if out is not None else None
+        return ops.exp1_noise(B, 9 * n_in, seed, drow if row0 is None else row0, stream_id, device=dev, out=flat).view(B, 9, n_in)
+
+    def _gen_impl(self, obj, noise):
+        """The device work of gen(): no host synchronisation inside (gen() checks the error flag once at the end)."""
         if obj.dim() != 3:
             raise RuntimeError(f"gen: expected obj [B,4,N], got {tuple(obj.shape)}")
         B, dev = obj.shape[0], obj.device
@@ -87,14 +93,6 @@ class GenNet(nn.Module):
         label = idx6[:, 0].contiguous()                                    # per-sample label
         err = ops.new_err_flag(dev)
         pk = self.GatedPixelCNN.packed()
-        if noise is None:
-            if stream_id is None:
-                stream_id = self._noise_stream
-                self._noise_stream += 1
-            dseed, drow = ops.default_noise_key()
-            if seed is None:
-                seed = dseed if self.noise_seed is None else self.noise_seed
-            noise = ops.exp1_noise(B, 9 * pk.n_in, seed, drow if row0 is None else row0, stream_id, device=dev).view(B, 9, pk.n_in)
         # The gated GEMMs add the class-conditional row cls[label[m]] in their epilogue: with rows in arrival order every lane of a
         # store instruction gathers from a different 4 KB row of the table; sorted by label a 128-row tile holds one or two labels
         # and the gather is a broadcast again (measured: -10 % on the gated GEMMs at 65 536 grasps with 123 distinct object codes).
@@ -110,13 +108,28 @@ class GenNet(nn.Module):
         verts = self._hand_vertices(recon)                                 # :116-118
         self.recon_encoder(verts, out=z_pos[:, :1024])                     # :120
         recon_pos = self.pos_decoder(z_pos).view(B, 6)                     # :122-123
+        aux = dict(idx6=idx6, codes=codes, feat_type=feat_type, feat_pos=z_pos[:, 1024:], verts=verts, hand_feat=z_pos[:, :1024])
+        return recon, recon_pos, aux, err
+
+    _RANGE_ERROR = ("GenNet.gen: code or label index out of range (prior classes vs codebook rows, "
+                    "gen_net.py:20-34); build GenNet(n_embeddings=...) to match the prior")
+
+    @torch.no_grad()
+    def gen(self, obj, noise=None, return_aux=False, seed=None, row0=None, stream_id=None):
+        """obj [B,4,N] f32 on the GPU -> (recon [B,55], recon_pos [B,6]).
+        ``noise`` [B,9,prior_tokens] ~ Exp(1) fixes the prior's draws (parity runs).  Without it the draws come from the
+        device Philox generator keyed by (seed, stream_id, row0 + b): a batch sharded over ranks (``row0`` = first global
+        row of the shard, same ``seed`` / ``stream_id``) generates exactly what the unsharded call generates (SURVEY 8e).
+        Defaults: seed = set_noise_seed's, else torch.initial_seed(); one stream per call; rows of this rank
+        (ops.default_noise_key), so ranks that name nothing never share noise."""
+        if obj.dim() != 3:
+            raise RuntimeError(f"gen: expected obj [B,4,N], got {tuple(obj.shape)}")
+        if noise is None:
+            noise = self._draw_noise(obj.shape[0], obj.device, seed, row0, stream_id)
+        recon, recon_pos, aux, err = self._gen_impl(obj, noise)
         if int(err.item()) != 0:
-            raise RuntimeError("GenNet.gen: code or label index out of range (prior classes vs codebook rows, "
-                               "gen_net.py:20-34); build GenNet(n_embeddings=...) to match the prior")
-        if return_aux:
-            return recon, recon_pos, dict(idx6=idx6, codes=codes, feat_type=feat_type, feat_pos=z_pos[:, 1024:],
-                                          verts=verts, hand_feat=z_pos[:, :1024])
-        return recon, recon_pos
+            raise RuntimeError(self._RANGE_ERROR)
+        return (recon, recon_pos, aux) if return_aux else (recon, recon_pos)
 
     @torch.no_grad()
     def gen_byid(self, idx6, noise=None):
@@ -128,3 +141,4 @@ class GenNet(nn.Module):
         self.GatedPixelCNN.generate(None, idx6, shape=(3, 3), batch_size=B, noise=noise)
         recon = self.decoder(torch.zeros(B, 2560, device=dev)).view(B, 55)
         return recon, torch.zeros(B, 6, device=dev)
+

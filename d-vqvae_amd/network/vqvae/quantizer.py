@@ -79,8 +79,10 @@ class VectorQuantizer(nn.Module):
                 idx = ops.vq_argmin(zf, E, fast=False)
             else:
                 idx = ops.vq_argmin(zf, E, packed=packed, slow_rows=st["counter"])
-                self._regime_update(st, zf.shape[0])
-        z_q = ops.vq_lookup(E, idx).view(z.shape)
+                if not torch.cuda.is_current_stream_capturing():       # the probe copies to the host: not inside a graph capture
+                    self._regime_update(st, zf.shape[0])
+        # idx comes from the argmin kernels: in range by construction, so the flag is supplied and never read (no host sync here)
+        z_q = ops.vq_lookup(E, idx, err=ops.new_err_flag(zf.device)).view(z.shape)
         return idx.unsqueeze(1), z_q
 
     def forward(self, z, istrain):
