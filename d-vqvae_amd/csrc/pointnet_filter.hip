@@ -526,7 +526,8 @@ __device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k &
 //           point for the channels on the "everything" list (DVQ_PN_EXHAUSTIVE / non-finite inputs).
 // stats (optional): channels with one candidate, with another count, wave entries, candidates.
 constexpr int PAIR_CAP = 1024;
-constexpr int FB_CAP = 2048;
+constexpr int FB_CAP = 512;
+constexpr int SORT_CAP = 3072;                            // (channel, point) pairs evaluated in point order; more: channel order
 __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restrict__ part, int tiles, const float* __restrict__ h2buf,
                                                        int N, int Npad, const float* __restrict__ w3, const float* __restrict__ b3,
                                                        const float* __restrict__ wnorm, const float* __restrict__ rnorm,
@@ -543,9 +544,14 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
     __shared__ float fb_part[16];
     __shared__ float hm[MAX_TILES], dm[MAX_TILES], rd[MAX_TILES];
     __shared__ unsigned best_k[1024];
+    __shared__ int pcnt[1024];                             // pairs per point -> first slot of the point -> fill cursor
+    __shared__ unsigned sorted[SORT_CAP];                  // channel | point << 10, grouped by point
+    __shared__ int wave_tot[4];
     const int tid = threadIdx.x, g = tid >> 4, j = tid & 15;
     const long b = blockIdx.x;
     if (tid == 0) { pair_count = 0; fb_count = 0; all_count = 0; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pcnt[tid + 256 * i] = 0;
     if (tid < tiles) {
         const unsigned* ts = tstat + 4 * (b * tiles + tid);
         hm[tid] = __uint_as_float(ts[0]) * 1.00001f;
@@ -648,8 +654,74 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
         n_cand += cands;
     }
     __syncthreads();
-    // ---- phase B: table; four channels of a group in flight (first candidates), further candidates afterwards
-    for (int n0 = g; n0 < ((abl & 64) ? 0 : 1024); n0 += 64) {
+    // ---- phase A2: the pairs in POINT order (counting sort in the LDS).  A cloud's 1 024 channels take their maxima at ~100-200
+    // distinct points, so ~1 500 candidate pairs name each conv2 row ~10 times: evaluated channel by channel every pair fetched
+    // its 512-byte row from HBM again (0.74 MB per cloud, the kernel ran at the HBM roofline); grouped by point a row is
+    // fetched once and found in the L1 by the pairs that follow.
+    const int npairs = min(pair_count, pair_cap);
+    for (int n = tid; n < 1024; n += 256)
+        for (int k = 0; k < cand_n[n]; ++k) atomicAdd(&pcnt[cand[n][k] & 1023], 1);     // N > 1024: points 1024 apart share a slot range
+    for (int i = tid; i < npairs; i += 256) atomicAdd(&pcnt[(pair_list[i] >> 10) & 1023], 1);
+    __syncthreads();
+    int total;
+    {
+        const int c0 = pcnt[4 * tid], c1 = pcnt[4 * tid + 1], c2 = pcnt[4 * tid + 2], c3 = pcnt[4 * tid + 3];
+        int incl = c0 + c1 + c2 + c3;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if ((tid & 63) >= o) incl += v;
+        }
+        if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < (tid >> 6); ++w) base += wave_tot[w];
+        total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        const int excl = base + incl - (c0 + c1 + c2 + c3);
+        pcnt[4 * tid] = excl;
+        pcnt[4 * tid + 1] = excl + c0;
+        pcnt[4 * tid + 2] = excl + c0 + c1;
+        pcnt[4 * tid + 3] = excl + c0 + c1 + c2;
+    }
+    __syncthreads();
+    const bool by_point = total <= SORT_CAP && !(abl & 64);
+    if (by_point) {
+        for (int n = tid; n < 1024; n += 256)
+            for (int k = 0; k < cand_n[n]; ++k) {
+                const int p = cand[n][k];
+                sorted[atomicAdd(&pcnt[p & 1023], 1)] = (unsigned)n | ((unsigned)p << 10);
+            }
+        for (int i = tid; i < npairs; i += 256) {
+            const int code = pair_list[i];
+            sorted[atomicAdd(&pcnt[(code >> 10) & 1023], 1)] = (unsigned)code;
+        }
+        __syncthreads();
+        // ---- phase B, point order: every 16-lane group takes a contiguous share of the list, four pairs in flight
+        const int per = (total + 15) >> 4, i0 = g * per, i1 = min(total, i0 + per);
+        for (int i = i0; i < i1; i += 4) {
+            f32x4 w0[4], w1[4], ha[4], hb[4];
+            int nn[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned code = sorted[min(i + u, i1 - 1)];
+                nn[u] = (int)(code & 1023u);
+                const float* wr = w3 + nn[u] * 128 + 8 * j;
+                w0[u] = *reinterpret_cast<const f32x4*>(wr);
+                w1[u] = *reinterpret_cast<const f32x4*>(wr + 4);
+                const float* hr = h2 + (long)(code >> 10) * 128 + 8 * j;
+                ha[u] = *reinterpret_cast<const f32x4*>(hr);
+                hb[u] = *reinterpret_cast<const f32x4*>(hr + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float v = exact_dot_regs(w0[u], w1[u], ha[u], hb[u]);
+                if (j == 0 && i + u < i1) atomicMax(&best_k[nn[u]], f2key(v));
+            }
+        }
+    }
+    // ---- phase B, channel order (more pairs than the sorted list holds): table; four channels of a group in flight (first
+    // candidates), further candidates afterwards
+    for (int n0 = g; n0 < ((abl & 64) || by_point ? 0 : 1024); n0 += 64) {
         f32x4 w0[4], w1[4], ha[4], hb[4];
         int cn[4];
 #pragma unroll
@@ -684,9 +756,8 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
             if (j == 0) atomicMax(&best_k[n], f2key(best));
         }
     }
-    // ---- phase B: overflow list
-    const int npairs = min(pair_count, pair_cap);
-    for (int i = g; i < npairs; i += 16) {
+    // ---- phase B, channel order: overflow list
+    for (int i = g; i < (by_point ? 0 : npairs); i += 16) {
         const int code = pair_list[i];
         const int n = code & 1023;
         const float* wr = w3 + n * 128 + 8 * j;
