@@ -851,69 +851,12 @@ __device__ __forceinline__ void skinny_prefetch(const GemmParams& p, int helper,
     if (sink == 0x9e3779b9u && p.M < 0) p.out[0] = 0.f;                   // never true: keeps the loads alive
 }
 
+// Epilogues of the skinny kernels: lane <-> row m, registers 4g..4g+3 <-> four consecutive columns nb0 + 8g + 4h (gemm_common.h,
+// gemm_epilogue_t_at: the same arithmetic in the same order).  `xch`: 4 KB of LDS for the gate's tanh / sigmoid exchange.
 template <int EPI>
-__global__ __launch_bounds__(128) void gemm_bf16x3_skinny_kernel(const GemmParams p, int n_col_wgs, int n_work) {
-    __shared__ __attribute__((aligned(16))) float xch[64 * 16];          // gate: the sigmoid block's 16 values per lane
-    const int tid = threadIdx.x;
-    if ((int)blockIdx.x >= n_work) {
-        skinny_prefetch(p, (int)blockIdx.x - n_work, (int)gridDim.x - n_work, tid);
-        return;
-    }
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
-    const long m0 = (long)((int)blockIdx.x / n_col_wgs) * 32;
-    const int n0 = ((int)blockIdx.x % n_col_wgs) * 64;                   // two 32-column blocks per workgroup
-    const int nb0 = n0 + 32 * wave;                                      // this wave's block
-    long m = m0 + r;
-    const bool m_ok = m < p.M;
-    if (!m_ok) m = p.M - 1;                                              // clamped rows / columns only feed masked outputs
-    int nrow = nb0 + r;
-    if (nrow >= p.N) nrow = p.N - 1;
-
-    f32x16 c;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) c[e] = 0.f;
-    SkinnyCursor cur;
-    cur.open(p, 0, m, nrow, h);
-    // two chunks (eight k-steps) in flight behind the one being multiplied; every K is a multiple of 64 here (launch check).
-    // The steady state has no branch around a load: with one the compiler's wait insertion falls back to vmcnt(0) before every
-    // use, i.e. one full memory latency per chunk.
-    int chunks = 0;
-    for (int s2 = 0; s2 < p.nsrc; ++s2) chunks += p.src[s2].K >> 6;
-    SkinnyChunk q0, q1, q2;
-    bf16x8 a0[3];
-    if (chunks >= 3) {
-        cur.load(p, m, nrow, h, q0);
-        cur.load(p, m, nrow, h, q1);
-        cur.load(p, m, nrow, h, q2);
-        skinny_fix(q0);
-        split_frag(q0.a[0], q0.a[1], a0);
-        int t = 0;
-        for (; t + 6 <= chunks; t += 3) {
-            // q0's successor q1 is already in flight; q0 itself is re-loaded only AFTER q1's fix-up has read ... nothing of q0
-            skinny_chunk(q0, q1, a0, c); cur.load(p, m, nrow, h, q0);
-            skinny_chunk(q1, q2, a0, c); cur.load(p, m, nrow, h, q1);
-            // q2's successor is the q0 just loaded: its fix-up waits for that load (two chunks of MFMAs behind it)
-            skinny_chunk(q2, q0, a0, c); cur.load(p, m, nrow, h, q2);
-        }
-        const int rem = chunks - t - 3;                                  // 0 .. 2 chunks not yet loaded; q0 is fixed and split
-        skinny_chunk(q0, q1, a0, c); if (rem > 0) cur.load(p, m, nrow, h, q0);
-        skinny_chunk(q1, q2, a0, c); if (rem > 1) cur.load(p, m, nrow, h, q1);
-        if (rem > 0) {
-            skinny_chunk(q2, q0, a0, c);
-            if (rem > 1) { skinny_chunk(q0, q1, a0, c); skinny_chunk_last(q1, a0, c); }
-            else skinny_chunk_last(q0, a0, c);
-        } else skinny_chunk_last(q2, a0, c);
-    } else {
-        if (chunks > 0) cur.load(p, m, nrow, h, q0);
-        if (chunks > 1) cur.load(p, m, nrow, h, q1);
-        if (chunks > 0) { skinny_fix(q0); split_frag(q0.a[0], q0.a[1], a0); }
-        if (chunks > 1) { skinny_chunk(q0, q1, a0, c); skinny_chunk_last(q1, a0, c); }
-        else if (chunks > 0) skinny_chunk_last(q0, a0, c);
-    }
-    // ---- epilogues: lane <-> row m, registers 4g..4g+3 <-> four consecutive columns nb0 + 8g + 4h (gemm_common.h,
-    // gemm_epilogue_t_at: the same arithmetic in the same order)
+__device__ __forceinline__ void skinny_epilogue(const GemmParams& p, const f32x16& c, float* xch, long m0, int n0, int nb0, int r, int h,
+                                                int lane, int wave, bool m_ok) {
+    long m;
     m = m0 + r;
     if constexpr (EPI == EPI_BIAS || EPI == EPI_RESID) {
         if (!m_ok) return;
@@ -976,6 +919,300 @@ __global__ __launch_bounds__(128) void gemm_bf16x3_skinny_kernel(const GemmParam
     }
 }
 
+template <int EPI>
+__global__ __launch_bounds__(128) void gemm_bf16x3_skinny_kernel(const GemmParams p, int n_col_wgs, int n_work) {
+    __shared__ __attribute__((aligned(16))) float xch[64 * 16];          // gate: the sigmoid block's 16 values per lane
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= n_work) {
+        skinny_prefetch(p, (int)blockIdx.x - n_work, (int)gridDim.x - n_work, tid);
+        return;
+    }
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const long m0 = (long)((int)blockIdx.x / n_col_wgs) * 32;
+    const int n0 = ((int)blockIdx.x % n_col_wgs) * 64;                   // two 32-column blocks per workgroup
+    const int nb0 = n0 + 32 * wave;                                      // this wave's block
+    long m = m0 + r;
+    const bool m_ok = m < p.M;
+    if (!m_ok) m = p.M - 1;                                              // clamped rows / columns only feed masked outputs
+    int nrow = nb0 + r;
+    if (nrow >= p.N) nrow = p.N - 1;
+
+    f32x16 c;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) c[e] = 0.f;
+    SkinnyCursor cur;
+    cur.open(p, 0, m, nrow, h);
+    // two chunks (eight k-steps) in flight behind the one being multiplied; every K is a multiple of 64 here (launch check).
+    // The steady state has no branch around a load: with one the compiler's wait insertion falls back to vmcnt(0) before every
+    // use, i.e. one full memory latency per chunk.
+    int chunks = 0;
+    for (int s2 = 0; s2 < p.nsrc; ++s2) chunks += p.src[s2].K >> 6;
+    SkinnyChunk q0, q1, q2;
+    bf16x8 a0[3];
+    if (chunks >= 3) {
+        cur.load(p, m, nrow, h, q0);
+        cur.load(p, m, nrow, h, q1);
+        cur.load(p, m, nrow, h, q2);
+        skinny_fix(q0);
+        split_frag(q0.a[0], q0.a[1], a0);
+        int t = 0;
+        for (; t + 6 <= chunks; t += 3) {
+            // q0's successor q1 is already in flight; q0 itself is re-loaded only AFTER q1's fix-up has read ... nothing of q0
+            skinny_chunk(q0, q1, a0, c); cur.load(p, m, nrow, h, q0);
+            skinny_chunk(q1, q2, a0, c); cur.load(p, m, nrow, h, q1);
+            // q2's successor is the q0 just loaded: its fix-up waits for that load (two chunks of MFMAs behind it)
+            skinny_chunk(q2, q0, a0, c); cur.load(p, m, nrow, h, q2);
+        }
+        const int rem = chunks - t - 3;                                  // 0 .. 2 chunks not yet loaded; q0 is fixed and split
+        skinny_chunk(q0, q1, a0, c); if (rem > 0) cur.load(p, m, nrow, h, q0);
+        skinny_chunk(q1, q2, a0, c); if (rem > 1) cur.load(p, m, nrow, h, q1);
+        if (rem > 0) {
+            skinny_chunk(q2, q0, a0, c);
+            if (rem > 1) { skinny_chunk(q0, q1, a0, c); skinny_chunk_last(q1, a0, c); }
+            else skinny_chunk_last(q0, a0, c);
+        } else skinny_chunk_last(q2, a0, c);
+    } else {
+        if (chunks > 0) cur.load(p, m, nrow, h, q0);
+        if (chunks > 1) cur.load(p, m, nrow, h, q1);
+        if (chunks > 0) { skinny_fix(q0); split_frag(q0.a[0], q0.a[1], a0); }
+        if (chunks > 1) { skinny_chunk(q0, q1, a0, c); skinny_chunk_last(q1, a0, c); }
+        else if (chunks > 0) skinny_chunk_last(q0, a0, c);
+    }
+    skinny_epilogue<EPI>(p, c, xch, m0, n0, nb0, r, h, lane, wave, m_ok);
+}
+
+// ---- LDS-staged variant (round 3).  The register variant above fetches a lane's 128-byte line in four 16-byte pieces with four
+// instructions, each touching 32 different lines: 640 line accesses per 64-k chunk and wave, 1 280 per CU -- and a chunk took
+// 4 x 320 = 1 280 cycles whatever the split arithmetic or the prefetch depth: one cache line per clock, the vector memory
+// path's tag rate.  Here the loads are COALESCED (eight lanes per weight line, sixteen per activation row: 4x fewer line
+// accesses) and go through the LDS, whose reads produce the MFMA operand layout (conflict-free through an XOR of the 16-byte
+// piece index with (row >> 1) & 7).  Weights: private to the wave that multiplies them (source-side swizzle, lane-linear
+// writes, no synchronisation).  Activations: the two waves of the workgroup multiply the SAME rows, so each loads and splits
+// half of the chunk (16 rows) into bf16 planes in a shared slot -- half the split arithmetic per wave, none in the MFMA
+// loop -- with one two-wave barrier per chunk.  A single in-order wave per SIMD can issue ~48 instructions in the 192 cycles of
+// a k-step's six dependent MFMAs: the loop has 6 MFMAs + 6 LDS reads per k-step and ~35 more per k-step for the next chunk.
+typedef unsigned sk2_u4 __attribute__((ext_vector_type(4)));   // a native vector (HIP's uint4 is a struct: its copies become memcpy calls
+typedef unsigned sk2_u2 __attribute__((ext_vector_type(2)));   // that keep a load -> LDS-store buffer in scratch memory)
+constexpr int SK2_PL = 32 * 128;                            // one plane of one operand: 32 rows x 64 k bf16
+constexpr int SK2_SLOT = 3 * SK2_PL;                        // 12 288
+constexpr int SK2_OFF_A = 2 * 2 * SK2_SLOT;                 // two waves x two weight slots, then two shared activation slots
+constexpr int SK2_OFF_X = SK2_OFF_A + 2 * SK2_SLOT;
+constexpr int SK2_SMEM = SK2_OFF_X + 4096;                  // 77 824 B
+
+constexpr int SK2_NP = 2;                                   // staging waves per column block: each takes 4 / SK2_NP load instructions
+constexpr int SK2_NI = 4 / SK2_NP;
+struct Sk2W { sk2_u4 w[3][SK2_NI]; };                       // its share of a chunk's weights as loaded: instruction, this lane's piece
+struct Sk2A { f32x4 a[SK2_NI]; };                           // its share of the block's half of the activations
+
+struct Sk2Cursor {                                          // wave-uniform source state of the weight and of the activation stream
+    int s, k_left, s_a, k_a;
+    const float* a_base;
+    const uint16_t* w_base[3];
+    int ldw, lda;
+
+    __device__ __forceinline__ void open(const GemmParams& p, int src_i) {
+        s = src_i;
+        if (s >= p.nsrc) { k_left = 0; return; }
+        const GemmSrc& src = p.src[s];
+        k_left = src.K;
+        ldw = (int)src.ldw;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) w_base[pl] = src.Wp + pl * src.wp_plane;
+    }
+    __device__ __forceinline__ void open_a(const GemmParams& p, int src_i) {
+        s_a = src_i;
+        if (s_a >= p.nsrc) { k_a = 0; return; }
+        const GemmSrc& src = p.src[s_a];
+        k_a = src.K;
+        a_base = src.A;
+        lda = (int)src.lda;
+    }
+    // weights: instruction i covers rows 8i .. 8i+7 of the wave's 32, eight lanes per 128-byte line; the lane fetches the piece
+    // that belongs at its lane-linear LDS position: logical piece = (lane & 7) ^ f(row), f(row) = (row >> 1) & 7
+    __device__ __forceinline__ void load_w(const GemmParams& p, int nb0, int part, int lane, Sk2W& t) {
+        const int pe = (lane & 7) ^ ((lane >> 4) & 3);      // f(8i + (lane >> 3)) = (lane >> 4) + 4 (i & 1)
+#pragma unroll
+        for (int ii = 0; ii < SK2_NI; ++ii) {
+            const int i = SK2_NI * part + ii;
+            const int n = min(nb0 + 8 * i + (lane >> 3), p.N - 1);          // clamped rows / columns only feed masked outputs
+            const int off = n * ldw + 8 * (pe ^ (4 * (i & 1)));
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) t.w[pl][ii] = *reinterpret_cast<const sk2_u4*>(w_base[pl] + off);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) w_base[pl] += 64;
+        k_left -= 64;
+        if (k_left <= 0) open(p, s + 1);
+    }
+    // activations, half `wave` of the rows (16), this staging wave's instructions: rows 16 wave + 4i .. + 3, sixteen lanes per 256 bytes
+    __device__ __forceinline__ void load_a(const GemmParams& p, long m0, int wave, int part, int lane, Sk2A& t) {
+#pragma unroll
+        for (int ii = 0; ii < SK2_NI; ++ii) {
+            const int i = SK2_NI * part + ii;
+            const long m = min(m0 + 16 * wave + 4 * i + (lane >> 4), p.M - 1);
+            t.a[ii] = *reinterpret_cast<const f32x4*>(a_base + m * lda + 4 * (lane & 15));
+        }
+        a_base += 64;
+        k_a -= 64;
+        if (k_a <= 0) open_a(p, s_a + 1);
+    }
+};
+
+__device__ __forceinline__ void sk2_store_w(char* slot, int part, int lane, const Sk2W& t) {       // lane-linear: 1 KiB per instruction
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int ii = 0; ii < SK2_NI; ++ii) *reinterpret_cast<sk2_u4*>(slot + pl * SK2_PL + 1024 * (SK2_NI * part + ii) + 16 * lane) = t.w[pl][ii];
+}
+// exact three-way split of the lane's four floats per instruction, 8 bytes per plane into the shared slot
+__device__ __forceinline__ void sk2_store_a(char* slot, int wave, int part, int lane, const Sk2A& t) {
+#pragma unroll
+    for (int ii = 0; ii < SK2_NI; ++ii) {
+        const int row = 16 * wave + 4 * (SK2_NI * part + ii) + (lane >> 4);
+        unsigned pa[3], pb[3];
+        split3_pair(t.a[ii][0], t.a[ii][1], pa[0], pa[1], pa[2]);
+        split3_pair(t.a[ii][2], t.a[ii][3], pb[0], pb[1], pb[2]);
+        char* dst = slot + row * 128 + 16 * (((lane & 15) >> 1) ^ ((row >> 1) & 7)) + 8 * (lane & 1);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<sk2_u2*>(dst + pl * SK2_PL) = sk2_u2{pa[pl], pb[pl]};
+    }
+}
+
+struct Sk2Frag { sk2_u4 w[3], a[3]; };                     // one k-step in the MFMA operand layout, both operands as planes
+__device__ __forceinline__ void sk2_read(const char* wslot, const char* aslot, int j, int r, int h, Sk2Frag& f) {
+    const int o = r * 128 + 16 * ((2 * j + h) ^ ((r >> 1) & 7));
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        f.w[pl] = *reinterpret_cast<const sk2_u4*>(wslot + pl * SK2_PL + o);
+        f.a[pl] = *reinterpret_cast<const sk2_u4*>(aslot + pl * SK2_PL + o);
+    }
+}
+__device__ __forceinline__ void sk2_mfma(const Sk2Frag& f, f32x16& c) {
+    const bf16x8 a[3] = {__builtin_bit_cast(bf16x8, f.a[0]), __builtin_bit_cast(bf16x8, f.a[1]), __builtin_bit_cast(bf16x8, f.a[2])};
+    skinny_mfma(__builtin_bit_cast(uint4, f.w[0]), __builtin_bit_cast(uint4, f.w[1]), __builtin_bit_cast(uint4, f.w[2]), a, c);
+}
+// the four k-steps of one chunk; the reads of k-step j + 1 are issued before the six MFMAs of k-step j
+__device__ __forceinline__ void sk2_chunk(const char* wslot, const char* aslot, int r, int h, f32x16& c) {
+    Sk2Frag f0, f1;
+    sk2_read(wslot, aslot, 0, r, h, f0);
+    sk2_read(wslot, aslot, 1, r, h, f1);
+    sk2_mfma(f0, c);
+    sk2_read(wslot, aslot, 2, r, h, f0);
+    sk2_mfma(f1, c);
+    sk2_read(wslot, aslot, 3, r, h, f1);
+    sk2_mfma(f0, c);
+    sk2_mfma(f1, c);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(128 + 128 * SK2_NP) void gemm_bf16x3_skinny2_kernel(const GemmParams p, int n_col_wgs, int n_work) {
+    extern __shared__ __attribute__((aligned(16))) char sk2_smem[];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= n_work) {
+        if (tid < 128) skinny_prefetch(p, (int)blockIdx.x - n_work, (int)gridDim.x - n_work, tid);
+        return;
+    }
+    // Waves 0 and 1 multiply (two adjacent 32-column blocks: one dependent MFMA chain each, on SIMDs of their own); waves 2 .. stage
+    // for them: wave 2 + w + 2 part loads its share of block w's weights and of half w of the activations, splits, writes the LDS.
+    // A single in-order wave that did both spent 1 900 cycles per chunk: its ~220 staging instructions do not overlap with its
+    // own chain of dependent MFMAs unless every one of them is placed by hand.  One barrier per chunk for all waves.  What is left
+    // is the chain itself: a dependent v_mfma_f32_32x32x16 (same accumulator) issues every ~41 cycles, not every 32 -- measured
+    // 0.47 us per 24-MFMA chunk with two or four staging waves and with either consumer schedule.
+    const int lane = tid & 63;
+    const int wave4 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave4 >= 2;
+    const int wave = wave4 & 1;                                          // the column block this wave multiplies or stages
+    const int part = (wave4 >> 1) - 1;                                   // staging waves: which of the block's load instructions
+    const int r = lane & 31, h = lane >> 5;
+    const long m0 = (long)((int)blockIdx.x / n_col_wgs) * 32;
+    const int n0 = ((int)blockIdx.x % n_col_wgs) * 64;
+    const int nb0 = n0 + 32 * wave;
+    const bool m_ok = m0 + r < p.M;
+    char* w0 = sk2_smem + wave * 2 * SK2_SLOT;                           // block `wave`'s weight slots
+    char* w1 = w0 + SK2_SLOT;
+    char* a0 = sk2_smem + SK2_OFF_A;                                     // the workgroup's activation slots
+    char* a1 = a0 + SK2_SLOT;
+    float* xch = reinterpret_cast<float*>(sk2_smem + SK2_OFF_X);
+    int chunks = 0;
+    for (int s2 = 0; s2 < p.nsrc; ++s2) chunks += p.src[s2].K >> 6;     // every K is a multiple of 64 here (launch check)
+
+    if (producer) {
+        // chunk t + 1 is written while chunk t is multiplied; its loads were issued two iterations earlier
+        Sk2Cursor cur;
+        cur.open(p, 0);
+        cur.open_a(p, 0);
+        Sk2W wa, wb;
+        Sk2A aa, ab;
+        if (chunks > 0) {
+            cur.load_w(p, nb0, part, lane, wa); cur.load_a(p, m0, wave, part, lane, aa);                        // chunk 0
+            if (chunks > 1) { cur.load_w(p, nb0, part, lane, wb); cur.load_a(p, m0, wave, part, lane, ab); }    // chunk 1
+            sk2_store_w(w0, part, lane, wa);
+            sk2_store_a(a0, wave, part, lane, aa);
+            if (chunks > 2) { cur.load_w(p, nb0, part, lane, wa); cur.load_a(p, m0, wave, part, lane, aa); }    // chunk 2
+        }
+        __syncthreads();                                                 // chunk 0 is in its slots
+        int t = 0;
+        for (; t + 4 < chunks; t += 2) {                                 // no branch around a load in the steady state
+            sk2_store_w(w1, part, lane, wb); sk2_store_a(a1, wave, part, lane, ab);
+            cur.load_w(p, nb0, part, lane, wb); cur.load_a(p, m0, wave, part, lane, ab);
+            __syncthreads();
+            sk2_store_w(w0, part, lane, wa); sk2_store_a(a0, wave, part, lane, aa);
+            cur.load_w(p, nb0, part, lane, wa); cur.load_a(p, m0, wave, part, lane, aa);
+            __syncthreads();
+        }
+        const int rem = chunks - t;                                      // 0 .. 4 chunks left; one barrier per chunk, as the consumers
+        if (rem > 0) {
+            if (rem > 1) { sk2_store_w(w1, part, lane, wb); sk2_store_a(a1, wave, part, lane, ab); }
+            if (rem > 3) { cur.load_w(p, nb0, part, lane, wb); cur.load_a(p, m0, wave, part, lane, ab); }       // chunk t + 3
+            __syncthreads();
+        }
+        if (rem > 1) {
+            if (rem > 2) { sk2_store_w(w0, part, lane, wa); sk2_store_a(a0, wave, part, lane, aa); }
+            __syncthreads();
+        }
+        if (rem > 2) {
+            if (rem > 3) { sk2_store_w(w1, part, lane, wb); sk2_store_a(a1, wave, part, lane, ab); }
+            __syncthreads();
+        }
+        if (rem > 3) __syncthreads();
+        if constexpr (EPI == EPI_GATE) __syncthreads();                  // the consumers' exchange barrier
+        return;
+    }
+    f32x16 c;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) c[e] = 0.f;
+    __syncthreads();                                                     // chunk 0 is in its slots
+    // Software pipeline over the chunks: all four k-steps of chunk t are in registers when its MFMAs start, so the barrier that
+    // hands slot t back to the staging waves and publishes chunk t + 1 is taken FIRST, and chunk t + 1 is read under chunk t's
+    // 24 MFMAs (k-step by k-step: the wave is in-order).
+    Sk2Frag f[4], g[4];
+    if (chunks > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sk2_read(w0, a0, j, r, h, f[j]);
+    }
+    for (int t = 0; t < chunks; t += 2) {
+        __syncthreads();                                                 // chunk t + 1 written, chunk t read
+        if (t + 1 < chunks) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sk2_read(w1, a1, j, r, h, g[j]); sk2_mfma(f[j], c); }
+            __syncthreads();
+            if (t + 2 < chunks) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { sk2_read(w0, a0, j, r, h, f[j]); sk2_mfma(g[j], c); }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sk2_mfma(g[j], c);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sk2_mfma(f[j], c);
+        }
+    }
+    skinny_epilogue<EPI>(p, c, xch, m0, n0, nb0, r, h, lane, wave, m_ok);
+}
+
 constexpr long SKINNY_MAX_M = 256;     // above this the tiled kernels win (every 32-row block re-reads the weight panel from L2)
 
 template <int EPI>
@@ -989,7 +1226,20 @@ int launch_skinny(const GemmParams& p, hipStream_t stream) {
         // helpers only where most of the chip would idle AND the panel is worth it (>= 1 MB of planes)
         const bool big = 6.0 * p.N * ksum >= 1.0e6;
         const int helpers = (dvq_knobs().gemm_skinny_prefetch && big && n_work <= 64) ? 192 : 0;
-        DVQ_LAUNCH((gemm_bf16x3_skinny_kernel<EPI>), dim3((unsigned)(n_work + helpers)), dim3(128), 0, stream, p, n_col, n_work);
+        if (dvq_knobs().gemm_skinny == 2) {                               // the register-staged variant (A/B runs)
+            DVQ_LAUNCH((gemm_bf16x3_skinny_kernel<EPI>), dim3((unsigned)(n_work + helpers)), dim3(128), 0, stream, p, n_col, n_work);
+        } else {
+            static DvqOncePerDevice attr_once;
+            const hipError_t e = attr_once.run([] {
+                return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_skinny2_kernel<EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SK2_SMEM);
+            });
+            if (e != hipSuccess) {
+                dvq_set_error("gemm_bf16x3: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+                return DVQ_ELAUNCH;
+            }
+            DVQ_LAUNCH((gemm_bf16x3_skinny2_kernel<EPI>), dim3((unsigned)(n_work + helpers)), dim3(128 + 128 * SK2_NP), SK2_SMEM, stream, p, n_col, n_work);
+        }
     }
     DVQ_CHECK_LAUNCH("gemm_bf16x3_skinny");
     return DVQ_OK;

@@ -24,7 +24,7 @@ DvqKnobs* read_knobs() {
     auto num = [](const char* name) { const char* e = getenv(name); return e ? atol(e) : 0L; };
     k->gemm_wide = !is("DVQ_GEMM_WIDE", '0');
     k->gemm_dephase = !is("DVQ_GEMM_DEPHASE", '0');
-    k->gemm_skinny = !is("DVQ_GEMM_SKINNY", '0');
+    k->gemm_skinny = is("DVQ_GEMM_SKINNY", '0') ? 0 : (is("DVQ_GEMM_SKINNY", '2') ? 2 : 1);   // 2: the register-staged variant
     k->vq_kernel = (getenv("DVQ_VQ_KERNEL") && atoi(getenv("DVQ_VQ_KERNEL")) == 16) ? 16 : 8;
     k->gemm_skinny_prefetch = !is("DVQ_GEMM_SKINNY_PREFETCH", '0');
     k->pn_filter = is("DVQ_PN_FILTER", '0') ? 0 : (is("DVQ_PN_FILTER", '2') ? 2 : 1);

@@ -966,8 +966,10 @@ def test_skinny_gemm_equals_tiled_kernels_bitwise():
         return out
     a = run()
     b = _with_env("DVQ_GEMM_SKINNY", "0", run)
+    c = _with_env("DVQ_GEMM_SKINNY", "2", run)              # the register-staged variant of the skinny kernel
     for k in a:
         assert torch.equal(a[k], b[k]), f"{k}: skinny kernel != tiled kernel"
+        assert torch.equal(a[k], c[k]), f"{k}: LDS-staged skinny kernel != register-staged one"
     assert torch.equal(a["logits"][3:4], a["logits_row3"])
 
 

@@ -15,15 +15,15 @@ def timed(fn, n):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / n
 
-for M in (1, 8, 32, 100, 256):
+for M in (1, 8, 100, 256):
     for N, K in ((1024, 2048), (512, 512), (1024, 512)):
         x = torch.randn(M, K, device=dev); b = torch.randn(N, device=dev)
         ws = [torch.randn(N, K, device=dev) * 0.03 for _ in range(48)]
         pls = [packing.split_bf16x3(w) for w in ws]
         out = torch.empty(M, N, device=dev)
         res = {}
-        for mode in ("1", "0"):
+        for mode in ("1", "2", "0"):
             os.environ["DVQ_GEMM_SKINNY"] = mode; lib.dvq_reload_env()
             res[mode] = (timed(lambda i: ops.linear(x, ws[0], b, out=out, planes=pls[0]), 96),
                          timed(lambda i: ops.linear(x, ws[i % 48], b, out=out, planes=pls[i % 48]), 96))
-        print(f"M={M:4d} N={N} K={K}: skinny warm {res['1'][0]:6.1f} us, rotating {res['1'][1]:6.1f} us | tiled warm {res['0'][0]:6.1f} us, rotating {res['0'][1]:6.1f} us", flush=True)
+        print(f"M={M:4d} N={N} K={K}: skinny (LDS-staged) warm {res['1'][0]:6.1f} us, rotating {res['1'][1]:6.1f} us | register-staged warm {res['2'][0]:6.1f} us, rotating {res['2'][1]:6.1f} us | tiled warm {res['0'][0]:6.1f} us, rotating {res['0'][1]:6.1f} us", flush=True)
