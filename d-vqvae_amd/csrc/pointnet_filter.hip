@@ -433,6 +433,10 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         }
     };
     int stage = 0;
+    f32x16 accP;                                          // the chunk's last accumulator block, scored under the next chunk's first MFMAs
+    float pb1 = NEG_BIG, pb2 = NEG_BIG, pb3 = NEG_BIG;
+    bool pending = false;
+#pragma unroll 1
     for (int c = 0; c < ((abl & 2) ? 0 : 16); ++c) {
         __syncthreads();                                  // chunk c is in its stage; the other stage and tb parity are free
         if (c + 1 < 16 && !(abl & 1024)) wreg = w3_load(w3h, 64 * (c + 1), wave, lane);
@@ -447,23 +451,36 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         for (int s = 0; s < 8; ++s) wf0[s] = w3_frag(st, r, 2 * s + h);
 #pragma unroll
         for (int s = 0; s < 8; ++s) wf1[s] = w3_frag(st, 32 + r, 2 * s + h);
+        // Four MFMA blocks and four chain blocks per chunk, each chain under the MFMAs of the block that follows its own.  The last
+        // chain of a chunk (second point block x channels 32..63: accP) has no successor inside the chunk: it runs under the FIRST
+        // MFMA block of the next chunk (8 dependent MFMAs that had nothing to cover them), except before a publish (c = 7, 15).
         f32x16 accA, accB;
-        float a1 = NEG_BIG, a2 = NEG_BIG, a3m = NEG_BIG, b1m = NEG_BIG, b2m = NEG_BIG, b3m = NEG_BIG;
+        float a1 = NEG_BIG, a2 = NEG_BIG, a3m = NEG_BIG;
         F_MFMA_BLOCK(accA, 0, wf0);
+        if (pending) {
+            F_CHAIN_BLOCK(accP, 1, pb1, pb2, pb3);
+            F_INTERLEAVE();
+            if (!(abl & 512)) finish(c - 1, 1, pb1, pb2, pb3);
+            else if (pb1 + pb2 + pb3 == 12345.f) tb[lane] = pb1;
+        }
         F_MFMA_BLOCK(accB, 1, wf0);
         F_CHAIN_BLOCK(accA, 0, a1, a2, a3m);
         F_INTERLEAVE();
         F_MFMA_BLOCK(accA, 0, wf1);
         F_CHAIN_BLOCK(accB, 1, a1, a2, a3m);
         F_INTERLEAVE();
-        F_MFMA_BLOCK(accB, 1, wf1);
-        F_CHAIN_BLOCK(accA, 0, b1m, b2m, b3m);
+        pb1 = NEG_BIG; pb2 = NEG_BIG; pb3 = NEG_BIG;
+        F_MFMA_BLOCK(accP, 1, wf1);
+        F_CHAIN_BLOCK(accA, 0, pb1, pb2, pb3);
         F_INTERLEAVE();
-        F_CHAIN_BLOCK(accB, 1, b1m, b2m, b3m);
-        if (!(abl & 512)) {
-            finish(c, 0, a1, a2, a3m);
-            finish(c, 1, b1m, b2m, b3m);
-        } else if (a1 + b1m + a2 + b2m + a3m + b3m == 12345.f) tb[lane] = a1;
+        if (!(abl & 512)) finish(c, 0, a1, a2, a3m);
+        else if (a1 + a2 + a3m == 12345.f) tb[lane] = a1;
+        pending = (c & 7) != 7;
+        if (!pending) {
+            F_CHAIN_BLOCK(accP, 1, pb1, pb2, pb3);
+            if (!(abl & 512)) finish(c, 1, pb1, pb2, pb3);
+            else if (pb1 + pb2 + pb3 == 12345.f) tb[lane] = pb1;
+        }
         if (c + 1 < 16 && !(abl & 1024)) w3_store(fl + (stage ^ 1) * F_STAGE3, wave, lane, wreg);
         stage ^= 1;
     }
