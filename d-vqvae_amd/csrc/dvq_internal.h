@@ -170,7 +170,7 @@ int dvq_gemm_mode();
 struct DvqKnobs {
     int gemm_wide;        // 0: 128 x 128 kernels only
     int gemm_dephase;
-    int vq_kernel;        // 8 (default) or 16: which streaming VQ kernel (DVQ_VQ_KERNEL; both return the same indices)
+    int vq_kernel;        // 16 (default): vq_stream16.hip; 8: vq_stream.hip's eight-wave kernel; 32: vq_rows.hip (DVQ_VQ_KERNEL)
     int gemm_skinny_prefetch;   // 0: no helper workgroups (DVQ_GEMM_SKINNY_PREFETCH=0)
     int gemm_skinny;      // 0: tiled kernels also for M <= 256 (DVQ_GEMM_SKINNY=0; the two must agree bitwise)
     int pn_filter;        // 0 six-product trunk, 1 default, 2 filtered trunk whatever the tile fill
@@ -183,6 +183,8 @@ struct DvqKnobs {
 const DvqKnobs& dvq_knobs();
 int dvq_launch_vq_stream16(const float* z, const float* E, const void* packed, long M, int64_t* idx, unsigned long long* slow_rows,
                            unsigned long long* dbg, hipStream_t st);
+int dvq_launch_vq_rows(const float* z, const float* E, const void* packed, long M, int64_t* idx, unsigned long long* slow_rows,
+                       hipStream_t st);
 // simple helpers implemented in misc.hip
 int dvq_launch_gather_rows(const float* table, const int64_t* idx, long idx_stride, long M, int K, int D,
                            float* out, long ldo, int32_t* err_flag, hipStream_t stream);

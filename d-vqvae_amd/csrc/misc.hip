@@ -25,7 +25,10 @@ DvqKnobs* read_knobs() {
     k->gemm_wide = !is("DVQ_GEMM_WIDE", '0');
     k->gemm_dephase = !is("DVQ_GEMM_DEPHASE", '0');
     k->gemm_skinny = is("DVQ_GEMM_SKINNY", '0') ? 0 : (is("DVQ_GEMM_SKINNY", '2') ? 2 : 1);   // 2: the register-staged variant
-    k->vq_kernel = (getenv("DVQ_VQ_KERNEL") && atoi(getenv("DVQ_VQ_KERNEL")) == 16) ? 16 : 8;
+    {
+        const int v = getenv("DVQ_VQ_KERNEL") ? atoi(getenv("DVQ_VQ_KERNEL")) : 0;
+        k->vq_kernel = v == 8 ? 8 : (v == 32 ? 32 : 16);       // default: the sixteen-wave kernel; 8: eight waves (generated tile body); 32: rows resident, codebook streamed
+    }
     k->gemm_skinny_prefetch = !is("DVQ_GEMM_SKINNY_PREFETCH", '0');
     k->pn_filter = is("DVQ_PN_FILTER", '0') ? 0 : (is("DVQ_PN_FILTER", '2') ? 2 : 1);
     k->pn_exhaustive = is("DVQ_PN_EXHAUSTIVE", '1');

@@ -914,8 +914,9 @@ extern "C" int dvq_vq_argmin_fast(const float* z, const float* E, const void* pa
         }
     }
     const char* pk = (const char*)packed;
-    // default: this file's eight-wave kernel; DVQ_VQ_KERNEL=16: the sixteen-wave kernel (vq_stream16.hip: four waves per SIMD, 32
-    // entries each, plain code).  Same indices, same speed within the run-to-run spread (tools/vq_kernel_ab.py: 36.4 us both).
+    // default (round 3, after the library lost its compiler-formed packed-fp32 instructions): the sixteen-wave kernel of
+    // vq_stream16.hip (34.1-35.0 us against 35.6-35.9 us for this file's eight-wave kernel, DVQ_VQ_KERNEL=8, in bench.py's
+    // microbenchmark; 36.4 us both before); DVQ_VQ_KERNEL=32: vq_rows.hip (rows resident, codebook streamed: 42 us).  Same indices.
     int which = dvq_knobs().vq_kernel;
     unsigned long long* dbg16 = nullptr;
 #ifdef DVQ_DIAG
@@ -926,6 +927,10 @@ extern "C" int dvq_vq_argmin_fast(const float* z, const float* E, const void* pa
     if (which == 16) {
         DVQ_PROF("vq_argmin_fast", 2.0 * M * K * D, (double)M * D * 4 + (double)K * D * 4 + (double)M * 8, st);
         return dvq_launch_vq_stream16(z, E, packed, (long)M, idx, slow_rows, dbg16, st);
+    }
+    if (which == 32) {
+        DVQ_PROF("vq_argmin_fast", 2.0 * M * K * D, (double)M * D * 4 + (double)K * D * 4 + (double)M * 8, st);
+        return dvq_launch_vq_rows(z, E, packed, (long)M, idx, slow_rows, st);
     }
     const int cus = device_cus();
     const long tiles = (M + TILE - 1) / TILE;

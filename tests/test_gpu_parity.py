@@ -989,7 +989,8 @@ def test_vq_kernel_variants_agree():
     def run():
         return [ops.vq_argmin(c_, E, packed=pk, fast=True) for c_ in cases] + [ops.vq_argmin(cases[3], Et, packed=pkt, fast=True)]
     a = run()
-    b = _with_env("DVQ_VQ_KERNEL", "16", run)
-    for x, y in zip(a, b):
-        assert torch.equal(x, y)
+    for kern in ("16", "32", "8"):                                    # 32: rows resident, codebook streamed (vq_rows.hip)
+        b = _with_env("DVQ_VQ_KERNEL", kern, run)
+        for i, (x, y) in enumerate(zip(a, b)):
+            assert torch.equal(x, y), f"DVQ_VQ_KERNEL={kern}, case {i}: {int((x != y).sum())} rows differ"
     assert torch.equal(a[3], ops.vq_argmin(cases[3], E, fast=False))
