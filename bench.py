@@ -99,7 +99,8 @@ def pmc_traffic(kind, batch):
     (None, None) if there is none.  Not measured in this run: PMC collection needs rocprofv3 around the process."""
     if batch != 65536:
         return None, None
-    names = {"vq_fast": "vq_stream_kernel", "pn_trunk": "pn_trunk_filter_kernel<4>", "pn_exact": "pn_exact_kernel",
+    names = {"vq_fast": "::vq_stream",         # vq_stream16_kernel (default) / vq_stream_kernel (DVQ_VQ_KERNEL=8)
+             "pn_trunk": "pn_trunk_filter_kernel<4>", "pn_exact": "pn_exact_kernel",
              # template-argument lists print as "<2, true>": match up to the first argument
              "gemm_gate": "gemm_bf16x3_wide_kernel<2,", "gemm_bias": "gemm_bf16x3_wide_kernel<0,", "gemm_resid": "gemm_bf16x3_wide_kernel<1,"}
     try:
