@@ -498,6 +498,48 @@ def test_dvqvae_eval_golden(golden):
         net(gpu(obj), gpu(hand))
 
 
+def test_dvqvae_eval_full_size_properties(golden):
+    """BASELINE config 2 (PointNet -> VQ -> embedding forward, N = 1024, batch 16 384) through size-independent properties: the batch
+    is a 1 024-sample block tiled 16 times, so every tile must give the block's codes and embeddings bit for bit, the block computed
+    alone the same, and single samples too."""
+    from dvqvae_amd.network.DVQVAE import DVQVAE
+    from conftest import dvqvae_state_dict
+    g = golden("g8_dvqvae")
+    net = DVQVAE(obj_inchannel=4)
+    net.load_state_dict(dvqvae_state_dict(net.state_dict(), g), strict=True)
+    net.eval().to(DEV)
+    blk, reps, N = 1024, 16, 1024
+    obj = gpu(synth.synthetic_clouds(blk, N, seed=81))
+    hand = gpu(synth.synthetic_normal((blk, 3, 778), SEED, "dvq/hand/full", 0.05))
+    idx_b, emb_b = net(obj, hand)
+    idx, emb = net(obj.repeat(reps, 1, 1), hand.repeat(reps, 1, 1))
+    B = blk * reps
+    assert tuple(idx.shape) == (7 * B, 1) and tuple(emb.shape)[0] == B
+    assert torch.equal(idx.view(7, reps, blk), idx_b.view(7, 1, blk).expand(7, reps, blk))
+    assert torch.equal(emb.view(reps, blk, -1), emb_b.view(1, blk, -1).expand(reps, blk, -1))
+    for b in (0, 513, 1023):
+        i1, e1 = net(obj[b:b + 1], hand[b:b + 1])
+        assert torch.equal(i1.view(7), idx_b.view(7, blk)[:, b]) and torch.equal(e1, emb_b[b:b + 1])
+    assert int(idx.min()) >= 0 and int(idx.max()) < 128 and len(torch.unique(idx_b.view(7, blk)[6])) > 8
+
+
+def test_gen_ho3d_size_properties():
+    """BASELINE config 3 (prior sampling + decode at batch 8 192 on HO3D-sized clouds, N = 3000: twelve 256-point tiles per cloud, the
+    filtered trunk): a 512-grasp block tiled 16 times reproduces the block, the block alone and single grasps, bit for bit."""
+    net, _ = _gennet()
+    blk, reps, N = 512, 16, 3000
+    obj = gpu(synth.synthetic_clouds(blk, N, seed=93))
+    q = gpu(synth.exp1_noise(blk, 9, 512, seed=94))
+    r0, p0, aux0 = net.gen(obj, noise=q, return_aux=True)
+    r, p, aux = net.gen(obj.repeat(reps, 1, 1), noise=q.repeat(reps, 1, 1), return_aux=True)
+    assert bool(torch.isfinite(r).all()) and bool(torch.isfinite(p).all())
+    assert torch.equal(r.view(reps, blk, 55), r0.expand(reps, blk, 55)) and torch.equal(p.view(reps, blk, 6), p0.expand(reps, blk, 6))
+    assert torch.equal(aux["codes"].view(reps, blk, -1), aux0["codes"].view(1, blk, -1).expand(reps, blk, -1))
+    for b in (0, 255, 511):
+        rb, pb = net.gen(obj[b:b + 1], noise=q[b:b + 1])
+        assert torch.equal(rb, r0[b:b + 1]) and torch.equal(pb, p0[b:b + 1])
+
+
 # ------------------------------------------------------------------------------------------ pre/post steps
 def test_transform_cloud_matches_numpy():
     pc = synth.synthetic_clouds(1, 300, seed=3)[0]
