@@ -499,7 +499,7 @@ def test_dvqvae_eval_golden(golden):
 
 
 def test_dvqvae_eval_full_size_properties(golden):
-    """BASELINE config 2 (PointNet -> VQ -> embedding forward, N = 1024, batch 16 384) through size-independent properties: the batch
+    """BASELINE config 3 (PointNet -> VQ -> embedding forward, N = 1024, batch 16 384) through size-independent properties: the batch
     is a 1 024-sample block tiled 16 times, so every tile must give the block's codes and embeddings bit for bit, the block computed
     alone the same, and single samples too."""
     from dvqvae_amd.network.DVQVAE import DVQVAE
@@ -524,7 +524,7 @@ def test_dvqvae_eval_full_size_properties(golden):
 
 
 def test_gen_ho3d_size_properties():
-    """BASELINE config 3 (prior sampling + decode at batch 8 192 on HO3D-sized clouds, N = 3000: twelve 256-point tiles per cloud, the
+    """BASELINE config 4 (prior sampling + decode at batch 8 192 on HO3D-sized clouds, N = 3000: twelve 256-point tiles per cloud, the
     filtered trunk): a 512-grasp block tiled 16 times reproduces the block, the block alone and single grasps, bit for bit."""
     net, _ = _gennet()
     blk, reps, N = 512, 16, 3000
