@@ -34,10 +34,30 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = fp32 vector peak
 BF16_MFMA_PEAK_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA
-# The GEMMs run "bf16x3": every fp32 product costs six bf16 MFMA products (exact 3-way operand split), so the roof of
-# ALGORITHMIC fp32 FLOP/s is the dense bf16 peak / 6.  With DVQ_GEMM=fp32 they run on v_mfma_f32_32x32x2_f32 instead.
-GEMM_MODE = "fp32" if os.environ.get("DVQ_GEMM", "").lower().startswith("f") else "bf16x3"
-GEMM_PEAK_TF = FP32_MFMA_PEAK_TF if GEMM_MODE == "fp32" else BF16_MFMA_PEAK_TF / 6.0
+# The GEMMs run "f16x2" (default): every fp32 product costs THREE fp16 MFMA products (two fp16 pieces per operand, the second
+# scaled by 2^11; two accumulators), so the roof of ALGORITHMIC fp32 FLOP/s is the dense fp16 peak / 3.  DVQ_GEMM=bf16x3: the
+# exact three-piece bf16 split, six products (peak / 6).  DVQ_GEMM=fp32: v_mfma_f32_32x32x2_f32.
+_gm = os.environ.get("DVQ_GEMM", "").strip().lower()
+GEMM_MODE = "fp32" if _gm == "fp32" else ("bf16x3" if _gm == "bf16x3" else "f16x2")
+GEMM_PEAK_TF = {"fp32": FP32_MFMA_PEAK_TF, "bf16x3": BF16_MFMA_PEAK_TF / 6.0, "f16x2": BF16_MFMA_PEAK_TF / 3.0}[GEMM_MODE]
+GEMM_PEAK_NOTE = {"fp32": "fp32 MFMA (= fp32 vector) peak",
+                  "bf16x3": "dense bf16 MFMA 2500 TF / 6 partial products per fp32 product",
+                  "f16x2": "dense fp16 MFMA 2500 TF / 3 partial products per fp32 product"}[GEMM_MODE]
+DTYPE_NOTE = {
+    "fp32": "f32",
+    "bf16x3": "f32 (every fp32 operand split exactly into 3 bf16 pieces on the bf16 matrix cores, fp32 accumulate; the 6 "
+              "partial products of weight >= 2^-24 are kept, the 3 dropped ones are <= 3*2^-24 |a||b| per product: "
+              "fp32-GEMM-class accuracy, <= 4e-6*scale against fp64 in tests/test_gpu_parity.py::test_linear_fuzz..., "
+              "not IEEE-fp32 bitwise; PointNet conv3 + max over the points: fp16 matrix-core filter that only SELECTS "
+              "candidate points, every emitted value is a plain fp32 FMA dot product)",
+    "f16x2": "f32 (GEMMs: every fp32 operand as two fp16 pieces, a1 = fp16(a), a2 = fp16((a - a1) * 2^11), weights pre-scaled by "
+             "one power of two per output row; the 3 partial products a1 b1, a1 b2, a2 b1 are exact in fp32 and accumulate in "
+             "TWO fp32 accumulators (large / cross terms) on v_mfma_f32_16x16x32_f16; dropped: a2 b2 and the two residuals, "
+             "<= 3*2^-22 |a||b| per product: fp32-GEMM-class accuracy, <= 4e-6*scale against fp64 in "
+             "tests/test_gpu_parity.py::test_linear_fuzz... (measured ~1e-7*scale, a third of the six-product bf16 split kept "
+             "behind DVQ_GEMM=bf16x3), not IEEE-fp32 bitwise; PointNet conv1/conv2: six-product bf16 split; conv3 + max over "
+             "the points: fp16 matrix-core filter that only SELECTS candidate points, every emitted value is a plain fp32 FMA "
+             "dot product)"}[GEMM_MODE]
 
 
 def parse():
@@ -102,7 +122,9 @@ def pmc_traffic(kind, batch):
     names = {"vq_fast": "::vq_stream",         # vq_stream16_kernel (default) / vq_stream_kernel (DVQ_VQ_KERNEL=8)
              "pn_trunk": "pn_trunk_filter_kernel<4>", "pn_exact": "pn_exact_kernel",
              # template-argument lists print as "<2, true>": match up to the first argument
-             "gemm_gate": "gemm_bf16x3_wide_kernel<2,", "gemm_bias": "gemm_bf16x3_wide_kernel<0,", "gemm_resid": "gemm_bf16x3_wide_kernel<1,"}
+             "gemm_gate": "gemm_f16x2_kernel<2,", "gemm_bias": "gemm_f16x2_kernel<0,", "gemm_resid": "gemm_f16x2_kernel<1,"}
+    if GEMM_MODE == "bf16x3":
+        names.update({"gemm_gate": "gemm_bf16x3_wide_kernel<2,", "gemm_bias": "gemm_bf16x3_wide_kernel<0,", "gemm_resid": "gemm_bf16x3_wide_kernel<1,"})
     try:
         import glob
         path = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))[-1]
@@ -413,12 +435,7 @@ def main():
         out = {"metric": f"grasps/sec at batch={B_global}, N={N} pts, K={K}", "value": value, "unit": "grasps/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-               "dtype": "f32" if GEMM_MODE == "fp32" else
-                        "f32 (every fp32 operand split exactly into 3 bf16 pieces on the bf16 matrix cores, fp32 accumulate; the 6 "
-                        "partial products of weight >= 2^-24 are kept, the 3 dropped ones are <= 3*2^-24 |a||b| per product: "
-                        "fp32-GEMM-class accuracy, <= 4e-6*scale against fp64 in tests/test_gpu_parity.py::test_linear_fuzz..., "
-                        "not IEEE-fp32 bitwise; PointNet conv3 + max over the points: fp16 matrix-core filter that only SELECTS "
-                        "candidate points, every emitted value is a plain fp32 FMA dot product)",
+               "dtype": DTYPE_NOTE,
                "data": "synthetic", "gathered_sha256": gathered_sha,
                "config": {"workload": f"GenNet.gen full path, global batch {B_global} ({B} grasps on rank 0), N={N} pts, K={K} "
                                       f"codebooks, 15-layer gated PixelCNN prior (cached sampler), device Philox noise inside "
@@ -443,8 +460,7 @@ def main():
             tr, tr_src = pmc_traffic(dom, B)
             out["roofline"] = {"bound": "mfma", "kernel": {"pn_trunk": "pn_trunk_kernel (fused PointNet trunk)"}.get(dom, f"gemm_{GEMM_MODE} {dom}"),
                                "achieved": achieved, "peak": GEMM_PEAK_TF, "unit": "TFLOP/s", "frac": achieved / GEMM_PEAK_TF,
-                               "peak_note": ("dense bf16 MFMA 2500 TF / 6 partial products per fp32 product"
-                                             if GEMM_MODE == "bf16x3" else "fp32 MFMA (= fp32 vector) peak"),
+                               "peak_note": GEMM_PEAK_NOTE,
                                "traffic": tr, "traffic_source": tr_src, "launches": d["count"], "avg_launch_ms": d["ms"] / d["count"],
                                "flops_per_launch": d["flops"] / d["count"], "share_of_step": d["ms"] / pe_ms,
                                "measured_in": f"second pass of {args.prof_steps} step(s) with per-launch HIP events "

@@ -22,6 +22,7 @@ _lock = threading.Lock()
 _lib = None
 
 DVQ_MAX_SRC = 8
+PLANES_BF16X3, PLANES_F16X2 = 0, 1
 
 c_f32p = C.c_void_p      # device pointers travel as integers
 c_i64p = C.c_void_p
@@ -31,11 +32,12 @@ c_stream = C.c_void_p
 
 class GemmSrc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("ldx", C.c_int64), ("ldw", C.c_int64),
-                ("K", C.c_int32), ("_pad", C.c_int32), ("wp", C.c_void_p), ("wp_plane", C.c_int64)]
+                ("K", C.c_int32), ("wp_kind", C.c_int32), ("wp", C.c_void_p), ("wp_plane", C.c_int64), ("w_scale", C.c_void_p)]
 
 
 class MlpLayer(C.Structure):
-    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("wp", C.c_void_p), ("n_out", C.c_int32), ("k_in", C.c_int32)]
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("wp", C.c_void_p), ("n_out", C.c_int32), ("k_in", C.c_int32),
+                ("w_scale", C.c_void_p), ("wp_kind", C.c_int32), ("_pad", C.c_int32)]
 
 
 class PointnetWeights(C.Structure):
@@ -47,19 +49,22 @@ class PointnetWeights(C.Structure):
 
 
 class PixelcnnLayer(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("wv", "bv", "wh", "wv2h", "bh", "cls", "wr", "br", "wv_p", "wh_p", "wv2h_p", "wr_p")]
+    _fields_ = [(n, C.c_void_p) for n in ("wv", "bv", "wh", "wv2h", "bh", "cls", "wr", "br", "wv_p", "wh_p", "wv2h_p", "wr_p",
+                                          "sv", "sh", "sr")]
 
 
 class PixelcnnWeights(C.Structure):
     _fields_ = [("n_layers", C.c_int32), ("dim", C.c_int32), ("n_in", C.c_int32), ("n_classes", C.c_int32),
-                ("n_hidden", C.c_int32), ("_pad", C.c_int32), ("tok_emb", C.c_void_p),
+                ("n_hidden", C.c_int32), ("planes_kind", C.c_int32), ("tok_emb", C.c_void_p),
                 ("layers_host", C.POINTER(PixelcnnLayer)), ("w0", C.c_void_p), ("b0", C.c_void_p),
-                ("w2", C.c_void_p), ("b2", C.c_void_p), ("w0_p", C.c_void_p), ("w2_p", C.c_void_p)]
+                ("w2", C.c_void_p), ("b2", C.c_void_p), ("w0_p", C.c_void_p), ("w2_p", C.c_void_p),
+                ("s0", C.c_void_p), ("s2", C.c_void_p)]
 
 
 class ManoModel(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("v_template", "blend_w", "blend_w_planes", "j_template", "j_shapedirs",
-                                          "weights", "comps", "pose_mean")] + [("parents", C.c_int32 * 16)]
+                                          "weights", "comps", "pose_mean")] + [
+        ("parents", C.c_int32 * 16), ("blend_w_scale", C.c_void_p), ("planes_kind", C.c_int32), ("_pad", C.c_int32)]
 
 
 class ProfEntry(C.Structure):
@@ -77,6 +82,8 @@ SIGNATURES = {
     "dvq_mlp3_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "dvq_mlp3": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.POINTER(MlpLayer), c_f32p, C.c_int64, C.c_void_p, C.c_size_t, c_stream]),
     "dvq_split_bf16x3": (C.c_int, [c_f32p, C.c_int64, C.c_void_p, c_stream]),
+    "dvq_f16x2_row_absmax": (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, c_f32p, c_stream]),
+    "dvq_split_f16x2": (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, c_f32p, C.c_void_p, c_f32p, c_stream]),
     "dvq_vq_argmin_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "dvq_vq_argmin": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int, C.c_int, c_i64p, c_f32p, C.c_void_p,
                                 C.c_size_t, c_stream]),

@@ -117,8 +117,8 @@ struct GemmSrc {
     const float* W;
     long lda, ldw;
     int K;
-    int pad_;
-    const uint16_t* Wp;   // optional: W pre-split into three bf16 planes [3][N][ldw] (plane stride wp_plane elements)
+    int wp_kind;          // DVQ_PLANES_BF16X3: Wp = three bf16 planes; DVQ_PLANES_F16X2: two fp16 planes of w * 2^t[row] (+ GemmParams::wscale)
+    const uint16_t* Wp;   // optional: W pre-split into planes [planes][N][ldw] (plane stride wp_plane elements)
     long wp_plane;
 };
 
@@ -128,6 +128,7 @@ struct GemmParams {
     int N;
     long M;
     const float* bias;   // [N] or null
+    const float* wscale; // f16x2 planes: [N] row scales 2^-t[n] (one array for all sources of the launch)
     float* out;          // EPI_BIAS/RESID: [M,N]; EPI_GATE: [M,N/2]
     long ldo;
     int relu;
@@ -161,6 +162,7 @@ __device__ __forceinline__ bool dvq_argmin_better(float v, int i, float bv, int 
 
 int dvq_launch_gemm(const GemmParams& p, GemmEpilogue epi, hipStream_t stream);
 int dvq_launch_gemm_bf16x3(const GemmParams& p, GemmEpilogue epi, hipStream_t stream);
+int dvq_launch_gemm_f16x2(const GemmParams& p, GemmEpilogue epi, hipStream_t stream);
 // 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split-bf16 (default); env DVQ_GEMM=fp32|bf16x3
 int dvq_gemm_mode();
 

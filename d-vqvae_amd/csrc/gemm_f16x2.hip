@@ -1,0 +1,384 @@
+// fp32-class GEMM on the fp16 matrix cores with THREE products per fp32 product ("f16x2", the default of the path's GEMMs).
+//
+//   weights (packer, once):  w~ = w * 2^t_n (one power of two per output row n: max_k |w~| in [2^14, 2^15)),
+//                            w1 = fp16(w~), w2 = fp16((w~ - w1) * 2^11)                      (w~ - w1 is exact in fp32)
+//   activations (staging):   a1 = fp16(a),  a2 = fp16((a - a1) * 2^11)
+//   two fp32 accumulators:   hi += a1 w1 ;  lo += a1 w2 ; lo += a2 w1        (v_mfma_f32_16x16x32_f16: products exact in fp32)
+//   epilogue:                out = (hi + lo * 2^-11) * 2^-t_n (+ bias, ...)
+//
+// fp16 carries 11 significant bits and the second piece is stored scaled by 2^11, so it stays a NORMAL fp16 number wherever
+// the first piece is one: 22 bits of every operand down to |a| = 2^-14; below that the absolute error is <= 2^-36.  Dropped:
+// a2 w2 and the two representation residuals, together <= 3 * 2^-22 |a w| per product; the cross terms are summed apart from
+// the large ones.  Measured against fp64 (tools/microbench/gemm_f16x2_wide.hip): 0.6-0.9e-7 * sum|a w|, a third of the
+// six-product split-bf16 kernels' (gemm_bf16x3.hip, kept behind DVQ_GEMM=bf16x3), at half their matrix work.
+// Range: |a| must stay below 65 520 (fp16); beyond it the row's outputs are NaN, never a silently wrong number
+// (GenNet.gen re-runs such a batch on the split-bf16 kernels, which have fp32's range).
+//
+// Shape: the 16x16x32 instruction holds a higher clock than 32x32x16 at equal cycles per FLOP (MI355X_MICROARCH.md, DVFS
+// give-back item 7): measured here 288 against 262 TFLOP/s on the gated PixelCNN shape (M = 16 384, N = 1024, K = 1536).
+//
+// Tiled kernel: 128 x 256 output tile, eight waves as 2 (M) x 4 (N) of 64 x 64, one workgroup per CU, K-tiles of 32, two LDS
+// stages of 48 KiB: both operands as fp16 planes with 64-byte rows, the 16-byte chunk c of row r stored at c ^ ((4 - (r >> 2)) & 3)
+// (conflict-free ds_read_b128 in the 16-row fragment shape: the four lane groups of a read hit sixteen different 16-byte bank
+// groups).  Activations go global -> registers -> split -> LDS (once per element), weight planes by LDS-DMA with the swizzle on
+// the source address.  Weights are MFMA operand A: a lane owns ONE output row m and four consecutive columns per block, so
+// every store is 16 bytes and a wave-instruction covers 64-byte row segments.
+// The accumulation order of an output element -- k-tiles of 32 in source order; per tile hi: (a1 w1), lo: (a1 w2) then
+// (a2 w1) -- is the same in the skinny kernel below: results do not depend on the batch tiling (batched == loop, bitwise).
+#include "dvq_internal.h"
+#include "gemm_common.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int TM = 128, TN = 256, BK = 32;
+constexpr int A_PL = TM * 64;                               // one activation plane [128][32] fp16
+constexpr int W_PL = TN * 64;                               // one weight plane [256][32] fp16
+constexpr int STAGE = 2 * A_PL + 2 * W_PL;                  // 49 152 B
+constexpr size_t SMEM = 2 * STAGE;                          // 98 304 B: one workgroup per CU (eight waves, <= 256 registers)
+constexpr float LO_SCALE = 1.0f / 2048.0f;
+
+__device__ __forceinline__ int swz16(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+
+// a -> (fp16(a), fp16((a - fp16(a)) * 2^11)) for eight values; the subtraction is exact
+__device__ __forceinline__ void split2(const f32x4& lo, const f32x4& hi, h8& p1, h8& p2) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const float a0 = j < 4 ? lo[j] : hi[j - 4], a1 = j < 4 ? lo[j + 1] : hi[j - 3];
+        const h2 h = __builtin_convertvector(f32x2{a0, a1}, h2);                       // v_cvt_pk_f16_f32, round to nearest even
+        const float r0 = a0 - (float)h[0], r1 = a1 - (float)h[1];
+        const h2 l = __builtin_convertvector(f32x2{r0 * 2048.0f, r1 * 2048.0f}, h2);
+        p1[j] = h[0]; p1[j + 1] = h[1];
+        p2[j] = l[0]; p2[j + 1] = l[1];
+    }
+}
+
+struct TileCursor {
+    int s, k_left;
+    const float* a_ptr;
+    const uint16_t* w_ptr[4];
+
+    __device__ __forceinline__ void open(const GemmParams& p, int src_i, long m0, int n0, int tid, int wave, int lane) {
+        s = src_i;
+        if (s >= p.nsrc) { k_left = 0; return; }
+        const GemmSrc& src = p.src[s];
+        k_left = src.K;
+        {
+            long m = m0 + (tid >> 2);
+            if (m >= p.M) m = p.M - 1;                     // clamped rows / columns only feed outputs the epilogue masks
+            a_ptr = src.A + m * src.lda + 8 * (tid & 3);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                      // 32 pieces of 16 rows x 64 B (two planes x 256 rows), four per wave
+            const int id = wave * 4 + i;
+            const int pl = id >> 4, rb = id & 15;
+            const int row = rb * 16 + (lane >> 2);
+            int n = n0 + row;
+            if (n >= p.N) n = p.N - 1;
+            w_ptr[i] = src.Wp + pl * src.wp_plane + (long)n * src.ldw + 8 * ((lane & 3) ^ swz16(row));
+        }
+    }
+    __device__ __forceinline__ bool valid() const { return k_left > 0; }
+    __device__ __forceinline__ void issue_w(char* stage, int wave) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = wave * 4 + i;
+            const int pl = id >> 4, rb = id & 15;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[i],
+                                             (__attribute__((address_space(3))) void*)(stage + 2 * A_PL + pl * W_PL + rb * 1024), 16, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void advance(const GemmParams& p, long m0, int n0, int tid, int wave, int lane) {
+        a_ptr += BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w_ptr[i] += BK;
+        k_left -= BK;
+        if (k_left <= 0) open(p, s + 1, m0, n0, tid, wave, lane);
+    }
+};
+
+// Epilogue of a wave's 64 x 64 block held as 4 x 4 blocks of 16 x 16: hi / lo [jn][i][e] = column n0w + 16 jn + 4 (lane >> 4) + e of
+// row m0w + 16 i + (lane & 15).  The arithmetic per element -- (hi + lo * 2^-11) * scale, + bias, ... in this order -- is shared
+// with the skinny kernel.
+__device__ __forceinline__ f32x4 f16x2_combine(const f32x4& hi, const f32x4& lo, const float* ws, int n, bool vec) {
+    f32x4 v = hi + lo * LO_SCALE;
+    if (vec) v *= *reinterpret_cast<const f32x4*>(ws + n);
+    return v;
+}
+
+template <int EPI>
+__device__ __forceinline__ void f16x2_store_block(const GemmParams& p, long m, int n, f32x4 v, bool full) {
+    if (full) {
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+        if constexpr (EPI == EPI_RESID) v += *reinterpret_cast<const f32x4*>(p.resid + m * p.ldr + n);
+        if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        *reinterpret_cast<f32x4*>(p.out + m * p.ldo + n) = v;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (n + c >= p.N) continue;
+            float x = v[c] * p.wscale[n + c] + (p.bias ? p.bias[n + c] : 0.f);
+            if constexpr (EPI == EPI_RESID) x += p.resid[m * p.ldr + n + c];
+            if (p.relu) x = fmaxf(x, 0.f);
+            p.out[m * p.ldo + n + c] = x;
+        }
+    }
+}
+
+// gate: `a` = the four tanh channels at gate-packed index na, `g` = their sigmoid partners at na + 32; natural channel c
+__device__ __forceinline__ void f16x2_store_gate(const GemmParams& p, long m, int na, int c, f32x4 a, f32x4 g, const float* crow) {
+    const int nb = na + 32;
+    if (p.bias) {
+        a += *reinterpret_cast<const f32x4*>(p.bias + na);
+        g += *reinterpret_cast<const f32x4*>(p.bias + nb);
+    }
+    if (p.pre) {
+        *reinterpret_cast<f32x4*>(p.pre + m * p.ldpre + na) = a;
+        *reinterpret_cast<f32x4*>(p.pre + m * p.ldpre + nb) = g;
+    }
+    if (crow) {
+        a += *reinterpret_cast<const f32x4*>(crow + na);
+        g += *reinterpret_cast<const f32x4*>(crow + nb);
+    }
+    f32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = tanhf(a[q]) * sigmoidf_(g[q]);
+    *reinterpret_cast<f32x4*>(p.out + m * p.ldo + c) = o;
+}
+
+template <int EPI>
+__device__ __forceinline__ void f16x2_epilogue(const GemmParams& p, f32x4 (&hi)[4][4], f32x4 (&lo)[4][4], long m0w, int n0w, int c0w,
+                                               int lane) {
+    const int lr = lane & 15, lc = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long m = m0w + i * 16 + lr;
+        if (m >= p.M) continue;
+        if constexpr (EPI == EPI_BIAS || EPI == EPI_RESID) {
+            const bool vec_ok = (p.N % 4 == 0) && (p.ldo % 4 == 0) && (EPI != EPI_RESID || p.ldr % 4 == 0);
+#pragma unroll
+            for (int jn = 0; jn < 4; ++jn) {
+                const int n = n0w + jn * 16 + 4 * lc;
+                if (n >= p.N) continue;
+                const bool full = vec_ok && n + 3 < p.N;
+                f16x2_store_block<EPI>(p, m, n, f16x2_combine(hi[jn][i], lo[jn][i], p.wscale, n, full), full);
+            }
+        } else if constexpr (EPI == EPI_GATE) {
+            if (n0w >= p.N) continue;                      // N % 128 == 0: a wave's 64 columns are all inside or all outside
+            const float* crow = p.cls ? p.cls + (long)p.label[m] * p.N : nullptr;
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                const int nl = jn * 16 + 4 * lc;
+                const int na = n0w + nl;
+                f16x2_store_gate(p, m, na, c0w + nl, f16x2_combine(hi[jn][i], lo[jn][i], p.wscale, na, true),
+                                 f16x2_combine(hi[jn + 2][i], lo[jn + 2][i], p.wscale, na + 32, true), crow);
+            }
+        }
+    }
+}
+
+template <int EPI, bool DEPHASE>
+__global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    const int tid = threadIdx.x;
+    const int tiles_n = (p.N + TN - 1) / TN;
+    const long tiles_m = (p.M + TM - 1) / TM;
+    const long b = blockIdx.x;
+    const long j = b >> 3;                                  // XCD-aware map: the column tiles of a 128-row panel run on one XCD
+    const long mt = (j / tiles_n) * 8 + (b & 7);
+    const int nt = (int)(j % tiles_n);
+    if (mt >= tiles_m) return;
+    const long m0 = mt * TM;
+    const int n0 = nt * TN;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    f32x4 hi[4][4], lo[4][4];                               // [jn][i]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { hi[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    TileCursor cur;
+    cur.open(p, 0, m0, n0, tid, wave, lane);
+    const int a_dst = (tid >> 2) * 64 + 16 * ((tid & 3) ^ swz16(tid >> 2));
+    f32x4 alo, ahi;
+    auto load_a = [&]() {
+        alo = *reinterpret_cast<const f32x4*>(cur.a_ptr);
+        ahi = *reinterpret_cast<const f32x4*>(cur.a_ptr + 4);
+    };
+    auto store_a = [&](char* stage) {
+        h8 p1, p2;
+        split2(alo, ahi, p1, p2);
+        *reinterpret_cast<h8*>(stage + a_dst) = p1;
+        *reinterpret_cast<h8*>(stage + A_PL + a_dst) = p2;
+    };
+    load_a();
+    cur.issue_w(smem_c, wave);
+    cur.advance(p, m0, n0, tid, wave, lane);
+    store_a(smem_c);
+    bool more = cur.valid();
+    if (more) load_a();                                     // tile 1's activations: written into the other stage during tile 0
+
+    const int rd = (lane & 15) * 64 + 16 * ((lane >> 4) ^ swz16(lane & 15));       // fragment read: row lane & 15, chunk lane >> 4
+    int stage = 0;
+    while (true) {
+        dvq_dma_barrier();                                  // this stage is complete (weight DMA landed, activation planes written);
+                                                            // everybody is done reading the other stage
+        const char* st = smem_c + stage * STAGE;
+        char* nx = smem_c + (stage ^ 1) * STAGE;
+        // The two waves of a SIMD (w and w + 4) move in lock step: waves 0..3 feed the next stage at the top of the tile, waves 4..7
+        // half way, so that one of the pair runs MFMAs while the other sits in the DMA issue.
+        auto feed = [&]() {
+            store_a(nx);                                    // loaded a K-tile ago; before the DMA issue (vmcnt counts in order)
+            cur.issue_w(nx, wave);
+            cur.advance(p, m0, n0, tid, wave, lane);
+            if (cur.valid()) load_a();
+        };
+        if (more && (wave < 4 || !DEPHASE)) feed();
+        h8 af[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) af[i][pl] = *reinterpret_cast<const h8*>(st + pl * A_PL + (wm * 64 + i * 16) * 64 + rd);
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) {
+            if (DEPHASE && jn == 2 && more && wave >= 4) feed();
+            const h8 w1 = *reinterpret_cast<const h8*>(st + 2 * A_PL + (wn * 64 + jn * 16) * 64 + rd);
+            const h8 w2 = *reinterpret_cast<const h8*>(st + 2 * A_PL + W_PL + (wn * 64 + jn * 16) * 64 + rd);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                hi[jn][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, af[i][0], hi[jn][i], 0, 0, 0);
+                lo[jn][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2, af[i][0], lo[jn][i], 0, 0, 0);
+                lo[jn][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, af[i][1], lo[jn][i], 0, 0, 0);
+            }
+        }
+        if (!more) break;
+        more = cur.valid();
+        stage ^= 1;
+    }
+    f16x2_epilogue<EPI>(p, hi, lo, m0 + wm * 64, n0 + wn * 64, (n0 >> 1) + wn * 32, lane);
+}
+
+template <int EPI>
+int launch_tiled(const GemmParams& p, hipStream_t stream) {
+    static DvqOncePerDevice attr_once;
+    {
+        const hipError_t e = attr_once.run([] {
+            const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_kernel<EPI, false>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM);
+            const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_kernel<EPI, true>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM);
+            return e0 != hipSuccess ? e0 : e1;
+        });
+        if (e != hipSuccess) {
+            dvq_set_error("gemm_f16x2: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return DVQ_ELAUNCH;
+        }
+    }
+    const long tiles_m = (p.M + TM - 1) / TM;
+    const long tiles_n = (p.N + TN - 1) / TN;
+    const long grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
+    static const char* const names[] = {"gemm_bias", "gemm_resid", "gemm_gate"};
+    double ksum = 0;
+    for (int s = 0; s < p.nsrc; ++s) ksum += p.src[s].K;
+    {
+        DVQ_PROF(names[EPI], 2.0 * (double)p.M * p.N * ksum, ((double)p.M + p.N) * ksum * 4, stream);
+        if (dvq_knobs().gemm_dephase) DVQ_LAUNCH((gemm_f16x2_kernel<EPI, true>), dim3((unsigned)grid), dim3(512), SMEM, stream, p);
+        else DVQ_LAUNCH((gemm_f16x2_kernel<EPI, false>), dim3((unsigned)grid), dim3(512), SMEM, stream, p);
+    }
+    DVQ_CHECK_LAUNCH("gemm_f16x2");
+    return DVQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- packer
+// row_absmax[n] = max(row_absmax[n], max over o, k of |w[o][n][k]|)   (w: [outer][N][K] dense; one wave per (o, n) row)
+__global__ void f16x2_absmax_kernel(const float* __restrict__ w, long rows, int N, int K, float* __restrict__ absmax) {
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* src = w + row * K;
+    float mx = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float v = fabsf(src[k]);
+        mx = (v > mx || v != v) ? v : mx;                   // a NaN weight poisons the row's scale (outputs NaN, as in fp32)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(mx, o);
+        mx = (ov > mx || ov != ov) ? ov : mx;
+    }
+    if (lane == 0) {
+        // non-negative floats order like their bit patterns; NaN patterns are larger than every finite one
+        atomicMax(reinterpret_cast<unsigned*>(absmax + row % N), __float_as_uint(mx));
+    }
+}
+
+// t_n from the row maximum: the largest power of two with max|w| * 2^t < 2^15  (rows of zeros, Inf or NaN: t = 0)
+__device__ __forceinline__ int f16x2_exponent(float amax) {
+    if (!(amax > 0.f) || !(amax < INFINITY)) return 0;
+    int e;
+    (void)frexpf(amax, &e);                                 // amax = f * 2^e, f in [0.5, 1)
+    int t = 15 - e;
+    if (t > 126) t = 126;                                   // 2^-t must stay a normal fp32 number
+    if (t < -126) t = -126;
+    return t;
+}
+
+__global__ void f16x2_split_kernel(const float* __restrict__ w, long total, int N, int K, const float* __restrict__ absmax,
+                                   uint16_t* __restrict__ planes, float* __restrict__ row_scale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int n = (int)((i / K) % N);
+    const int t = f16x2_exponent(absmax[n]);
+    const float ws = ldexpf(w[i], t);
+    const _Float16 h1 = (_Float16)ws;
+    const float r = ws - (float)h1;
+    const _Float16 h2v = (_Float16)(r * 2048.0f);
+    planes[i] = __builtin_bit_cast(uint16_t, h1);
+    planes[total + i] = __builtin_bit_cast(uint16_t, h2v);
+    if (i < N) row_scale[i] = ldexpf(1.0f, -f16x2_exponent(absmax[i]));
+}
+
+}  // namespace
+
+// Called by dvq_launch_gemm (gemm_f32.hip) after argument validation, when every source carries f16x2 planes.
+int dvq_launch_gemm_f16x2(const GemmParams& p, GemmEpilogue epi, hipStream_t stream) {
+    DVQ_REQUIRE(p.wscale, "gemm_f16x2: planes without row scales");
+    for (int s = 0; s < p.nsrc; ++s) {
+        const GemmSrc& g = p.src[s];
+        DVQ_REQUIRE(g.Wp && dvq_aligned16(g.Wp) && g.wp_plane % 8 == 0 && g.ldw % 8 == 0, "gemm_f16x2: weight planes of source %d are not 16-byte aligned", s);
+    }
+    switch (epi) {
+        case EPI_BIAS: return launch_tiled<EPI_BIAS>(p, stream);
+        case EPI_RESID: return launch_tiled<EPI_RESID>(p, stream);
+        case EPI_GATE:
+            DVQ_REQUIRE(dvq_aligned16(p.out) && p.ldo % 4 == 0 && (!p.pre || (dvq_aligned16(p.pre) && p.ldpre % 4 == 0)), "gemm_f16x2: gate outputs are not 16-byte aligned");
+            return launch_tiled<EPI_GATE>(p, stream);
+        default: break;
+    }
+    dvq_set_error("gemm_f16x2: epilogue %d is not available on the fp16 split path", (int)epi);
+    return DVQ_EINVAL;
+}
+
+extern "C" int dvq_f16x2_row_absmax(const float* w, int64_t outer, int N, int K, float* row_absmax, dvq_stream_t stream) {
+    DVQ_REQUIRE(outer >= 1 && N >= 1 && K >= 1 && w && row_absmax, "f16x2_row_absmax: bad arguments");
+    const long rows = (long)outer * N;
+    DVQ_LAUNCH(f16x2_absmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, w, rows, N, K, row_absmax);
+    DVQ_CHECK_LAUNCH("f16x2_row_absmax");
+    return DVQ_OK;
+}
+
+extern "C" int dvq_split_f16x2(const float* w, int64_t outer, int N, int K, const float* row_absmax, uint16_t* planes, float* row_scale,
+                               dvq_stream_t stream) {
+    DVQ_REQUIRE(outer >= 1 && N >= 1 && K >= 1 && w && row_absmax && planes && row_scale, "split_f16x2: bad arguments");
+    const long total = (long)outer * N * K;
+    DVQ_LAUNCH(f16x2_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, total, N, K, row_absmax, planes,
+               row_scale);
+    DVQ_CHECK_LAUNCH("split_f16x2");
+    return DVQ_OK;
+}

@@ -159,8 +159,8 @@ int launch(const GemmParams& p, hipStream_t stream) {
 int dvq_gemm_mode() {
     static int mode = -1;
     if (mode < 0) {
-        const char* e = getenv("DVQ_GEMM");
-        mode = (e && (e[0] == 'f' || e[0] == 'F')) ? 0 : 1;
+        const char* e = getenv("DVQ_GEMM");                 // "fp32": the exact fp32 chain; "bf16x3" / "f16x2" / unset: follow the weight images
+        mode = (e && (e[0] == 'f' || e[0] == 'F') && (e[1] == 'p' || e[1] == 'P')) ? 0 : 1;
     }
     return mode;
 }
@@ -177,6 +177,17 @@ int dvq_launch_gemm(const GemmParams& p, GemmEpilogue epi, hipStream_t stream) {
                     "gemm: source %d rows are not 16-byte aligned", s);
     }
     const bool split = dvq_gemm_mode() == 1 && epi != EPI_ARGMIN;     // the exact VQ argmin stays on the fp32 chain
+    if (split && (epi == EPI_BIAS || epi == EPI_RESID || epi == EPI_GATE)) {
+        // fp16 three-product planes (the default packing): every source must carry them, with one row-scale array for the launch
+        int n16 = 0;
+        for (int s = 0; s < p.nsrc; ++s) n16 += (p.src[s].Wp && p.src[s].wp_kind == DVQ_PLANES_F16X2) ? 1 : 0;
+        if (n16) {
+            DVQ_REQUIRE(n16 == p.nsrc, "gemm: %d of %d sources carry fp16 planes (all or none)", n16, p.nsrc);
+            DVQ_REQUIRE(p.out && (epi != EPI_RESID || p.resid), "gemm: null output/residual");
+            DVQ_REQUIRE(epi != EPI_GATE || (p.N % BN == 0 && (!p.cls || p.label)), "gemm: gated epilogue needs N %% 128 == 0 (N=%d) and labels with a class bias", p.N);
+            return dvq_launch_gemm_f16x2(p, epi, stream);
+        }
+    }
     switch (epi) {
         case EPI_BIAS:
             DVQ_REQUIRE(p.out, "gemm: null output");
@@ -215,7 +226,11 @@ extern "C" int dvq_linear(const dvq_gemm_src* src, int nsrc, int64_t M, int N, c
     if (M == 0) return DVQ_OK;
     GemmParams p = {};
     for (int s = 0; s < nsrc; ++s)
-        p.src[s] = GemmSrc{src[s].x, src[s].w, (long)src[s].ldx, (long)src[s].ldw, src[s].K, 0, src[s].wp, (long)src[s].wp_plane};
+        p.src[s] = GemmSrc{src[s].x, src[s].w, (long)src[s].ldx, (long)src[s].ldw, src[s].K, src[s].wp_kind, src[s].wp, (long)src[s].wp_plane};
+    for (int s = 1; s < nsrc; ++s)
+        DVQ_REQUIRE(src[s].wp_kind != DVQ_PLANES_F16X2 || !src[s].wp || src[s].w_scale == src[0].w_scale,
+                    "dvq_linear: the fp16 planes of one call share ONE row-scale array (source %d has another)", s);
+    p.wscale = src[0].w_scale;
     p.nsrc = nsrc;
     p.M = M;
     p.N = N;
@@ -251,7 +266,8 @@ extern "C" int dvq_mlp3(const float* x, int64_t ldx, int64_t M, const dvq_mlp_la
     const long ldo[3] = {(long)L[0].n_out, (long)L[1].n_out, (long)ldy};
     for (int i = 0; i < 3; ++i) {
         GemmParams p = {};
-        p.src[0] = GemmSrc{in[i], L[i].w, ldi[i], (long)L[i].k_in, L[i].k_in, 0, L[i].wp, (long)L[i].n_out * L[i].k_in};
+        p.src[0] = GemmSrc{in[i], L[i].w, ldi[i], (long)L[i].k_in, L[i].k_in, L[i].wp_kind, L[i].wp, (long)L[i].n_out * L[i].k_in};
+        p.wscale = L[i].w_scale;
         p.nsrc = 1;
         p.M = M;
         p.N = L[i].n_out;

@@ -180,7 +180,8 @@ extern "C" int dvq_mano_forward(const dvq_mano_model* m, const float* betas, int
         }
         DVQ_CHECK_LAUNCH("mano_pose");
         GemmParams g = {};
-        g.src[0] = GemmSrc{X, m->blend_w, XK, XK, XK, 0, m->blend_w_planes, (long)NV * 3 * XK};
+        g.src[0] = GemmSrc{X, m->blend_w, XK, XK, XK, m->planes_kind, m->blend_w_planes, (long)NV * 3 * XK};
+        g.wscale = m->blend_w_scale;
         g.nsrc = 1;
         g.M = nb;
         g.N = NV * 3;

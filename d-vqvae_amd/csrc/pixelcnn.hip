@@ -137,6 +137,12 @@ int check_weights(const dvq_pixelcnn_weights* w) {
     DVQ_REQUIRE(w && w->layers_host && w->tok_emb && w->w0 && w->b0 && w->w2 && w->b2, "pixelcnn: null weights");
     DVQ_REQUIRE(w->n_layers >= 1 && w->dim >= 64 && w->dim % 64 == 0, "pixelcnn: dim=%d must be a multiple of 64", w->dim);
     DVQ_REQUIRE(w->n_hidden % 32 == 0 && w->n_in >= 1 && w->n_classes >= 1, "pixelcnn: bad head sizes");
+    DVQ_REQUIRE(w->planes_kind == DVQ_PLANES_BF16X3 || w->planes_kind == DVQ_PLANES_F16X2, "pixelcnn: unknown planes_kind %d", w->planes_kind);
+    if (w->planes_kind == DVQ_PLANES_F16X2 && w->w0_p) {
+        DVQ_REQUIRE(w->s0 && w->s2, "pixelcnn: fp16 planes without row scales (head)");
+        for (int l = 0; l < w->n_layers; ++l)
+            DVQ_REQUIRE(w->layers_host[l].sv && w->layers_host[l].sh && w->layers_host[l].sr, "pixelcnn: fp16 planes without row scales (layer %d)", l);
+    }
     return DVQ_OK;
 }
 
@@ -153,6 +159,7 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
         return DVQ_EWORKSPACE;
     }
     const int dim = w->dim, L = w->n_layers;
+    const int kind = w->planes_kind;                      // DVQ_PLANES_*: what every *_p image of this network holds
     for (int64_t b0 = 0; b0 < B; b0 += pl.chunk) {
         const long Bc = (long)((B - b0 < pl.chunk) ? (B - b0) : pl.chunk);
         DVQ_LAUNCH(sanitize_labels_kernel, dim3((unsigned)((Bc + 255) / 256)), dim3(256), 0, st, label + b0, Bc,
@@ -179,7 +186,7 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
                             if (ic < 0 || ic >= GRID) continue;
                             {
                                 const size_t tap = (size_t)(kr * k + kc), wsz = (size_t)2 * dim * dim;
-                                g.src[ns++] = GemmSrc{pl.XV(l, ir * GRID + ic), ly.wv + tap * wsz, (long)dim, (long)dim, dim, 0,
+                                g.src[ns++] = GemmSrc{pl.XV(l, ir * GRID + ic), ly.wv + tap * wsz, (long)dim, (long)dim, dim, kind,
                                                       ly.wv_p ? ly.wv_p + tap * wsz : nullptr, (long)(KR * k) * (long)wsz};
                             }
                         }
@@ -197,6 +204,7 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
                     g.M = Bc;
                     g.N = 2 * dim;
                     g.bias = ly.bv;
+                    g.wscale = ly.sv;
                     g.cls = ly.cls;
                     g.label = pl.lab;
                     g.out = out;
@@ -214,14 +222,14 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
                     const int k = (l == 0) ? 5 : 3, pad = k / 2, KC = k / 2 + 1;
                     GemmParams g = {};
                     int ns = 0;
-                    g.src[ns++] = GemmSrc{pl.HV(l, c), ly.wv2h, (long)2 * dim, (long)2 * dim, 2 * dim, 0, ly.wv2h_p, (long)4 * dim * dim};
+                    g.src[ns++] = GemmSrc{pl.HV(l, c), ly.wv2h, (long)2 * dim, (long)2 * dim, 2 * dim, kind, ly.wv2h_p, (long)4 * dim * dim};
                     for (int kc = 0; kc < KC; ++kc) {
                         if (l == 0 && kc == KC - 1) continue;            // mask 'A': last kernel column
                         const int ic = c - pad + kc;
                         if (ic < 0) continue;
                         {
                             const size_t wsz = (size_t)2 * dim * dim;
-                            g.src[ns++] = GemmSrc{pl.XH(l, r * GRID + ic), ly.wh + kc * wsz, (long)dim, (long)dim, dim, 0,
+                            g.src[ns++] = GemmSrc{pl.XH(l, r * GRID + ic), ly.wh + kc * wsz, (long)dim, (long)dim, dim, kind,
                                                   ly.wh_p ? ly.wh_p + kc * wsz : nullptr, (long)KC * (long)wsz};
                         }
                     }
@@ -229,13 +237,15 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
                     g.M = Bc;
                     g.N = 2 * dim;
                     g.bias = ly.bh;
+                    g.wscale = ly.sh;
                     g.cls = ly.cls;
                     g.label = pl.lab;
                     g.out = pl.g;
                     g.ldo = dim;
                     DVQ_PROPAGATE(dvq_launch_gemm(g, EPI_GATE, st));
                     GemmParams q = {};
-                    q.src[0] = GemmSrc{pl.g, ly.wr, (long)dim, (long)dim, dim, 0, ly.wr_p, (long)dim * dim};
+                    q.src[0] = GemmSrc{pl.g, ly.wr, (long)dim, (long)dim, dim, kind, ly.wr_p, (long)dim * dim};
+                    q.wscale = ly.sr;
                     q.nsrc = 1;
                     q.M = Bc;
                     q.N = dim;
@@ -251,11 +261,13 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
                     }
                 }
                 GemmParams h0 = {};
-                h0.src[0] = GemmSrc{pl.XH(L, pos), w->w0, (long)dim, (long)dim, dim, 0, w->w0_p, (long)w->n_hidden * dim};
+                h0.src[0] = GemmSrc{pl.XH(L, pos), w->w0, (long)dim, (long)dim, dim, kind, w->w0_p, (long)w->n_hidden * dim};
+                h0.wscale = w->s0;
                 h0.nsrc = 1; h0.M = Bc; h0.N = w->n_hidden; h0.bias = w->b0; h0.out = pl.hid; h0.ldo = w->n_hidden; h0.relu = 1;
                 DVQ_PROPAGATE(dvq_launch_gemm(h0, EPI_BIAS, st));
                 GemmParams h2 = {};
-                h2.src[0] = GemmSrc{pl.hid, w->w2, (long)w->n_hidden, (long)w->n_hidden, w->n_hidden, 0, w->w2_p, (long)w->n_in * w->n_hidden};
+                h2.src[0] = GemmSrc{pl.hid, w->w2, (long)w->n_hidden, (long)w->n_hidden, w->n_hidden, kind, w->w2_p, (long)w->n_in * w->n_hidden};
+                h2.wscale = w->s2;
                 h2.nsrc = 1; h2.M = Bc; h2.N = w->n_in; h2.bias = w->b2; h2.out = pl.lg; h2.ldo = w->n_in;
                 DVQ_PROPAGATE(dvq_launch_gemm(h2, EPI_BIAS, st));
                 {

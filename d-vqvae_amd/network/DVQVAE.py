@@ -27,13 +27,13 @@ def _codebooks(mod, n_embeddings=128):
 
 class _MLP(nn.Module):
     def _planes(self, lin):
-        """split-bf16 image of a Linear's weight, rebuilt when the parameter is replaced, moved or edited in place"""
+        """weight image of a Linear (packing.split_planes), rebuilt when the parameter is replaced, moved or edited in place"""
         w = lin.weight
         key = (w.data_ptr(), w._version, str(w.device))
         cache = self.__dict__.setdefault("_plane_cache", {})
         hit = cache.get(id(lin))
         if hit is None or hit[0] != key:
-            hit = (key, packing.split_bf16x3(w.detach()))
+            hit = (key, packing.split_planes(w.detach()))
             cache[id(lin)] = hit
         return hit[1]
 

@@ -83,33 +83,55 @@ def new_err_flag(dev: torch.device) -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------ dense
+def _planes_args(pl, w: Tensor, what: str):
+    """(kind, planes pointer, plane stride, scale pointer, scale tensor) of a weight image handed to an op: a packing.Planes
+    or, as before, the bare int16 [3,N,K] tensor of packing.split_bf16x3."""
+    from . import packing
+    if isinstance(pl, Tensor):
+        pl = packing.Planes(_lib.PLANES_BF16X3, pl)
+    n_pl = 2 if pl.kind == _lib.PLANES_F16X2 else 3
+    t = pl.planes
+    if t.dtype != torch.int16 or tuple(t.shape) != (n_pl,) + tuple(w.shape) or not t.is_contiguous() or not w.is_contiguous():
+        raise RuntimeError(f"{what}: planes must be the contiguous int16 [{n_pl},N,K] image of a contiguous weight")
+    if pl.kind == _lib.PLANES_F16X2 and (pl.scale is None or pl.scale.numel() != w.shape[0] or pl.scale.dtype != torch.float32):
+        raise RuntimeError(f"{what}: fp16 planes need their [N] row scales")
+    return pl.kind, t.data_ptr(), w.numel(), (pl.scale.data_ptr() if pl.scale is not None else None), pl.scale
+
+
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, relu: bool = False,
-           out: Optional[Tensor] = None, planes: Optional[Tensor] = None) -> Tensor:
-    """y = act(x @ weight^T + bias) (dvq_linear).  ``planes`` = packing.split_bf16x3(weight) skips the on-the-fly
-    split of the weight operand on the split-bf16 path."""
+           out: Optional[Tensor] = None, planes=None) -> Tensor:
+    """y = act(x @ weight^T + bias) (dvq_linear).  ``planes`` = packing.split_planes(weight): the pre-split weight image;
+    without it the image is built on the spot (two small launches), so both forms give the same bits."""
     return linear_multi([(x, weight)], bias, relu, out, planes=[planes] if planes is not None else None)
 
 
 def linear_multi(pairs: Sequence[Tuple[Tensor, Tensor]], bias: Optional[Tensor] = None, relu: bool = False,
-                 out: Optional[Tensor] = None, planes: Optional[Sequence[Tensor]] = None) -> Tensor:
+                 out: Optional[Tensor] = None, planes: Optional[Sequence] = None) -> Tensor:
+    """y = act(sum_s x_s @ w_s^T + bias).  fp16 images of one call must come from ONE packing.split_f16x2 group (shared row
+    scales); ``planes=None`` builds that group here when the default (fp16) arithmetic is selected."""
+    from . import packing
     lib = _lib.load()
     dev = _require_gpu(*[t for p in pairs for t in p], bias, out)
     M = pairs[0][0].shape[0]
     N = pairs[0][1].shape[0]
+    if planes is None and packing.gemm_kind() == _lib.PLANES_F16X2 and all(w.is_contiguous() and w.dtype == torch.float32 for _, w in pairs):
+        planes = packing.split_f16x2([w for _, w in pairs])
     srcs = (_lib.GemmSrc * len(pairs))()
+    scale0 = None
     for i, (x, w) in enumerate(pairs):
         _f32(x, "x"), _f32(w, "weight")
         if x.shape[0] != M or w.shape[0] != N or x.shape[1] != w.shape[1]:
             raise RuntimeError(f"linear: shape mismatch x{tuple(x.shape)} w{tuple(w.shape)}")
         px, ldx = _rows(x, "x")
         pw, ldw = _rows(w, "weight")
-        wp, wps = None, 0
+        kind, wp, wps, sp = 0, None, 0, None
         if planes is not None:
-            pl = planes[i]
-            if pl.dtype != torch.int16 or tuple(pl.shape) != (3,) + tuple(w.shape) or not pl.is_contiguous() or not w.is_contiguous():
-                raise RuntimeError("linear: planes must be the contiguous int16 [3,N,K] split of a contiguous weight")
-            wp, wps = pl.data_ptr(), w.numel()
-        srcs[i] = _lib.GemmSrc(px, pw, ldx, ldw, x.shape[1], 0, wp, wps)
+            kind, wp, wps, sp, st = _planes_args(planes[i], w, "linear")
+            if i == 0:
+                scale0 = st
+            elif kind == _lib.PLANES_F16X2 and st is not scale0:
+                raise RuntimeError("linear_multi: the fp16 images of one call must share their row scales (packing.split_f16x2 of the group)")
+        srcs[i] = _lib.GemmSrc(px, pw, ldx, ldw, x.shape[1], kind, wp, wps, sp)
     if bias is not None:
         _f32(bias, "bias")
         if bias.numel() != N or not bias.is_contiguous():
@@ -127,9 +149,9 @@ def linear_multi(pairs: Sequence[Tuple[Tensor, Tensor]], bias: Optional[Tensor] 
 
 def mlp3(x: Tensor, layers, out: Optional[Tensor] = None) -> Tensor:
     """Linear + ReLU, Linear + ReLU, Linear (dvq_mlp3: Decoder / Encoder of network/DVQVAE.py).
-    ``layers`` = three (weight [n_out, k_in], bias or None, planes or None) tuples."""
+    ``layers`` = three (weight [n_out, k_in], bias or None, planes (packing.split_planes) or None) tuples."""
     lib = _lib.load()
-    dev = _require_gpu(x, out, *[t for l in layers for t in l])
+    dev = _require_gpu(x, out, *[t for l in layers for t in l[:2]])
     if len(layers) != 3:
         raise RuntimeError("mlp3: exactly three layers")
     px, ldx = _rows(_f32(x, "x"), "x")
@@ -140,10 +162,10 @@ def mlp3(x: Tensor, layers, out: Optional[Tensor] = None) -> Tensor:
         _f32(w, "weight")
         if not w.is_contiguous() or w.shape[1] != k or (b is not None and (b.numel() != w.shape[0] or not b.is_contiguous())):
             raise RuntimeError(f"mlp3: layer {i} has weight {tuple(w.shape)} for {k} inputs")
-        if pl is not None and (pl.dtype != torch.int16 or tuple(pl.shape) != (3,) + tuple(w.shape) or not pl.is_contiguous()):
-            raise RuntimeError("mlp3: planes must be the contiguous int16 [3,N,K] split of the weight")
-        arr[i] = _lib.MlpLayer(w.data_ptr(), b.data_ptr() if b is not None else None, pl.data_ptr() if pl is not None else None,
-                               w.shape[0], w.shape[1])
+        kind, wp, sp = 0, None, None
+        if pl is not None:
+            kind, wp, _, sp, _ = _planes_args(pl, w, "mlp3")
+        arr[i] = _lib.MlpLayer(w.data_ptr(), b.data_ptr() if b is not None else None, wp, w.shape[0], w.shape[1], sp, kind, 0)
         k = w.shape[0]
     if out is None:
         out = torch.empty(M, k, dtype=torch.float32, device=dev)

@@ -47,6 +47,63 @@ def split_bf16x3(w: Tensor) -> Tensor:
     return out
 
 
+def gemm_kind() -> int:
+    """Which weight image the GEMM weights are packed into: the fp16 three-product split (default, DVQ_GEMM unset or
+    "f16x2"), or the exact three-plane bf16 split with DVQ_GEMM=bf16x3 (and with DVQ_GEMM=fp32, where the library ignores
+    the images and runs the fp32 matrix-core kernel)."""
+    import os
+    v = os.environ.get("DVQ_GEMM", "").strip().lower()
+    if v in ("", "f16x2"):
+        return _lib.PLANES_F16X2
+    if v in ("bf16x3", "fp32"):
+        return _lib.PLANES_BF16X3
+    raise RuntimeError(f"DVQ_GEMM={v!r}: expected f16x2 (default), bf16x3 or fp32")
+
+
+class Planes:
+    """Pre-split image of one weight tensor [..., N, K]: ``planes`` int16 [P, *w.shape] (P = 3: bf16x3, 2: f16x2), ``scale`` =
+    the f16x2 row scales [N] (shared by every tensor split in the same group), ``kind`` = DVQ_PLANES_*."""
+    __slots__ = ("kind", "planes", "scale")
+
+    def __init__(self, kind: int, planes: Tensor, scale: Optional[Tensor] = None):
+        self.kind, self.planes, self.scale = kind, planes, scale
+
+
+def split_f16x2(ws) -> list:
+    """fp16 images of tensors whose products are summed into the SAME output rows (the taps of a conv; horiz_stack and
+    vert_to_horiz of a gated layer): each ``w`` is [N, K] or [outer, N, K]; one power-of-two scale per row for the whole group
+    (dvq_f16x2_row_absmax + dvq_split_f16x2).  Returns one ``Planes`` per tensor, all holding the same ``scale`` tensor."""
+    lib = _lib.load()
+    ws = [w.contiguous() for w in ws]
+    N = ws[0].shape[-2]
+    dev = ws[0].device
+    if any(w.dim() not in (2, 3) or w.shape[-2] != N or w.dtype != torch.float32 or w.device != dev for w in ws):
+        raise RuntimeError("split_f16x2: float32 tensors [N,K] / [outer,N,K] with the same N on one device")
+    absmax = torch.zeros(N, dtype=torch.float32, device=dev)
+    scale = torch.empty(N, dtype=torch.float32, device=dev)
+    out = []
+    with torch.cuda.device(dev):
+        st = torch.cuda.current_stream(dev).cuda_stream
+        for w in ws:
+            outer = w.shape[0] if w.dim() == 3 else 1
+            _lib.check(lib.dvq_f16x2_row_absmax(w.data_ptr(), outer, N, w.shape[-1], absmax.data_ptr(), st), "dvq_f16x2_row_absmax")
+        for w in ws:
+            outer = w.shape[0] if w.dim() == 3 else 1
+            pl = torch.empty((2,) + tuple(w.shape), dtype=torch.int16, device=dev)
+            _lib.check(lib.dvq_split_f16x2(w.data_ptr(), outer, N, w.shape[-1], absmax.data_ptr(), pl.data_ptr(), scale.data_ptr(), st),
+                       "dvq_split_f16x2")
+            out.append(Planes(_lib.PLANES_F16X2, pl, scale))
+    return out
+
+
+def split_planes(w: Tensor, kind: Optional[int] = None) -> Planes:
+    """The weight image of one [N, K] matrix in the current (or the given) kind."""
+    kind = gemm_kind() if kind is None else kind
+    if kind == _lib.PLANES_F16X2:
+        return split_f16x2([w])[0]
+    return Planes(_lib.PLANES_BF16X3, split_bf16x3(w))
+
+
 def pointnet_filter_image(w3: Tensor) -> Tensor:
     """uint8 image of a conv3 weight matrix [1024,128] for the filtered PointNet trunk (dvq_pointnet_pack_filter)."""
     lib = _lib.load()
@@ -75,21 +132,38 @@ class _Packed:
         if self.device == device:
             return self
         self.tensors = {k: (v.to(device) if v.dtype == torch.int16 else _dev(v, device)) for k, v in self.tensors.items()
-                        if not k.endswith(("__planes", "__filter"))}
+                        if not k.endswith(("__planes", "__filter", "__scale"))}
         self.device = device
-        for name in self.PLANES:                        # split-bf16 images of the GEMM weights, built on the device
-            for key in [k for k in self.tensors if k == name or (k.startswith(name) and k[len(name):].isdigit())]:
-                self.tensors[key + "__planes"] = split_bf16x3(self._plane_source(key, self.tensors[key]))
+        self.kind = self._kind()
+        for scale_key, keys in self._plane_groups():    # weight images of the GEMM weights, built on the device
+            srcs = [self._plane_source(k, self.tensors[k]) for k in keys]
+            if self.kind == _lib.PLANES_F16X2:
+                pls = split_f16x2(srcs)
+                for k, pl in zip(keys, pls):
+                    self.tensors[k + "__planes"] = pl.planes
+                self.tensors[scale_key + "__scale"] = pls[0].scale
+            else:
+                for k, src in zip(keys, srcs):
+                    self.tensors[k + "__planes"] = split_bf16x3(src)
         self._bind()
         return self
 
-    PLANES = ()
+    def _kind(self) -> int:
+        return gemm_kind()
+
+    def _plane_groups(self):
+        """[(name of the group's row scales, [tensor keys whose products are summed into the same outputs])]"""
+        return []
 
     def _plane_source(self, key, t):
         return t
 
     def planes_ptr(self, key):
         t = self.tensors.get(key + "__planes")
+        return t.data_ptr() if t is not None else None
+
+    def scale_ptr(self, key):
+        t = self.tensors.get(key + "__scale")
         return t.data_ptr() if t is not None else None
 
     def _bind(self):
@@ -132,7 +206,12 @@ class PackedPointNet(_Packed):
                 setattr(s, name, self.tensors[name].data_ptr())
         self.cstruct = s
 
-    PLANES = ("s_w2", "s_w3", "s_f1", "s_f2", "s_f3", "w2", "w3")
+    def _kind(self):                                     # the trunk kernels multiply conv2 / conv3 themselves (six-product bf16 split,
+        return _lib.PLANES_BF16X3                        # fp16 filter): their images -- and the small STN FCs' -- stay bf16x3
+
+    def _plane_groups(self):
+        return [(k, [k]) for k in ("s_w2", "s_w3", "s_f1", "s_f2", "s_f3", "w2", "w3")]
+
     # the fused trunk kernel consumes conv3's weights with the k order inside every 16-channel block permuted to the order in
     # which conv2's accumulator delivers its channels (pos 8h+j <-> channel 8(j>>2)+4h+(j&3)); see csrc/pointnet.hip
     K_PERM16 = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
@@ -193,6 +272,8 @@ class PackedPixelCNN(_Packed):
             for name, _ in _lib.PixelcnnLayer._fields_:
                 if name.endswith("_p"):
                     setattr(self._layers[i], name, self.planes_ptr(f"{name[:-2]}{i}"))
+                elif name in ("sv", "sh", "sr"):
+                    setattr(self._layers[i], name, self.scale_ptr(f"{name}{i}"))
                 else:
                     setattr(self._layers[i], name, t[f"{name}{i}"].data_ptr())
         s = _lib.PixelcnnWeights()
@@ -201,9 +282,15 @@ class PackedPixelCNN(_Packed):
         s.layers_host = C.cast(self._layers, C.POINTER(_lib.PixelcnnLayer))
         s.w0, s.b0, s.w2, s.b2 = (t[k].data_ptr() for k in ("w0", "b0", "w2", "b2"))
         s.w0_p, s.w2_p = self.planes_ptr("w0"), self.planes_ptr("w2")
+        s.s0, s.s2 = self.scale_ptr("s0"), self.scale_ptr("s2")
+        s.planes_kind = self.kind
         self.cstruct = s
 
-    PLANES = ("wv", "wh", "wv2h", "wr", "w0", "w2")
+    def _plane_groups(self):
+        g = []
+        for i in range(self.n_layers):                  # horiz_stack's taps and vert_to_horiz feed ONE gate (models.py:76-81)
+            g += [(f"sv{i}", [f"wv{i}"]), (f"sh{i}", [f"wh{i}", f"wv2h{i}"]), (f"sr{i}", [f"wr{i}"])]
+        return g + [("s0", ["w0"]), ("s2", ["w2"])]
 
 
 class PackedMano(_Packed):
@@ -234,15 +321,16 @@ class PackedMano(_Packed):
         self.parents[0] = -1
         self.faces = np.asarray(arrays.get("faces", np.zeros((0, 3), dtype=np.int64)))
 
-    PLANES = ("blend_w",)
+    def _plane_groups(self):
+        return [("blend_w", ["blend_w"])]
 
     def _bind(self):
         s = _lib.ManoModel()
-        for name, _ in _lib.ManoModel._fields_[:-1]:
-            if name == "blend_w_planes":
-                s.blend_w_planes = self.planes_ptr("blend_w")
-            else:
-                setattr(s, name, self.tensors[name].data_ptr())
+        for name in ("v_template", "blend_w", "j_template", "j_shapedirs", "weights", "comps", "pose_mean"):
+            setattr(s, name, self.tensors[name].data_ptr())
+        s.blend_w_planes = self.planes_ptr("blend_w")
+        s.blend_w_scale = self.scale_ptr("blend_w")
+        s.planes_kind = self.kind
         for j, p in enumerate(self.parents):
             s.parents[j] = p
         self.cstruct = s

@@ -49,18 +49,26 @@ int dvq_reload_env(void);
  * y[M,N] = act( sum_s x_s[M,K_s] @ w_s[N,K_s]^T + bias[N] ) -- nn.Linear / 1x1 conv / conv taps.
  * Replaces: Decoder.forward (network/DVQVAE.py:183-185), STN3d fc1..fc3 (pointnet_encoder.py:35-37),
  * Encoder.forward (DVQVAE.py:161-166).  K_s % 32 == 0, 16-byte aligned rows.
- * Arithmetic ("split-bf16", default): every fp32 operand is split exactly into three bf16 pieces and the six
- * partial products of weight >= 2^-24 are accumulated in fp32 on the bf16 matrix cores -- fp32-GEMM accuracy at
- * 2.67x fewer MFMA cycles.  DVQ_GEMM=fp32 in the environment selects v_mfma_f32_32x32x2_f32 instead.  Weights may be
- * handed over pre-split (`wp`, built by dvq_split_bf16x3) to skip their on-the-fly split. */
+ * Arithmetic: fp32 operands on the 16-bit matrix cores, fp32 accumulation, fp32-GEMM-class accuracy (<= 4e-6 * sum|x w| against
+ * fp64, measured ~1e-7).  What runs follows the weight image handed over in `wp`:
+ *   DVQ_PLANES_F16X2  (dvq_split_f16x2; what the host mirror packs by default): w * 2^t[n] (one power of two per output row) as
+ *       two fp16 planes, the second holding the remainder * 2^11; activations are split the same way while they are staged;
+ *       THREE products per fp32 product in two accumulators: out = (x1 w1 + (x1 w2 + x2 w1) * 2^-11) * 2^-t[n].  |x| < 65 520
+ *       (fp16 range): a row beyond it comes out NaN, never silently wrong.
+ *   DVQ_PLANES_BF16X3 (dvq_split_bf16x3), or no image at all (split on the fly): every operand split EXACTLY into three bf16
+ *       pieces, the six partial products of weight >= 2^-24: fp32's range, twice the matrix work.
+ * DVQ_GEMM=fp32 in the environment ignores the images and runs v_mfma_f32_32x32x2_f32 (exact fp32 chain). */
+#define DVQ_PLANES_BF16X3 0
+#define DVQ_PLANES_F16X2 1
 typedef struct {
     const float* x; /* [M, K] row stride ldx */
     const float* w; /* [N, K] row stride ldw */
     int64_t ldx, ldw;
     int32_t K;
-    int32_t _pad;
-    const uint16_t* wp; /* optional: w pre-split into three bf16 planes [3][N][ldw] (see "split-bf16" below) */
+    int32_t wp_kind;    /* DVQ_PLANES_* of `wp` */
+    const uint16_t* wp; /* optional: w pre-split into planes [3 or 2][N][ldw] */
     int64_t wp_plane;   /* elements between planes */
+    const float* w_scale; /* DVQ_PLANES_F16X2: [N] row scales 2^-t[n] (dvq_split_f16x2); ONE array for all sources of a call */
 } dvq_gemm_src;
 
 #define DVQ_MAX_SRC 8
@@ -75,14 +83,26 @@ int dvq_linear(const dvq_gemm_src* src_host, int nsrc, int64_t M, int N, const f
 typedef struct {
     const float* w;      /* [n_out, k_in] */
     const float* b;      /* [n_out] or NULL */
-    const uint16_t* wp;  /* optional [3][n_out][k_in] */
+    const uint16_t* wp;  /* optional planes [3 or 2][n_out][k_in] */
     int32_t n_out, k_in;
+    const float* w_scale; /* DVQ_PLANES_F16X2: [n_out] */
+    int32_t wp_kind;     /* DVQ_PLANES_* */
+    int32_t _pad;
 } dvq_mlp_layer;
 size_t dvq_mlp3_workspace_bytes(int64_t M, int n0, int n1);
 int dvq_mlp3(const float* x, int64_t ldx, int64_t M, const dvq_mlp_layer* layers_host /* [3] */, float* y, int64_t ldy,
              void* workspace, size_t workspace_bytes, dvq_stream_t stream);
 /* planes[p][i] (p = 0,1,2; bf16 bit patterns) with w[i] == planes[0][i] + planes[1][i] + planes[2][i] exactly */
 int dvq_split_bf16x3(const float* w, int64_t n, uint16_t* planes, dvq_stream_t stream);
+/* The fp16 image of a weight tensor w [outer][N][K] (dense; outer = conv taps, 1 for nn.Linear), N = output rows:
+ *   dvq_f16x2_row_absmax: row_absmax[n] = max(row_absmax[n], max_{o,k} |w[o][n][k]|)  -- the caller zeroes row_absmax [N] and
+ *       calls this once per tensor whose products are summed into the same outputs (all taps of a conv; horiz_stack and
+ *       vert_to_horiz of a gated layer, models.py:76-81);
+ *   dvq_split_f16x2: t[n] = largest power of two with row_absmax[n] * 2^t < 2^15; planes[0] = fp16(w * 2^t[n]),
+ *       planes[1] = fp16((w * 2^t[n] - planes[0]) * 2^11), both [outer][N][K]; row_scale[n] = 2^-t[n]. */
+int dvq_f16x2_row_absmax(const float* w, int64_t outer, int N, int K, float* row_absmax, dvq_stream_t stream);
+int dvq_split_f16x2(const float* w, int64_t outer, int N, int K, const float* row_absmax, uint16_t* planes /* [2][outer][N][K] */,
+                    float* row_scale /* [N] */, dvq_stream_t stream);
 
 /* ------------------------------------------------------------------ VQ codebook nearest neighbour
  * VectorQuantizer.forward(z, istrain=False), network/vqvae/quantizer.py:46-49:
@@ -171,18 +191,22 @@ typedef struct {
     const float* cls;  /* class_cond_embedding [n_classes][2*dim] gate-packed              */
     const float* wr;   /* horiz_resid [dim][dim]                                           */
     const float* br;   /* [dim]                                                            */
-    /* optional split-bf16 planes (dvq_split_bf16x3 of the whole tensor): [3][n_taps][2*dim][dim] for wv / wh */
+    /* optional weight images of the whole tensors (kind: dvq_pixelcnn_weights.planes_kind): [3 or 2][n_taps][2*dim][dim] for wv / wh */
     const uint16_t *wv_p, *wh_p, *wv2h_p, *wr_p;
+    /* DVQ_PLANES_F16X2: row scales of the three GEMMs of a layer: vertical [2*dim], horizontal [2*dim] (wh and wv2h are summed
+     * into the same outputs: their images share one absmax), residual [dim] */
+    const float *sv, *sh, *sr;
 } dvq_pixelcnn_layer;
 
 typedef struct {
     int32_t n_layers, dim, n_in /* tokens */, n_classes, n_hidden /* 2048 */;
-    int32_t _pad;
+    int32_t planes_kind;        /* DVQ_PLANES_* of every *_p image below and in the layers */
     const float* tok_emb;       /* embedding.weight [n_in][dim] */
     const dvq_pixelcnn_layer* layers_host; /* host array [n_layers]; layer 0: mask A applied, k=5 */
     const float *w0, *b0;       /* output_conv.0 [n_hidden][dim] */
     const float *w2, *b2;       /* output_conv.2 [n_in][n_hidden] */
-    const uint16_t *w0_p, *w2_p; /* optional split-bf16 planes */
+    const uint16_t *w0_p, *w2_p; /* optional weight images */
+    const float *s0, *s2;        /* DVQ_PLANES_F16X2: their row scales [n_hidden], [n_in] */
 } dvq_pixelcnn_weights;
 
 size_t dvq_pixelcnn_workspace_bytes(const dvq_pixelcnn_weights* w_host, int64_t B);
@@ -203,13 +227,16 @@ int dvq_pixelcnn_forward(const dvq_pixelcnn_weights* w_host, const int64_t* x, c
 typedef struct {
     const float* v_template;  /* [778,3] = the blendshape GEMM's bias [2334] */
     const float* blend_w;     /* [2334][160]: row e = [shapedirs[.,e] (10) | posedirs[.,e] (135) | 0 (15)]: V = X . blend_w^T */
-    const uint16_t* blend_w_planes;   /* optional split-bf16 planes of blend_w (dvq_split_bf16x3), [3][2334][160] */
+    const uint16_t* blend_w_planes;   /* optional weight image of blend_w, [3 or 2][2334][160] (planes_kind) */
     const float* j_template;  /* [16,3]   J_regressor @ v_template */
     const float* j_shapedirs; /* [10][48] J_regressor @ shapedirs */
     const float* weights;     /* [778,16] */
     const float* comps;       /* [45,45] hands_components */
     const float* pose_mean;   /* [48] */
     int32_t parents[16];
+    const float* blend_w_scale;       /* DVQ_PLANES_F16X2: [2334] row scales */
+    int32_t planes_kind;              /* DVQ_PLANES_* of blend_w_planes */
+    int32_t _pad;
 } dvq_mano_model;
 
 /* betas [B,10] (row stride ldb), pose [B,45] (ldp), optional global_orient [B,3] (ldg) and transl

@@ -16,7 +16,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in sorted(declared) if not hasattr(lib, n)]
     assert not missing, f"declared in dvq.h but not exported: {missing}"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert lib.dvq_abi_version() == 5
+    assert lib.dvq_abi_version() == 6
 
 
 def test_workspace_queries_need_no_gpu():

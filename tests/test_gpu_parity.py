@@ -37,11 +37,14 @@ def test_linear(M, N, K):
         assert_close(y, ref.float(), atol=2e-5, rtol=1e-5)
 
 
-def test_linear_fuzz_shapes_planes_and_batch_invariance():
-    """60 random (M, N, K): on-the-fly and pre-split weight planes give the same bits, results within fp32-GEMM accuracy of
-    the fp64 product, and every row of a batched call equals the same row computed in a smaller batch (the accumulation
-    order does not depend on the M tiling)."""
-    from dvqvae_amd import packing
+@pytest.mark.parametrize("kind", ["f16x2", "bf16x3"])
+def test_linear_fuzz_shapes_planes_and_batch_invariance(kind):
+    """60 random (M, N, K) per weight image (the fp16 three-product split = the default, and the six-product bf16 split): a
+    pre-split image and one built on the fly give the same bits, results within fp32-GEMM accuracy of the fp64 product, and
+    every row of a batched call equals the same row computed in a smaller batch (the accumulation order does not depend on
+    the M tiling)."""
+    from dvqvae_amd import _lib, packing
+    k = _lib.PLANES_F16X2 if kind == "f16x2" else _lib.PLANES_BF16X3
     rng = np.random.default_rng(3)
     for it in range(60):
         M = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 300, 1000, 4097]))
@@ -49,19 +52,49 @@ def test_linear_fuzz_shapes_planes_and_batch_invariance():
         K = 32 * int(rng.integers(1, 50))
         x = torch.randn(M, K, device=DEV) * float(10 ** rng.uniform(-2, 2))
         w = torch.randn(N, K, device=DEV) / np.sqrt(K)
+        if it % 7 == 3:
+            w *= torch.exp2(torch.randint(-30, 30, (N, 1), device=DEV).float())     # row magnitudes 2^-30 .. 2^30
         b = torch.randn(N, device=DEV) if it % 3 else None
         relu = bool(it % 2)
-        y = ops.linear(x, w, b, relu=relu)
-        yp = ops.linear(x, w, b, relu=relu, planes=packing.split_bf16x3(w))
+        y = _with_env("DVQ_GEMM", kind, lambda: ops.linear(x, w, b, relu=relu))
+        yp = ops.linear(x, w, b, relu=relu, planes=packing.split_planes(w, k))
         assert torch.equal(y, yp), f"case {it}: planes path differs"
         ref = x.double() @ w.double().t() + (b.double() if b is not None else 0)
         if relu:
             ref = ref.clamp_min(0)
-        scale = float((x.double().abs() @ w.double().abs().t()).max())
-        assert float((y.double() - ref).abs().max()) <= 4e-6 * scale + 1e-30, f"case {it}: M={M} N={N} K={K}"
+        scale = (x.double().abs() @ w.double().abs().t()) + (b.double().abs() if b is not None else 0)
+        assert bool(((y.double() - ref).abs() <= 4e-6 * scale.max(dim=0, keepdim=True).values + 1e-30).all()), f"case {it}: M={M} N={N} K={K}"
         lo = int(rng.integers(0, M))
         hi = min(M, lo + int(rng.integers(1, 70)))
-        assert torch.equal(ops.linear(x[lo:hi], w, b, relu=relu), y[lo:hi]), f"case {it}: rows {lo}:{hi} depend on the batch"
+        assert torch.equal(ops.linear(x[lo:hi], w, b, relu=relu, planes=packing.split_planes(w, k)), y[lo:hi]), f"case {it}: rows {lo}:{hi} depend on the batch"
+
+
+def test_linear_f16x2_range_and_small_magnitudes():
+    """The fp16 split keeps 22 bits of an activation down to |x| = 2^-14 and an absolute error of 2^-36 below; |x| >= 65 520
+    (fp16's range) turns that ROW into NaN -- never a silently wrong number -- and leaves the other rows alone."""
+    from dvqvae_amd import _lib, packing
+    if os.environ.get("DVQ_GEMM", "").lower() == "fp32":
+        pytest.skip("DVQ_GEMM=fp32: the library ignores the weight images")
+    torch.manual_seed(17)
+    M, N, K = 200, 256, 512
+    w = torch.randn(N, K, device=DEV) / np.sqrt(K)
+    pl = packing.split_planes(w, _lib.PLANES_F16X2)
+    for mag in (1e-3, 1e-4, 3e-6):
+        x = torch.randn(M, K, device=DEV) * mag
+        y = ops.linear(x, w, None, planes=pl)
+        ref = x.double() @ w.double().t()
+        scale = float((x.double().abs() @ w.double().abs().t()).max())
+        assert float((y.double() - ref).abs().max()) <= 4e-6 * scale + K * 2.0 ** -36 * float(w.abs().max())
+    x = torch.randn(M, K, device=DEV)
+    y0 = ops.linear(x, w, None, planes=pl)
+    x[7, 100] = 7.0e4
+    x[9, 3] = -1.0e30
+    y = ops.linear(x, w, None, planes=pl)
+    assert bool(torch.isnan(y[7]).all()) and bool(torch.isnan(y[9]).all())
+    keep = [i for i in range(M) if i not in (7, 9)]
+    assert torch.equal(y[keep], y0[keep])
+    yb = ops.linear(x, w, None, planes=packing.split_planes(w, _lib.PLANES_BF16X3))       # the six-product split has fp32's range
+    assert bool(torch.isfinite(yb).all())
 
 
 def test_linear_multi_source_and_strided_views():
@@ -85,19 +118,21 @@ def test_linear_rejects_bad_inputs():
         ops.linear(torch.zeros(4, 64, device=DEV), torch.zeros(8, 32, device=DEV))       # K mismatch
 
 
+@pytest.mark.parametrize("kind", [1, 0])
 @pytest.mark.parametrize("sizes", [(2560, 1024, 256, 55), (2048, 1024, 128, 6), (1024, 1024, 512, 256)])
-def test_mlp3_equals_three_linears_bitwise(sizes):
-    """dvq_mlp3 (Decoder / Encoder as one entry point) = the same three GEMM launches as three dvq_linear calls."""
+def test_mlp3_equals_three_linears_bitwise(sizes, kind):
+    """dvq_mlp3 (Decoder / Encoder as one entry point) = the same three GEMM launches as three dvq_linear calls (both weight images)."""
     ws = [gpu(synth.synthetic_normal((sizes[i + 1], sizes[i]), SEED, f"mlp3/w/{i}", sizes[i] ** -0.5)) for i in range(3)]
     bs = [gpu(synth.synthetic_normal((sizes[i + 1],), SEED, f"mlp3/b/{i}", 0.1)) for i in range(3)]
-    pls = [packing.split_bf16x3(w) for w in ws]
+    pls = [packing.split_planes(w, kind) for w in ws]
     for M in (1, 37, 3000):
         x = gpu(synth.synthetic_normal((M, sizes[0]), SEED, f"mlp3/x/{M}"))
         h = x
         for i in range(3):
             h = ops.linear(h, ws[i], bs[i], relu=i < 2, planes=pls[i])
         assert torch.equal(ops.mlp3(x, [(ws[i], bs[i], pls[i]) for i in range(3)]), h)
-        assert torch.equal(ops.mlp3(x, [(ws[i], bs[i], None) for i in range(3)]), h)
+        if kind == 0:
+            assert torch.equal(ops.mlp3(x, [(ws[i], bs[i], None) for i in range(3)]), h)      # no image: the on-the-fly bf16 split
     assert ops.mlp3(torch.zeros(0, sizes[0], device=DEV), [(ws[i], bs[i], None) for i in range(3)]).shape == (0, sizes[3])
     with pytest.raises(RuntimeError):
         ops.mlp3(torch.zeros(4, sizes[0], device=DEV), [(ws[0], bs[0], None), (ws[2], bs[2], None), (ws[1], bs[1], None)])
@@ -865,6 +900,19 @@ def test_fp32_gemm_branch_matches_goldens(tmp_path):
     assert " passed" in r.stdout
 
 
+def test_bf16x3_gemm_branch_matches_goldens(tmp_path):
+    """DVQ_GEMM=bf16x3 packs every GEMM weight as the exact three-plane bf16 split (six products, fp32's range: what the
+    fp16 three-product default falls back to): a fresh process runs the same golden subset on it."""
+    import os, subprocess, sys
+    env = dict(os.environ, DVQ_GEMM="bf16x3")
+    sel = ("test_linear or test_pointnet_golden or test_pixelcnn_small_golden or test_pixelcnn_sampling_golden or test_decoders_golden "
+           "or test_gen_end_to_end_golden or test_gen_batched_equals_loop")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", sel,
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 _GEMM_VARIANT_SCRIPT = r"""
 import sys, torch
 sys.path.insert(0, sys.argv[2]); sys.path.insert(0, sys.argv[2] + "/tests")
@@ -876,7 +924,7 @@ dev, out = "cuda:0", {}
 torch.manual_seed(0)
 for (M, N, K) in ((300, 512, 512), (4, 768, 1024), (16384, 1024, 512), (1000, 256, 96)):
     x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * 0.05; b = torch.randn(N, device=dev)
-    out[f"lin{M}x{N}x{K}"] = ops.linear(x, w, b, relu=True, planes=packing.split_bf16x3(w)).cpu()
+    out[f"lin{M}x{N}x{K}"] = ops.linear(x, w, b, relu=True, planes=packing.split_planes(w)).cpu()
 net = GatedPixelCNN(512, 512, 15, 128); load_synth(net, 5); net = net.to(dev)
 g = torch.Generator().manual_seed(1)
 x = torch.randint(0, 512, (150, 3, 3), generator=g).to(dev); lab = torch.randint(0, 128, (150,), generator=g).to(dev)
@@ -886,21 +934,24 @@ torch.save(out, sys.argv[1])
 
 
 def test_gemm_tile_variants_agree_bitwise(tmp_path):
-    """The 128x256 eight-wave GEMM tile (default where N % 256 == 0, N >= 512) and the 128x128 tile (DVQ_GEMM_WIDE=0) use the
-    same accumulation order: bias/ReLU GEMMs and the full 15-layer PixelCNN forward (gate, residual, multi-tap sources, ragged
-    M) must agree bit for bit -- and repeat bit for bit (a missing wait before the K-loop barrier showed up as run-to-run noise)."""
+    """Six-product kernels (DVQ_GEMM=bf16x3): the 128x256 eight-wave tile (default where N % 256 == 0, N >= 512) and the 128x128
+    tile (DVQ_GEMM_WIDE=0) use the same accumulation order.  Three-product kernels (default): the two feeding schedules of the
+    tiled kernel (DVQ_GEMM_DEPHASE).  Bias/ReLU GEMMs and the full 15-layer PixelCNN forward (gate, residual, multi-tap sources,
+    ragged M) must agree bit for bit -- and repeat bit for bit (a missing wait before the K-loop barrier showed up as
+    run-to-run noise)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for tag, wide in (("wide", "1"), ("narrow", "0"), ("wide2", "1")):
-        path = str(tmp_path / f"{tag}.pt")
-        r = subprocess.run([sys.executable, "-c", _GEMM_VARIANT_SCRIPT, path, root], env=dict(os.environ, DVQ_GEMM_WIDE=wide),
-                           capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        outs.append(torch.load(path))
-    for k in outs[0]:
-        assert torch.equal(outs[0][k], outs[1][k]), f"{k}: wide tile != 128x128 tile"
-        assert torch.equal(outs[0][k], outs[2][k]), f"{k}: wide tile not repeatable"
+    for mode, knob in (("bf16x3", "DVQ_GEMM_WIDE"), ("f16x2", "DVQ_GEMM_DEPHASE")):
+        outs = []
+        for tag, val in (("a", "1"), ("b", "0"), ("a2", "1")):
+            path = str(tmp_path / f"{mode}_{tag}.pt")
+            r = subprocess.run([sys.executable, "-c", _GEMM_VARIANT_SCRIPT, path, root], env=dict(os.environ, DVQ_GEMM=mode, **{knob: val}),
+                               capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+            outs.append(torch.load(path))
+        for k in outs[0]:
+            assert torch.equal(outs[0][k], outs[1][k]), f"{mode} {k}: {knob}=1 != {knob}=0"
+            assert torch.equal(outs[0][k], outs[2][k]), f"{mode} {k}: not repeatable"
 
 
 def test_pointnet_large_clouds_nonfinite_inputs_and_missing_filter_image():
@@ -983,21 +1034,25 @@ def test_default_noise_is_fresh_per_call_and_follows_manual_seed():
     assert tuple(n.shape) == (5, 30) and n.is_contiguous() and torch.equal(n, ops.exp1_noise(5, 32, 1, device=DEV)[:, :30])
 
 
-def test_skinny_gemm_equals_tiled_kernels_bitwise():
-    """Small M (the reference's B = 1 / 8 / 100 call pattern) runs the per-wave 32 x 32 kernel; it issues the tiled kernels' MFMA
-    sequence, so bias / ReLU, residual, multi-source and gated results (the whole PixelCNN forward) must be bit-identical with
-    DVQ_GEMM_SKINNY=0, and a batch must equal its rows computed one by one."""
+@pytest.mark.parametrize("kind", ["f16x2", "bf16x3"])
+def test_skinny_gemm_equals_tiled_kernels_bitwise(kind):
+    """Small M (the reference's B = 1 / 8 / 100 call pattern) runs the skinny kernels; they issue the tiled kernels' MFMA sequence,
+    so bias / ReLU, residual, multi-source and gated results (the whole PixelCNN forward) must be bit-identical with
+    DVQ_GEMM_SKINNY=0, and a batch must equal its rows computed one by one -- for both weight images."""
+    from dvqvae_amd import _lib
     from dvqvae_amd.network.pixelcnn.models import GatedPixelCNN
     torch.manual_seed(5)
+    k = _lib.PLANES_F16X2 if kind == "f16x2" else _lib.PLANES_BF16X3
 
     def run():
         out = {}
-        for (M, N, K) in ((1, 9, 256), (5, 55, 256), (32, 512, 512), (33, 1024, 1024), (100, 2048, 512), (256, 128, 1024), (7, 6, 128)):
+        for (M, N, K) in ((1, 9, 256), (5, 55, 256), (16, 512, 512), (17, 128, 96), (32, 512, 512), (33, 1024, 1024), (100, 2048, 512), (256, 128, 1024), (7, 6, 128)):
             g = torch.Generator().manual_seed(M * 1000 + N)
             x = gpu(torch.randn(M, K, generator=g)); w = gpu(torch.randn(N, K, generator=g) * 0.05); b = gpu(torch.randn(N, generator=g))
-            out[f"lin{M}x{N}x{K}"] = ops.linear(x, w, b, relu=True, planes=packing.split_bf16x3(w))
+            out[f"lin{M}x{N}x{K}"] = ops.linear(x, w, b, relu=True, planes=packing.split_planes(w, k))
             x2 = gpu(torch.randn(M, 64, generator=g)); w2 = gpu(torch.randn(N, 64, generator=g))
-            out[f"multi{M}x{N}"] = ops.linear_multi([(x, w), (x2, w2)], b, planes=[packing.split_bf16x3(w), packing.split_bf16x3(w2)])
+            pls = packing.split_f16x2([w, w2]) if k == _lib.PLANES_F16X2 else [packing.split_bf16x3(w), packing.split_bf16x3(w2)]
+            out[f"multi{M}x{N}"] = ops.linear_multi([(x, w), (x2, w2)], b, planes=pls)
         net = GatedPixelCNN(512, 512, 15, 128)
         load_synth(net, 5)
         net = net.to(DEV)
@@ -1006,12 +1061,14 @@ def test_skinny_gemm_equals_tiled_kernels_bitwise():
         out["logits"] = net(x, lab)
         out["logits_row3"] = net(x[3:4], lab[3:4])
         return out
-    a = run()
-    b = _with_env("DVQ_GEMM_SKINNY", "0", run)
-    c = _with_env("DVQ_GEMM_SKINNY", "2", run)              # the register-staged variant of the skinny kernel
-    for k in a:
-        assert torch.equal(a[k], b[k]), f"{k}: skinny kernel != tiled kernel"
-        assert torch.equal(a[k], c[k]), f"{k}: LDS-staged skinny kernel != register-staged one"
+    a = _with_env("DVQ_GEMM", kind, run)
+    b = _with_env("DVQ_GEMM", kind, lambda: _with_env("DVQ_GEMM_SKINNY", "0", run))
+    for key in a:
+        assert torch.equal(a[key], b[key]), f"{key}: skinny kernel != tiled kernel"
+    if kind == "bf16x3":
+        c = _with_env("DVQ_GEMM", kind, lambda: _with_env("DVQ_GEMM_SKINNY", "2", run))   # the register-staged variant of the skinny kernel
+        for key in a:
+            assert torch.equal(a[key], c[key]), f"{key}: LDS-staged skinny kernel != register-staged one"
     assert torch.equal(a["logits"][3:4], a["logits_row3"])
 
 

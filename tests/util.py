@@ -16,7 +16,7 @@ def load_synth(module, seed):
     return sd
 
 
-def assert_close(a, b, atol=1e-5, rtol=1e-5, what=""):
+def assert_close(a, b, atol=1e-5, rtol=0.0, what=""):
     a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
     b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
     np.testing.assert_allclose(a, b, atol=atol, rtol=rtol, err_msg=what)
