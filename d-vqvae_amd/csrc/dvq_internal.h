@@ -175,6 +175,7 @@ struct DvqKnobs {
     int vq_kernel;        // 16 (default): vq_stream16.hip; 8: vq_stream.hip's eight-wave kernel; 32: vq_rows.hip (DVQ_VQ_KERNEL)
     int gemm_skinny_prefetch;   // 0: no helper workgroups (DVQ_GEMM_SKINNY_PREFETCH=0)
     int gemm_skinny;      // 0: tiled kernels also for M <= 256 (DVQ_GEMM_SKINNY=0; the two must agree bitwise)
+    int gemm_skinny_cols; // f16x2 skinny kernel: output columns per wave, 16 / 8 / 4 (DVQ_GEMM_SKINNY_COLS; 0 = by the launch's size; same bits)
     int pn_filter;        // 0 six-product trunk, 1 default, 2 filtered trunk whatever the tile fill
     int pn_exhaustive;    // 1: exact stage evaluates every point (what the filter must reproduce bit for bit)
     int pn_caps[2];       // candidate-list capacities (tests shrink them to reach the overflow paths); <= 0: default

@@ -295,6 +295,197 @@ int launch_tiled(const GemmParams& p, hipStream_t stream) {
     return DVQ_OK;
 }
 
+// ================================================================================================================
+// Skinny kernel for M <= 256 (the reference's own call pattern: GenNet.gen with B = 1 per call, 1 / 20 / 49 / 100 grasps per object,
+// gen_diverse_grasp_ho3d.py:212-236): a B = 1 call is ~470 dependent GEMM launches with M = 1 row each, so what counts is the
+// time of ONE small launch, not throughput.  Measured (gated launch, K = 3072, M = 1): 13.5 us whether a wave owns 16, 8 or 4
+// columns (32 / 64 / 128 waves), with 24 or 48 KB of loads in flight, with or without 192 helper workgroups sweeping the rows
+// into the XCD's L2: not the weight stream but the wave's own instruction stream, ~70 instructions per k-step of which 32 split
+// the activations.  One single-wave workgroup per R output columns (R = 16, 8 or 4: the MFMA's sixteen weight rows are R real
+// rows and repeats, whose outputs nobody reads) and per 16 rows of M; for the gate the block's rows are R tanh columns
+// followed by their R sigmoid partners (R = 8 or 4), exchanged by a lane shuffle in the epilogue.  No LDS, no barrier: the
+// wave streams its weight rows HBM -> registers in the MFMA fragment shape (lane = row l & 15, 16-byte chunk l >> 4 of a
+// 64-byte k-step), its activation rows in whole 128-byte lines, PF k-steps ahead through a ring of register sets (no branch
+// around a load: steps past the end re-load the last tile), splits the activations in registers and runs the tiled kernel's
+// MFMA sequence per output -- hi: (a1 w1), lo: (a1 w2) then (a2 w1), k-steps in source order -- so the result is bit-identical
+// to the batched path (an output's value does not depend on its position in the 16 x 16 block:
+// tests/test_gpu_parity.py::test_skinny_gemm_equals_tiled_kernels_bitwise).
+template <int NB>
+struct SkinnySlot {
+    uint4 w[NB][2];
+    f32x4 a[2];
+};
+
+template <int NB>
+struct SkinnyCursor16 {
+    int s, k_left;
+    const float* a_ptr;
+    const uint16_t* w_ptr[NB][2];
+
+    __device__ __forceinline__ void open(const GemmParams& p, int src_i, long m, const int (&n)[NB], int lc) {
+        s = src_i;
+        const GemmSrc& src = p.src[s];
+        k_left = src.K;
+        a_ptr = src.A + m * src.lda + 8 * lc;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) w_ptr[b][pl] = src.Wp + pl * src.wp_plane + (long)n[b] * src.ldw + 8 * lc;
+    }
+    __device__ __forceinline__ void load(SkinnySlot<NB>& t) const {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            t.w[b][0] = *reinterpret_cast<const uint4*>(w_ptr[b][0]);
+            t.w[b][1] = *reinterpret_cast<const uint4*>(w_ptr[b][1]);
+        }
+        t.a[0] = *reinterpret_cast<const f32x4*>(a_ptr);
+        t.a[1] = *reinterpret_cast<const f32x4*>(a_ptr + 4);
+    }
+    // step to the next k-step of the launch, if there is one (wave-uniform; no load inside)
+    __device__ __forceinline__ void advance(const GemmParams& p, long m, const int (&n)[NB], int lc, bool last) {
+        if (last) return;
+        k_left -= BK;
+        if (k_left > 0) {
+            a_ptr += BK;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { w_ptr[b][0] += BK; w_ptr[b][1] += BK; }
+        } else open(p, s + 1, m, n, lc);
+    }
+};
+
+// block row j (0..15) of column group g -> output column (gate-packed index for the gate); rows past the real ones repeat row 0
+template <int EPI, int R>
+__device__ __forceinline__ int skinny_col(int g, int j) {
+    if constexpr (EPI == EPI_GATE) {
+        constexpr int per64 = 32 / R;                       // groups per 64-column gate block (32 tanh columns + 32 partners)
+        const int c0 = 64 * (g / per64) + R * (g % per64);
+        return j < R ? c0 + j : (j < 2 * R ? c0 + 32 + (j - R) : c0);
+    } else {
+        return j < R ? R * g + j : R * g;
+    }
+}
+
+// NB column groups per wave (2 when the launch has several row groups: they share the activation split, the larger part of a
+// k-step's instructions)
+template <int EPI, int R, int NB, int PF>
+__global__ __launch_bounds__(64) void gemm_f16x2_skinny_kernel(const GemmParams p, int T, int groups) {
+    const int lane = threadIdx.x;
+    const int lr = lane & 15, lc = lane >> 4;
+    const long mb0 = (long)blockIdx.y * 16;
+    long m = mb0 + lr;
+    if (m >= p.M) m = p.M - 1;                              // clamped rows / columns only feed masked outputs
+    int g[NB], n[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        g[b] = (int)blockIdx.x * NB + b;
+        if (g[b] >= groups) g[b] = groups - 1;              // an odd group count: the last wave computes its group twice
+        n[b] = skinny_col<EPI, R>(g[b], lr);
+        if (n[b] >= p.N) n[b] = p.N - 1;
+    }
+    f32x4 hi[NB], lo[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { hi[b] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    SkinnyCursor16<NB> cur;
+    cur.open(p, 0, m, n, lc);
+    SkinnySlot<NB> slot[PF];
+    int issued = 0;                                         // index of the k-step the cursor points at (the last one repeats)
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        cur.load(slot[u]);
+        cur.advance(p, m, n, lc, issued + 1 >= T);
+        issued = issued + 1 < T ? issued + 1 : T;
+    }
+    for (int t = 0; t < T; t += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            if (t + u < T) {
+                h8 a1, a2;
+                split2(slot[u].a[0], slot[u].a[1], a1, a2);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const h8 w1 = __builtin_bit_cast(h8, slot[u].w[b][0]), w2 = __builtin_bit_cast(h8, slot[u].w[b][1]);
+                    hi[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, a1, hi[b], 0, 0, 0);
+                    lo[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2, a1, lo[b], 0, 0, 0);
+                    lo[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, a2, lo[b], 0, 0, 0);
+                }
+            }
+            cur.load(slot[u]);
+            cur.advance(p, m, n, lc, issued + 1 >= T);
+            issued = issued + 1 < T ? issued + 1 : T;
+        }
+    }
+    // epilogue: the tiled kernel's arithmetic per element.  The lane holds block rows 4 lc .. 4 lc + 3 (four consecutive columns)
+    // of output row mb0 + lr.
+    const long mo = mb0 + lr;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (b > 0 && (int)blockIdx.x * NB + b >= groups) break;
+        const int nc = skinny_col<EPI, R>(g[b], 4 * lc);    // first of the lane's four columns
+        if constexpr (EPI == EPI_GATE) {
+            const bool live = 4 * lc < 2 * R && mo < p.M;   // N % 128 == 0: every group is whole
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (live) {
+                v = f16x2_combine(hi[b], lo[b], p.wscale, nc, true);
+                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + nc);
+                if (p.pre) *reinterpret_cast<f32x4*>(p.pre + mo * p.ldpre + nc) = v;
+                if (p.cls) v += *reinterpret_cast<const f32x4*>(p.cls + (long)p.label[mo] * p.N + nc);
+            }
+            f32x4 gg;                                       // the sigmoid partners sit R / 4 lane groups further
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gg[q] = __shfl(v[q], lane + 4 * R, 64);
+            if (live && 4 * lc < R) {
+                f32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = tanhf(v[q]) * sigmoidf_(gg[q]);
+                const int c = 32 * (nc >> 6) + (nc & 31);   // natural channel of gate-packed tanh column nc
+                *reinterpret_cast<f32x4*>(p.out + mo * p.ldo + c) = o;
+            }
+        } else {
+            if (4 * lc >= R || mo >= p.M || nc >= p.N) continue;
+            const bool vec_ok = (p.N % 4 == 0) && (p.ldo % 4 == 0) && (EPI != EPI_RESID || p.ldr % 4 == 0);
+            const bool full = vec_ok && nc + 3 < p.N;
+            f16x2_store_block<EPI>(p, mo, nc, f16x2_combine(hi[b], lo[b], p.wscale, nc, full), full);
+        }
+    }
+}
+
+constexpr long SKINNY_MAX_M = 256;     // above this the tiled kernel wins (every row group re-reads the weight panel from L2)
+
+template <int EPI, int R>
+void launch_skinny_r(const GemmParams& p, int T, int gy, hipStream_t stream) {
+    const int groups = EPI == EPI_GATE ? (p.N / 64) * (32 / R) : (p.N + R - 1) / R;
+    if (gy >= 3) DVQ_LAUNCH((gemm_f16x2_skinny_kernel<EPI, R, 2, 4>), dim3((unsigned)((groups + 1) / 2), (unsigned)gy), dim3(64), 0, stream, p, T, groups);
+    else DVQ_LAUNCH((gemm_f16x2_skinny_kernel<EPI, R, 1, 8>), dim3((unsigned)groups, (unsigned)gy), dim3(64), 0, stream, p, T, groups);
+}
+
+template <int EPI>
+int launch_skinny(const GemmParams& p, hipStream_t stream) {
+    static const char* const names[] = {"gemm_bias", "gemm_resid", "gemm_gate"};
+    double ksum = 0;
+    int T = 0;
+    for (int s = 0; s < p.nsrc; ++s) { ksum += p.src[s].K; T += p.src[s].K / BK; }
+    const int gy = (int)((p.M + 15) / 16);
+    // Columns per wave.  One row group (M <= 16): the launch waits for the single instruction stream of a wave (~70 instructions
+    // per k-step), whatever its width: 8 + 8 gate columns / 16 plain columns per wave.  More row groups: the widest blocks, two
+    // per wave (DVQ_GEMM_SKINNY_COLS = 16 / 8 / 4 forces a width: A/B runs, same bits).
+    const int want = dvq_knobs().gemm_skinny_cols;
+    int R = 16;
+    if (want == 4 || want == 8 || want == 16) R = want;
+    if (EPI == EPI_GATE && R == 16) R = 8;
+    {
+        DVQ_PROF(names[EPI], 2.0 * (double)p.M * p.N * ksum, ((double)p.M + p.N) * ksum * 4, stream);
+        if constexpr (EPI == EPI_GATE) {
+            if (R == 4) launch_skinny_r<EPI, 4>(p, T, gy, stream); else launch_skinny_r<EPI, 8>(p, T, gy, stream);
+        } else {
+            if (R == 4) launch_skinny_r<EPI, 4>(p, T, gy, stream);
+            else if (R == 8) launch_skinny_r<EPI, 8>(p, T, gy, stream);
+            else launch_skinny_r<EPI, 16>(p, T, gy, stream);
+        }
+    }
+    DVQ_CHECK_LAUNCH("gemm_f16x2_skinny");
+    return DVQ_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------- packer
 // row_absmax[n] = max(row_absmax[n], max over o, k of |w[o][n][k]|)   (w: [outer][N][K] dense; one wave per (o, n) row)
 __global__ void f16x2_absmax_kernel(const float* __restrict__ w, long rows, int N, int K, float* __restrict__ absmax) {
@@ -353,12 +544,21 @@ int dvq_launch_gemm_f16x2(const GemmParams& p, GemmEpilogue epi, hipStream_t str
         const GemmSrc& g = p.src[s];
         DVQ_REQUIRE(g.Wp && dvq_aligned16(g.Wp) && g.wp_plane % 8 == 0 && g.ldw % 8 == 0, "gemm_f16x2: weight planes of source %d are not 16-byte aligned", s);
     }
+    bool a_ok = true;                                       // 16-byte activation loads
+    for (int s = 0; s < p.nsrc; ++s) a_ok = a_ok && dvq_aligned16(p.src[s].A) && p.src[s].lda % 4 == 0;
+    DVQ_REQUIRE(a_ok, "gemm_f16x2: activation rows are not 16-byte aligned");
+    if (epi == EPI_GATE)
+        DVQ_REQUIRE(dvq_aligned16(p.out) && p.ldo % 4 == 0 && (!p.pre || (dvq_aligned16(p.pre) && p.ldpre % 4 == 0)), "gemm_f16x2: gate outputs are not 16-byte aligned");
+    if (dvq_knobs().gemm_skinny && p.M <= SKINNY_MAX_M) switch (epi) {
+        case EPI_BIAS: return launch_skinny<EPI_BIAS>(p, stream);
+        case EPI_RESID: return launch_skinny<EPI_RESID>(p, stream);
+        case EPI_GATE: return launch_skinny<EPI_GATE>(p, stream);
+        default: break;
+    }
     switch (epi) {
         case EPI_BIAS: return launch_tiled<EPI_BIAS>(p, stream);
         case EPI_RESID: return launch_tiled<EPI_RESID>(p, stream);
-        case EPI_GATE:
-            DVQ_REQUIRE(dvq_aligned16(p.out) && p.ldo % 4 == 0 && (!p.pre || (dvq_aligned16(p.pre) && p.ldpre % 4 == 0)), "gemm_f16x2: gate outputs are not 16-byte aligned");
-            return launch_tiled<EPI_GATE>(p, stream);
+        case EPI_GATE: return launch_tiled<EPI_GATE>(p, stream);
         default: break;
     }
     dvq_set_error("gemm_f16x2: epilogue %d is not available on the fp16 split path", (int)epi);

@@ -30,6 +30,7 @@ DvqKnobs* read_knobs() {
         k->vq_kernel = v == 8 ? 8 : (v == 32 ? 32 : 16);       // default: the sixteen-wave kernel; 8: eight waves (generated tile body); 32: rows resident, codebook streamed
     }
     k->gemm_skinny_prefetch = !is("DVQ_GEMM_SKINNY_PREFETCH", '0');
+    k->gemm_skinny_cols = (int)num("DVQ_GEMM_SKINNY_COLS");
     k->pn_filter = is("DVQ_PN_FILTER", '0') ? 0 : (is("DVQ_PN_FILTER", '2') ? 2 : 1);
     k->pn_exhaustive = is("DVQ_PN_EXHAUSTIVE", '1');
     k->pn_caps[0] = k->pn_caps[1] = -1;
