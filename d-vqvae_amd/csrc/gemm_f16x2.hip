@@ -264,6 +264,179 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(const GemmParams p) 
     f16x2_epilogue<EPI>(p, hi, lo, m0 + wm * 64, n0 + wn * 64, (n0 >> 1) + wn * 32, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Ping-pong schedule of the same tile (the default): the two waves of a SIMD -- w and w + 4, rows 0..63 and 64..127 of the tile --
+// alternate between a LOAD phase (the sixteen fragment reads of K-tile t; conversion + LDS write of this thread's share of tile
+// t + 2, whose activations it loaded a period ago; LDS-DMA of tile t + 2's weight planes; global loads of tile t + 3's activations)
+// and a COMPUTE phase (the 48 MFMAs of tile t on the fragments in registers, at s_setprio 1), one workgroup barrier per phase,
+// waves 4..7 half a period behind: one wave of every SIMD always has MFMAs to issue.  Three LDS stages (144 KiB): what a load
+// phase issues has two phases to land, and the stage it writes was last read two phases earlier.  Same operands into the same
+// MFMA sequence per output as gemm_f16x2_kernel: bit-identical.  Measured on the gated shape (M 16 384, N 1024, K 1536):
+// 300-307 TFLOP/s against 286-293 for the two-stage dephased kernel; in-kernel stamps (tools/microbench/gemm_f16x2_wide.hip):
+// load phase ~850 cycles + loop overhead against 803 for the compute phase at an in-kernel clock of 1.74 GHz; moving the split
+// into the compute phase's MFMA gaps (1 MFMA : 2 vector instructions) measured SLOWER (273).
+constexpr int PP_STAGES = 3;
+constexpr size_t PP_SMEM = PP_STAGES * STAGE;               // 147 456 B
+
+struct PpCursorA {
+    int s, k_left;
+    const float* a_ptr;
+    __device__ __forceinline__ void open(const GemmParams& p, int src_i, long m0, int tid) {
+        s = src_i;
+        if (s >= p.nsrc) { k_left = 0; return; }
+        const GemmSrc& src = p.src[s];
+        k_left = src.K;
+        long m = m0 + (tid >> 2);
+        if (m >= p.M) m = p.M - 1;                         // clamped rows / columns only feed outputs the epilogue masks
+        a_ptr = src.A + m * src.lda + 8 * (tid & 3);
+    }
+    __device__ __forceinline__ bool valid() const { return k_left > 0; }
+    __device__ __forceinline__ void advance(const GemmParams& p, long m0, int tid) {
+        a_ptr += BK;
+        k_left -= BK;
+        if (k_left <= 0) open(p, s + 1, m0, tid);
+    }
+};
+
+struct PpCursorW {
+    int s, k_left;
+    const uint16_t* w_ptr[4];
+    __device__ __forceinline__ void open(const GemmParams& p, int src_i, int n0, int wave, int lane) {
+        s = src_i;
+        if (s >= p.nsrc) { k_left = 0; return; }
+        const GemmSrc& src = p.src[s];
+        k_left = src.K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                      // 32 pieces of 16 rows x 64 B (two planes x 256 rows), four per wave
+            const int id = wave * 4 + i;
+            const int pl = id >> 4, rb = id & 15;
+            const int row = rb * 16 + (lane >> 2);
+            int n = n0 + row;
+            if (n >= p.N) n = p.N - 1;
+            w_ptr[i] = src.Wp + pl * src.wp_plane + (long)n * src.ldw + 8 * ((lane & 3) ^ swz16(row));
+        }
+    }
+    __device__ __forceinline__ void issue(char* stage, int wave) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = wave * 4 + i;
+            const int pl = id >> 4, rb = id & 15;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[i],
+                                             (__attribute__((address_space(3))) void*)(stage + 2 * A_PL + pl * W_PL + rb * 1024), 16, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void advance(const GemmParams& p, int n0, int wave, int lane) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w_ptr[i] += BK;
+        k_left -= BK;
+        if (k_left <= 0) open(p, s + 1, n0, wave, lane);
+    }
+};
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_f16x2_pp_kernel(const GemmParams p, int T) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    const int tid = threadIdx.x;
+    const int tiles_n = (p.N + TN - 1) / TN;
+    const long tiles_m = (p.M + TM - 1) / TM;
+    const long b = blockIdx.x;
+    const long j = b >> 3;                                  // XCD-aware map: the column tiles of a 128-row panel run on one XCD
+    const long mt = (j / tiles_n) * 8 + (b & 7);
+    const int nt = (int)(j % tiles_n);
+    if (mt >= tiles_m) return;
+    const long m0 = mt * TM;
+    const int n0 = nt * TN;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    PpCursorA ca;
+    PpCursorW cw;
+    ca.open(p, 0, m0, tid);
+    cw.open(p, 0, n0, wave, lane);
+    const int a_dst = (tid >> 2) * 64 + 16 * ((tid & 3) ^ swz16(tid >> 2));
+    f32x4 alo, ahi;
+    auto load_a = [&]() {
+        alo = *reinterpret_cast<const f32x4*>(ca.a_ptr);
+        ahi = *reinterpret_cast<const f32x4*>(ca.a_ptr + 4);
+        ca.advance(p, m0, tid);
+    };
+    auto store_a = [&](char* stage) {
+        h8 p1, p2;
+        split2(alo, ahi, p1, p2);
+        *reinterpret_cast<h8*>(stage + a_dst) = p1;
+        *reinterpret_cast<h8*>(stage + A_PL + a_dst) = p2;
+    };
+    // prologue: tiles 0 and 1 staged, tile 2's activations in registers
+    load_a();
+    cw.issue(smem_c, wave);
+    cw.advance(p, n0, wave, lane);
+    store_a(smem_c);
+    if (T > 1) {
+        load_a();
+        cw.issue(smem_c + STAGE, wave);
+        cw.advance(p, n0, wave, lane);
+        store_a(smem_c + STAGE);
+    }
+    if (T > 2) load_a();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    f32x4 hi[4][4], lo[4][4];                               // [jn][i]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { hi[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int rd = (lane & 15) * 64 + 16 * ((lane >> 4) ^ swz16(lane & 15));       // fragment read: row lane & 15, chunk lane >> 4
+    if (wave >= 4) __builtin_amdgcn_s_barrier();           // the second half runs half a period behind
+    int cur_st = 0, nx_st = 2;                              // stage of tile t, of tile t + 2
+    for (int t = 0; t < T; ++t) {
+        // ---- load phase
+        const char* st = smem_c + cur_st * STAGE;
+        h8 af[4][2], wf[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                af[i][pl] = *reinterpret_cast<const h8*>(st + pl * A_PL + (wm * 64 + i * 16) * 64 + rd);
+                wf[i][pl] = *reinterpret_cast<const h8*>(st + 2 * A_PL + pl * W_PL + (wn * 64 + i * 16) * 64 + rd);
+            }
+        // Everything this wave issued in its previous load phase (a period ago) has landed before it passes this phase's barrier:
+        // the DMA pieces of tile t + 1 -- read by everybody from the next load phase on -- and the activations converted below.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t + 2 < T) {
+            char* nx = smem_c + nx_st * STAGE;
+            store_a(nx);                                    // tile t + 2
+            cw.issue(nx, wave);
+            cw.advance(p, n0, wave, lane);
+            if (t + 3 < T) load_a();                        // tile t + 3
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers (and the plane writes retired) before the phase ends
+        __builtin_amdgcn_s_barrier();
+        // ---- compute phase: hi: (a1 w1); lo: (a1 w2) then (a2 w1) -- per output the order of gemm_f16x2_kernel
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hi[jn][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[jn][0], af[i][0], hi[jn][i], 0, 0, 0);
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lo[jn][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[jn][1], af[i][0], lo[jn][i], 0, 0, 0);
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lo[jn][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[jn][0], af[i][1], lo[jn][i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        cur_st = cur_st == PP_STAGES - 1 ? 0 : cur_st + 1;
+        nx_st = nx_st == PP_STAGES - 1 ? 0 : nx_st + 1;
+    }
+    if (wave < 4) __builtin_amdgcn_s_barrier();            // pairs with the late half's extra barrier
+    f16x2_epilogue<EPI>(p, hi, lo, m0 + wm * 64, n0 + wn * 64, (n0 >> 1) + wn * 32, lane);
+}
+
 template <int EPI>
 int launch_tiled(const GemmParams& p, hipStream_t stream) {
     static DvqOncePerDevice attr_once;
@@ -273,7 +446,9 @@ int launch_tiled(const GemmParams& p, hipStream_t stream) {
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM);
             const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_kernel<EPI, true>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM);
-            return e0 != hipSuccess ? e0 : e1;
+            const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_pp_kernel<EPI>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_SMEM);
+            return e0 != hipSuccess ? e0 : (e1 != hipSuccess ? e1 : e2);
         });
         if (e != hipSuccess) {
             dvq_set_error("gemm_f16x2: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -285,10 +460,13 @@ int launch_tiled(const GemmParams& p, hipStream_t stream) {
     const long grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
     static const char* const names[] = {"gemm_bias", "gemm_resid", "gemm_gate"};
     double ksum = 0;
-    for (int s = 0; s < p.nsrc; ++s) ksum += p.src[s].K;
+    int T = 0;
+    for (int s = 0; s < p.nsrc; ++s) { ksum += p.src[s].K; T += p.src[s].K / BK; }
     {
         DVQ_PROF(names[EPI], 2.0 * (double)p.M * p.N * ksum, ((double)p.M + p.N) * ksum * 4, stream);
-        if (dvq_knobs().gemm_dephase) DVQ_LAUNCH((gemm_f16x2_kernel<EPI, true>), dim3((unsigned)grid), dim3(512), SMEM, stream, p);
+        const int mode = dvq_knobs().gemm_dephase;          // DVQ_GEMM_DEPHASE: 2 (default) ping-pong, 1 two stages dephased, 0 two stages in lock step
+        if (mode == 2) DVQ_LAUNCH((gemm_f16x2_pp_kernel<EPI>), dim3((unsigned)grid), dim3(512), PP_SMEM, stream, p, T);
+        else if (mode == 1) DVQ_LAUNCH((gemm_f16x2_kernel<EPI, true>), dim3((unsigned)grid), dim3(512), SMEM, stream, p);
         else DVQ_LAUNCH((gemm_f16x2_kernel<EPI, false>), dim3((unsigned)grid), dim3(512), SMEM, stream, p);
     }
     DVQ_CHECK_LAUNCH("gemm_f16x2");

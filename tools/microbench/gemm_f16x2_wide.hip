@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#include <type_traits>
 #include "../../include/dvq.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -22,6 +23,7 @@ struct P {
     const uint16_t* Wp; long wp_plane; long ldw;
     int K, N; long M;
     const float* cs; const float* bias; float* out; long ldo;
+    unsigned long long* dbg;     // ABL 9: per-wave phase stamps (8 sums per wave)
 };
 
 constexpr int A_PL = 128 * 64, W_PL = 256 * 64, STAGE = 2 * A_PL + 2 * W_PL;   // 49 152 B
@@ -227,10 +229,230 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_wide(const P p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Ping-pong variant: the two waves of a SIMD (w and w + 4: rows 0..63 and 64..127 of the tile) alternate between a LOAD phase
+// (fragment reads of tile t, conversion + LDS write of its share of tile t + 2, LDS-DMA of tile t + 2, global loads of tile t + 3)
+// and a COMPUTE phase (48 MFMAs on the fragments in registers), one workgroup barrier per phase, waves 4..7 half a period behind.
+// Three LDS stages: what is issued in a load phase has two phases to land.
+constexpr int NSTAGE_PP = 3;
+template <int PRIO, int ABL>
+__global__ __launch_bounds__(512, 1) void gemm_f16x2_pp(const P p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int tiles_n = p.N / 256;
+    const long tiles_m = (p.M + 127) / 128;
+    const long b = blockIdx.x;
+    const long j = b >> 3;
+    const long mt = (j / tiles_n) * 8 + (b & 7);
+    const int nt = (int)(j % tiles_n);
+    if (mt >= tiles_m) return;
+    const long m0 = mt * 128;
+    const int n0 = nt * 256;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const float* a_ptr;
+    {
+        long m = m0 + (tid >> 2);
+        if (m >= p.M) m = p.M - 1;
+        a_ptr = p.A + m * p.lda + 8 * (tid & 3);
+    }
+    const int a_dst = (tid >> 2) * 64 + 16 * ((tid & 3) ^ swz<16>(tid >> 2));
+    const uint16_t* w_ptr[4];
+    int w_dst[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = wave * 4 + i;
+        const int pl = id >> 4, rb = id & 15;
+        const int row = rb * 16 + (lane >> 2);
+        w_ptr[i] = p.Wp + pl * p.wp_plane + (long)(n0 + row) * p.ldw + 8 * ((lane & 3) ^ swz<16>(row));
+        w_dst[i] = 2 * A_PL + pl * W_PL + rb * 1024;
+    }
+    const int T = p.K / BK;
+    f32x4 alo, ahi, blo, bhi;                               // ABL 4: a second register set, loads two periods ahead
+    auto load_a = [&](int t) {
+        alo = *reinterpret_cast<const f32x4*>(a_ptr + (long)t * BK);
+        ahi = *reinterpret_cast<const f32x4*>(a_ptr + (long)t * BK + 4);
+    };
+    auto load_b = [&](int t) {
+        blo = *reinterpret_cast<const f32x4*>(a_ptr + (long)t * BK);
+        bhi = *reinterpret_cast<const f32x4*>(a_ptr + (long)t * BK + 4);
+    };
+    auto store_a = [&](char* stage) {
+        h8 p1, p2;
+        split2(alo, ahi, p1, p2);
+        *reinterpret_cast<h8*>(stage + a_dst) = p1;
+        *reinterpret_cast<h8*>(stage + A_PL + a_dst) = p2;
+    };
+    auto store_b = [&](char* stage) {
+        h8 p1, p2;
+        split2(blo, bhi, p1, p2);
+        *reinterpret_cast<h8*>(stage + a_dst) = p1;
+        *reinterpret_cast<h8*>(stage + A_PL + a_dst) = p2;
+    };
+    auto issue_w = [&](char* stage, int t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr[i] + (long)t * BK),
+                                             (__attribute__((address_space(3))) void*)(stage + w_dst[i]), 16, 0, 0);
+    };
+    // ABL 3: weight planes through registers (global_load one period ahead, ds_write_b128 in the next load phase)
+    uint4 wreg[4];
+    auto load_w = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wreg[i] = *reinterpret_cast<const uint4*>(w_ptr[i] + (long)t * BK);
+    };
+    auto store_w = [&](char* stage) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(stage + w_dst[i] + 16 * lane) = wreg[i];
+    };
+    // prologue: tiles 0 and 1 staged, tile 2's activations in registers
+    load_a(0);
+    issue_w(smem, 0);
+    store_a(smem);
+    if (T > 1) { load_a(1); issue_w(smem + STAGE, 1); store_a(smem + STAGE); }
+    if (T > 2) load_a(2);
+    if (ABL == 4 && T > 3) load_b(3);
+    if (ABL == 3 && T > 2) load_w(2);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    f32x4 hi[4][4], lo[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { hi[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int lr = lane & 15, lc = lane >> 4;
+    const int rd = lr * 64 + 16 * (lc ^ swz<16>(lr));
+    unsigned long long clk0 = 0, rt0 = 0;
+    if (ABL == 9) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+    if (wave >= 4) __builtin_amdgcn_s_barrier();           // the second half runs half a period behind
+    unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto phase = [&](int t, auto setc) {
+        constexpr int SET = decltype(setc)::value;
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, t7 = 0;
+        if (ABL == 9) t0 = __builtin_amdgcn_s_memtime();
+        // ---- load phase
+        const char* st = smem + (t % NSTAGE_PP) * STAGE;
+        h8 af[4][2], wf[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                af[i][pl] = *reinterpret_cast<const h8*>(st + pl * A_PL + (wm * 64 + i * 16) * 64 + rd);
+                wf[i][pl] = *reinterpret_cast<const h8*>(st + 2 * A_PL + pl * W_PL + (wn * 64 + i * 16) * 64 + rd);
+            }
+        if (ABL == 9) { __builtin_amdgcn_sched_barrier(0); t1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+        if (t + 2 < T) {
+            char* nx = smem + ((t + 2) % NSTAGE_PP) * STAGE;
+            if (ABL == 9) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+            if (ABL == 4) { if (SET) store_b(nx); else store_a(nx); }
+            else if (ABL != 2 && ABL != 5) store_a(nx);     // tile t + 2, loaded a period ago
+            if (ABL == 9) { __builtin_amdgcn_sched_barrier(0); t3 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+            if (ABL == 3) store_w(nx);
+            else if (ABL != 1) issue_w(nx, t + 2);
+            if (ABL == 4) { if (t + 4 < T) { if (SET) load_b(t + 4); else load_a(t + 4); } }
+            else if (ABL == 5) { if (t + 3 < T) { if (SET) load_a(t + 3); else load_b(t + 3); } }      // the set that is NOT converted in this period
+            else if (t + 3 < T) { if (ABL != 2) load_a(t + 3); if (ABL == 3) load_w(t + 3); }
+        }
+        if (ABL == 9) { __builtin_amdgcn_sched_barrier(0); t4 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers before the phase ends
+        if (ABL == 9) { t5 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+        __builtin_amdgcn_s_barrier();
+        if (ABL == 9) { t6 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+        // ---- compute phase
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        if (ABL == 5) {                                     // conversion of tile t + 2 (loaded a period ago) in the MFMA shadow; past the
+                                                            // last tile it rewrites a stage nobody reads (no branch: one scheduling region)
+            char* nx = smem + ((t + 2) % NSTAGE_PP) * STAGE;
+            if (SET) store_b(nx); else store_a(nx);
+        }
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hi[jn][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[jn][0], af[i][0], hi[jn][i], 0, 0, 0);
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lo[jn][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[jn][1], af[i][0], lo[jn][i], 0, 0, 0);
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lo[jn][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[jn][0], af[i][1], lo[jn][i], 0, 0, 0);
+        if (ABL == 5) {
+#pragma unroll
+            for (int q = 0; q < 20; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);     // two vector instructions of the split
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);         // the two LDS writes
+            __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (ABL == 9) { __builtin_amdgcn_sched_barrier(0); t7 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+        __builtin_amdgcn_s_barrier();
+        if (ABL == 9 && t + 3 < T && t >= 2) {
+            const unsigned long long t8 = __builtin_amdgcn_s_memtime();
+            acc_t[0] += t1 - t0; acc_t[1] += t2 - t1; acc_t[2] += t3 - t2; acc_t[3] += t4 - t3; acc_t[4] += t5 - t4; acc_t[5] += t6 - t5;
+            acc_t[6] += t7 - t6; acc_t[7] += t8 - t7;
+        }
+    };
+    for (int t = 0; t < T; t += 2) {
+        phase(t, std::integral_constant<int, 0>{});
+        if (t + 1 < T) phase(t + 1, std::integral_constant<int, 1>{});
+    }
+    if (wave < 4) __builtin_amdgcn_s_barrier();            // pairs with the late half's extra barrier
+    if (ABL == 9 && lane == 0 && blockIdx.x < 64) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) p.dbg[((long)blockIdx.x * 8 + wave) * 8 + q] = acc_t[q];
+        p.dbg[4096 + ((long)blockIdx.x * 8 + wave) * 2] = __builtin_amdgcn_s_memtime() - clk0;
+        p.dbg[4096 + ((long)blockIdx.x * 8 + wave) * 2 + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long m = m0 + wm * 64 + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) {
+            const int n = n0 + wn * 64 + jn * 16 + 4 * (lane >> 4);
+            f32x4 v = hi[jn][i] + lo[jn][i] * (1.0f / 2048.0f);
+            v *= *reinterpret_cast<const f32x4*>(p.cs + n);
+            v += *reinterpret_cast<const f32x4*>(p.bias + n);
+            *reinterpret_cast<f32x4*>(p.out + m * p.ldo + n) = v;
+        }
+    }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 static double frand() { return (double)rand() / RAND_MAX; }
 static double nrand() { return sqrt(-2.0 * log(frand() + 1e-12)) * cos(6.283185307179586 * frand()); }
+
+template <int PRIO, int ABL>
+static double run_pp(const P& p, int iters, const float* const* Abufs, int nbuf) {
+    const int smem_b = NSTAGE_PP * STAGE;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_pp<PRIO, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_b));
+    const long tiles_m = (p.M + 127) / 128, tiles_n = p.N / 256;
+    const long grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    P q = p;
+    for (int i = 0; i < 5; ++i) { q.A = Abufs[i % nbuf]; hipLaunchKernelGGL((gemm_f16x2_pp<PRIO, ABL>), dim3((unsigned)grid), dim3(512), smem_b, 0, q); }
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) { q.A = Abufs[i % nbuf]; hipLaunchKernelGGL((gemm_f16x2_pp<PRIO, ABL>), dim3((unsigned)grid), dim3(512), smem_b, 0, q); }
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    q.A = Abufs[0];
+    hipLaunchKernelGGL((gemm_f16x2_pp<PRIO, ABL>), dim3((unsigned)grid), dim3(512), smem_b, 0, q);
+    CK(hipDeviceSynchronize());
+    return ms * 1e3 / iters;
+}
 
 template <int SHAPE, bool DEPHASE>
 static double run(const P& p, int iters, const float* const* Abufs, int nbuf) {
@@ -263,7 +485,9 @@ int main(int argc, char** argv) {
     if (!lin) printf("(no libdvq_hip.so: bf16x3 baseline skipped)\n");
     const long M = 16384;
     const int shapes[3][2] = {{1024, 1536}, {512, 2560}, {512, 1024}};
+    const int only = argc > 2 ? atoi(argv[2]) : -1;             // shape filter (PMC runs)
     for (int si = 0; si < 3; ++si) {
+        if (only >= 0 && si != only) continue;
         const int N = shapes[si][0], K = shapes[si][1];
         srand(1234 + si);
         std::vector<float> hA((size_t)M * K), hW((size_t)N * K), hb(N), hcs(N);
@@ -296,7 +520,8 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&dp, hp.size() * 2)); CK(hipMemcpy(dp, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
         CK(hipMalloc(&dp3, (size_t)3 * N * K * 2));
         CK(hipMalloc(&dout, (size_t)M * N * 4)); CK(hipMalloc(&dout2, (size_t)M * N * 4));
-        P p{dA[0], K, dp, (long)N * K, K, K, N, M, dcs, db, dout, N};
+        unsigned long long* ddbg; CK(hipMalloc(&ddbg, 8192 * 8)); CK(hipMemset(ddbg, 0, 8192 * 8));
+        P p{dA[0], K, dp, (long)N * K, K, K, N, M, dcs, db, dout, N, ddbg};
         const double flop = 2.0 * M * N * K;
         std::vector<float> hout((size_t)M * N);
         auto check = [&](const char* name, float* dev) {
@@ -317,6 +542,34 @@ int main(int argc, char** argv) {
         double us;
         us = run<16, false>(p, 40, dA, nbuf); printf("  f16x2 16x16x32          : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("16x16x32", dout);
         us = run<16, true>(p, 40, dA, nbuf);  printf("  f16x2 16x16x32 dephased : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("16x16x32 dephased", dout);
+        us = run_pp<0, 0>(p, 40, dA, nbuf); printf("  f16x2 ping-pong         : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("ping-pong", dout);
+        us = run_pp<1, 0>(p, 40, dA, nbuf); printf("  f16x2 ping-pong setprio : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("ping-pong setprio", dout);
+        us = run_pp<1, 5>(p, 40, dA, nbuf); printf("  f16x2 pp setprio, split in the compute phase : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("pp split in C", dout);
+        us = run_pp<0, 5>(p, 40, dA, nbuf); printf("  f16x2 pp (no setprio), split in the compute phase : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("pp split in C", dout);
+        us = run_pp<1, 4>(p, 40, dA, nbuf); printf("  f16x2 pp setprio, activations two periods ahead : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("pp A x2", dout);
+        us = run_pp<1, 0>(p, 40, dA, 1); printf("  f16x2 pp setprio, ONE activation buffer (cache-resident) : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6);
+        {
+            us = run_pp<1, 9>(p, 10, dA, nbuf); printf("  (stamped) pp setprio : %7.1f us\n", us);
+            std::vector<unsigned long long> h(8192);
+            CK(hipMemcpy(h.data(), ddbg, h.size() * 8, hipMemcpyDeviceToHost));
+            const char* nm[8] = {"frag read issue", "wait vmcnt(0) (A loads, W DMA of last period)", "split + ds_write A", "DMA issue + A loads", "wait lgkmcnt(0)", "barrier L->C", "compute (48 MFMA)", "barrier C->L"};
+            {
+                double c = 0, r = 0; for (int i = 0; i < 512; ++i) { c += (double)h[4096 + 2 * i]; r += (double)h[4096 + 2 * i + 1]; }
+                printf("    main loop: %.0f shader cycles in %.2f us per wave -> in-kernel clock %.0f MHz\n", c / 512, r / 512 * 0.01, c / r * 100.0);
+            }
+            const int steps = K / 32 - 5;
+            for (int half = 0; half < 2; ++half) {
+                printf("    waves %d..%d, cycles per K-tile:", 4 * half, 4 * half + 3);
+                double tot = 0;
+                for (int q = 0; q < 8; ++q) {
+                    double sum = 0; for (int b = 0; b < 64; ++b) for (int w = 4 * half; w < 4 * half + 4; ++w) sum += (double)h[(b * 8 + w) * 8 + q];
+                    printf(" [%s %.0f]", nm[q], sum / (64 * 4) / steps); tot += sum / (64 * 4) / steps;
+                }
+                printf(" total %.0f\n", tot);
+            }
+        }
+        us = run_pp<1, 1>(p, 40, dA, nbuf); printf("  (timing only) pp setprio, no weight DMA : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6);
+        us = run_pp<1, 2>(p, 40, dA, nbuf); printf("  (timing only) pp setprio, no activation path : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6);
         us = run<32, false>(p, 40, dA, nbuf); printf("  f16x2 32x32x16          : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("32x32x16", dout);
         us = run<32, true>(p, 40, dA, nbuf);  printf("  f16x2 32x32x16 dephased : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("32x32x16 dephased", dout);
         if (lin) {
