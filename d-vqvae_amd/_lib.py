@@ -114,6 +114,7 @@ SIGNATURES = {
     "dvq_prof_read": (C.c_int, [C.POINTER(ProfEntry), C.c_int]),
     "dvq_transform_cloud": (C.c_int, [c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, C.c_int, C.c_int, c_f32p, c_stream]),
     "dvq_exp1_noise": (C.c_int, [C.c_uint64, C.c_uint32, C.c_int64, C.c_int64, C.c_int, c_f32p, c_stream]),
+    "dvq_exp1_noise_rows": (C.c_int, [C.c_uint64, C.c_uint32, C.c_int64, c_i64p, C.c_int64, C.c_int, c_f32p, c_stream]),
     "dvq_probe_f16_subnormal": (C.c_int, [c_f32p, c_stream]),
     "dvq_nn_points": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int64, c_f32p, C.c_int64, C.c_int64, C.c_int64,
                                 C.c_int64, C.c_int, C.c_int, c_f32p, c_i64p, c_stream]),

@@ -109,12 +109,15 @@ __device__ __forceinline__ f32x4 f16x2_combine(const f32x4& hi, const f32x4& lo,
     return v;
 }
 
+// ReLU that keeps a NaN (torch.relu does; fmaxf would turn the NaN of an out-of-range row into 0 and hide it from gen()'s check)
+__device__ __forceinline__ float relu_nan(float x) { return x < 0.f ? 0.f : x; }
+
 template <int EPI>
 __device__ __forceinline__ void f16x2_store_block(const GemmParams& p, long m, int n, f32x4 v, bool full) {
     if (full) {
         if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
         if constexpr (EPI == EPI_RESID) v += *reinterpret_cast<const f32x4*>(p.resid + m * p.ldr + n);
-        if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (p.relu) { v[0] = relu_nan(v[0]); v[1] = relu_nan(v[1]); v[2] = relu_nan(v[2]); v[3] = relu_nan(v[3]); }
         *reinterpret_cast<f32x4*>(p.out + m * p.ldo + n) = v;
     } else {
 #pragma unroll
@@ -122,7 +125,7 @@ __device__ __forceinline__ void f16x2_store_block(const GemmParams& p, long m, i
             if (n + c >= p.N) continue;
             float x = v[c] * p.wscale[n + c] + (p.bias ? p.bias[n + c] : 0.f);
             if constexpr (EPI == EPI_RESID) x += p.resid[m * p.ldr + n + c];
-            if (p.relu) x = fmaxf(x, 0.f);
+            if (p.relu) x = relu_nan(x);
             p.out[m * p.ldo + n + c] = x;
         }
     }

@@ -148,7 +148,7 @@ __global__ void gather_rows_kernel(const float* __restrict__ table, const int64_
     if (k >= 0 && k < K) {
         v = *reinterpret_cast<const f32x4*>(table + k * D + c4 * 4);
     } else if (c4 == 0 && err_flag) {
-        *err_flag = 1;
+        atomicOr(err_flag, 1);
     }
     *reinterpret_cast<f32x4*>(out + m * ldo + c4 * 4) = v;
 }
@@ -221,13 +221,15 @@ __device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, uns
 
 // out[r, 4q..4q+3] = -log(u), u = (24 random bits + 0.5) 2^-24 in (0, 1): Exp(1) variates that depend only on
 // (seed, stream, GLOBAL row row0 + r, column), not on how the rows are split into calls, batches or ranks
-__global__ void exp1_noise_kernel(unsigned long long seed, unsigned stream_id, long row0, long rows, int cols, float* __restrict__ out) {
+// `perm` (optional): output row r holds the draws of global row row0 + perm[r] (the prior is evaluated in label order)
+__global__ void exp1_noise_kernel(unsigned long long seed, unsigned stream_id, long row0, long rows, int cols, float* __restrict__ out,
+                                  const int64_t* __restrict__ perm) {
     const int quads = cols / 4;
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long r = gid / quads;
     const int q = (int)(gid % quads);
     if (r >= rows) return;
-    const unsigned long long grow = (unsigned long long)(row0 + r);
+    const unsigned long long grow = (unsigned long long)(row0 + (perm ? (long)perm[r] : r));
     unsigned c[4] = {(unsigned)q, (unsigned)grow, (unsigned)(grow >> 32), stream_id};
     philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
     f32x4 v;
@@ -324,6 +326,11 @@ extern "C" int dvq_transform_cloud(const float* pc, int64_t pc_batch_stride, con
 }
 
 extern "C" int dvq_exp1_noise(uint64_t seed, uint32_t stream_id, int64_t row0, int64_t rows, int cols, float* out, dvq_stream_t stream) {
+    return dvq_exp1_noise_rows(seed, stream_id, row0, nullptr, rows, cols, out, stream);
+}
+
+extern "C" int dvq_exp1_noise_rows(uint64_t seed, uint32_t stream_id, int64_t row0, const int64_t* perm, int64_t rows, int cols, float* out,
+                                   dvq_stream_t stream) {
     DVQ_REQUIRE(rows >= 0 && cols > 0 && cols % 4 == 0 && row0 >= 0, "exp1_noise: bad shape rows=%ld cols=%d row0=%ld", (long)rows, cols, (long)row0);
     if (rows == 0) return DVQ_OK;
     DVQ_REQUIRE(out && dvq_aligned16(out), "exp1_noise: null/unaligned output");
@@ -332,7 +339,7 @@ extern "C" int dvq_exp1_noise(uint64_t seed, uint32_t stream_id, int64_t row0, i
     {
         DVQ_PROF("exp1_noise", 0, (double)rows * cols * 4, (hipStream_t)stream);
         DVQ_LAUNCH(exp1_noise_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                   (unsigned long long)seed, (unsigned)stream_id, (long)row0, (long)rows, cols, out);
+                   (unsigned long long)seed, (unsigned)stream_id, (long)row0, (long)rows, cols, out, perm);
     }
     DVQ_CHECK_LAUNCH("exp1_noise");
     return DVQ_OK;

@@ -22,7 +22,7 @@ __global__ void sanitize_labels_kernel(const int64_t* __restrict__ label, long B
     if (b >= B) return;
     int64_t l = label[b];
     if (l < 0 || l >= n_classes) {
-        if (err_flag) *err_flag = 1;
+        if (err_flag) atomicOr(err_flag, 1);
         l = 0;
     }
     out[b] = l;
@@ -66,7 +66,7 @@ __global__ void sample_kernel(const float* __restrict__ logits, const float* __r
     if (forced) {
         code = forced[b * NPOS + pos];
         if (code < 0 || code >= n_in) {
-            if (lane == 0 && err_flag) *err_flag = 1;
+            if (lane == 0 && err_flag) atomicOr(err_flag, 1);
             code = 0;
         }
     } else {
@@ -92,7 +92,10 @@ __global__ void sample_kernel(const float* __restrict__ logits, const float* __r
             const int oi = __shfl_xor(bi, o);
             if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
         }
-        if (bi == 0x7fffffff) bi = 0;      // all scores NaN: torch.argmax would return the first NaN; keep 0
+        if (bi == 0x7fffffff) {            // all scores NaN: torch.argmax would return the first NaN; keep 0 -- and say so (bit 2 of the
+            bi = 0;                        // flag: non-finite logits, e.g. an activation beyond the fp16 range of the default GEMM
+            if (lane == 0 && err_flag) atomicOr(err_flag, 4);       // arithmetic; the host mirror generates the batch again on the bf16 split)
+        }
         code = bi;
         if (lane == 0) codes[b * NPOS + pos] = code;
     }

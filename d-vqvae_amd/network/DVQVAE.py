@@ -29,7 +29,7 @@ class _MLP(nn.Module):
     def _planes(self, lin):
         """weight image of a Linear (packing.split_planes), rebuilt when the parameter is replaced, moved or edited in place"""
         w = lin.weight
-        key = (w.data_ptr(), w._version, str(w.device))
+        key = (w.data_ptr(), w._version, str(w.device), packing.gemm_kind())
         cache = self.__dict__.setdefault("_plane_cache", {})
         hit = cache.get(id(lin))
         if hit is None or hit[0] != key:

@@ -7,7 +7,7 @@ import os
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import _lib, ops, packing
 from .DVQVAE import Decoder, _codebooks
 from .pixelcnn.models import GatedPixelCNN
 from .pointnet_encoder import PointNetEncoder
@@ -33,6 +33,7 @@ class GenNet(nn.Module):
         #                              None: torch.initial_seed(), i.e. torch.manual_seed governs the draws as it does the reference's
         self._noise_stream = 0       # one Philox stream per gen() call unless the caller names it
         self.sort_by_label = os.environ.get("DVQ_SORT_LABELS", "1") != "0"   # prior evaluated in label order (gather locality)
+        self.range_fallbacks = 0     # gen() calls re-run on the bf16 split because an activation left fp16's range
 
     def set_noise_seed(self, seed, first_stream=0):
         """Seed of the prior's sampling noise; every gen() call without explicit ``noise`` / ``stream_id`` uses the next stream."""
@@ -66,20 +67,26 @@ class GenNet(nn.Module):
             ops.vq_lookup(E, flat[:, i * 3 + j], out=z_out[:, 256 * k: 256 * (k + 1)], err=err)
         return self.decoder(z_out).view(B, 55)
 
-    def _draw_noise(self, B, dev, seed, row0, stream_id, out=None):
-        """[B, 9, prior_tokens] Exp(1) variates of the device Philox generator under gen()'s key rules."""
-        n_in = self.GatedPixelCNN.packed().n_in
+    def _noise_key(self, seed, row0, stream_id):
+        """(seed, first global row, stream) of the device Philox generator under gen()'s key rules."""
         if stream_id is None:
             stream_id = self._noise_stream
             self._noise_stream += 1
         dseed, drow = ops.default_noise_key()
         if seed is None:
             seed = dseed if self.noise_seed is None else self.noise_seed
-        flat = out.view(B, 9 * n_in) if out is not None else None
-        return ops.exp1_noise(B, 9 * n_in, seed, drow if row0 is None else row0, stream_id, device=dev, out=flat).view(B, 9, n_in)
+        return seed, (drow if row0 is None else row0), stream_id
 
-    def _gen_impl(self, obj, noise):
-        """The device work of gen(): no host synchronisation inside (gen() checks the error flag once at the end)."""
+    def _draw_noise(self, B, dev, key, perm=None):
+        """[B, 9, prior_tokens] Exp(1) variates; with ``perm``, row r holds the draws of batch row perm[r]."""
+        n_in = self.GatedPixelCNN.packed().n_in
+        seed, row0, stream_id = key
+        return ops.exp1_noise(B, 9 * n_in, seed, row0, stream_id, device=dev, perm=perm).view(B, 9, n_in)
+
+    def _gen_impl(self, obj, noise, key=None):
+        """The device work of gen(): no host synchronisation inside (gen() checks the error flag once at the end).
+        ``noise`` None: the prior's draws come from the device generator under ``key``, drawn directly in the order the prior
+        is evaluated in (no gather of the [B, 9, tokens] tensor)."""
         if obj.dim() != 3:
             raise RuntimeError(f"gen: expected obj [B,4,N], got {tuple(obj.shape)}")
         B, dev = obj.shape[0], obj.device
@@ -99,10 +106,13 @@ class GenNet(nn.Module):
         # Rows are independent, so the order changes no result; the codes are scattered back.
         if B >= 512 and self.sort_by_label:
             order = torch.argsort(label, stable=True)
-            codes_s = ops.pixelcnn_sample(pk, label[order].contiguous(), noise.index_select(0, order), err=err)   # :92
+            noise_s = self._draw_noise(B, dev, key, perm=order) if noise is None else noise.index_select(0, order)
+            codes_s = ops.pixelcnn_sample(pk, label[order].contiguous(), noise_s, err=err)   # :92
             codes = torch.empty_like(codes_s)
             codes[order] = codes_s
         else:
+            if noise is None:
+                noise = self._draw_noise(B, dev, key)
             codes = ops.pixelcnn_sample(pk, label, noise.contiguous(), err=err)   # :92
         recon = self._decode(codes, {"z_out": z_out}, None, err)           # :95-113
         verts = self._hand_vertices(recon)                                 # :116-118
@@ -124,11 +134,21 @@ class GenNet(nn.Module):
         (ops.default_noise_key), so ranks that name nothing never share noise."""
         if obj.dim() != 3:
             raise RuntimeError(f"gen: expected obj [B,4,N], got {tuple(obj.shape)}")
-        if noise is None:
-            noise = self._draw_noise(obj.shape[0], obj.device, seed, row0, stream_id)
-        recon, recon_pos, aux, err = self._gen_impl(obj, noise)
-        if int(err.item()) != 0:
+        key = self._noise_key(seed, row0, stream_id) if noise is None else None
+        recon, recon_pos, aux, err = self._gen_impl(obj, noise, key)
+        # one host synchronisation per call: the index-range flag and "every parameter is finite"
+        status = int((err + 2 * (~(torch.isfinite(recon).all() & torch.isfinite(recon_pos).all())).to(torch.int32)).item())
+        if status & 1:
             raise RuntimeError(self._RANGE_ERROR)
+        if (status & 6) and packing.gemm_kind() == _lib.PLANES_F16X2:     # non-finite parameters, or a draw from all-NaN logits (bit 2)
+            # The default GEMM arithmetic splits activations into fp16 pieces: a value beyond fp16's range (|x| >= 65 520) turns its
+            # row into NaN -- never a silently wrong number.  Such a batch is generated again on the six-product bf16 split, which
+            # has fp32's range (csrc/gemm_f16x2.hip); NaN / Inf INPUTS come out non-finite there too, as in the reference.
+            self.range_fallbacks += 1
+            with packing.gemm_kind_as(_lib.PLANES_BF16X3):
+                recon, recon_pos, aux, err = self._gen_impl(obj, noise, key)
+                if int(err.item()) & 1:
+                    raise RuntimeError(self._RANGE_ERROR)
         return (recon, recon_pos, aux) if return_aux else (recon, recon_pos)
 
     @torch.no_grad()

@@ -268,14 +268,16 @@ def vq_lookup(E: Tensor, idx: Tensor, out: Optional[Tensor] = None, err: Optiona
 
 
 # ------------------------------------------------------------------------------------------ sampling noise
-def exp1_noise(rows: int, cols: int, seed: int, row0: int = 0, stream_id: int = 0, device=None, out: Optional[Tensor] = None) -> Tensor:
+def exp1_noise(rows: int, cols: int, seed: int, row0: int = 0, stream_id: int = 0, device=None, out: Optional[Tensor] = None,
+               perm: Optional[Tensor] = None) -> Tensor:
     """[rows, cols] Exp(1) variates from the device Philox generator, keyed by (seed, stream_id, GLOBAL row row0 + r, column):
-    a shard of a batch (row0 = its first row) draws exactly the rows the whole batch would draw (dvq_exp1_noise)."""
+    a shard of a batch (row0 = its first row) draws exactly the rows the whole batch would draw (dvq_exp1_noise).
+    ``perm`` (int64 [rows] on the device): row r of the result holds the draws of global row row0 + perm[r]."""
     lib = _lib.load()
     if cols % 4 != 0:                                     # the generator writes 16-byte quads: draw a padded row, keep the columns asked for
         if device is None and out is not None:
             device = out.device
-        wide = exp1_noise(rows, (cols + 3) // 4 * 4, seed, row0, stream_id, device=device)
+        wide = exp1_noise(rows, (cols + 3) // 4 * 4, seed, row0, stream_id, device=device, perm=perm)
         if out is None:
             return wide[:, :cols].contiguous()
         out.copy_(wide[:, :cols])
@@ -287,9 +289,11 @@ def exp1_noise(rows: int, cols: int, seed: int, row0: int = 0, stream_id: int = 
     dev = _require_gpu(out)
     if tuple(out.shape) != (rows, cols) or not out.is_contiguous() or out.dtype != torch.float32:
         raise RuntimeError("exp1_noise: `out` must be a contiguous float32 [rows, cols] tensor")
+    if perm is not None and (perm.dtype != torch.int64 or perm.numel() != rows or not perm.is_contiguous() or perm.device != out.device):
+        raise RuntimeError("exp1_noise: `perm` must be a contiguous int64 [rows] tensor on the output's device")
     with torch.cuda.device(dev):
-        check(lib.dvq_exp1_noise(int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_id) & 0xFFFFFFFF, int(row0), rows, cols, out.data_ptr(),
-                                 _stream(dev)), "dvq_exp1_noise")
+        check(lib.dvq_exp1_noise_rows(int(seed) & 0xFFFFFFFFFFFFFFFF, int(stream_id) & 0xFFFFFFFF, int(row0),
+                                      perm.data_ptr() if perm is not None else None, rows, cols, out.data_ptr(), _stream(dev)), "dvq_exp1_noise")
     return out
 
 
@@ -339,7 +343,7 @@ def pointnet_encode(packed, pc: Tensor, out: Optional[Tensor] = None, want_trans
 
 
 # ------------------------------------------------------------------------------------------ PixelCNN
-def pixelcnn_sample(packed, label: Tensor, noise: Tensor, return_logits: bool = False, err: Optional[Tensor] = None):
+def pixelcnn_sample(packed, label: Tensor, noise: Tensor, return_logits: bool = False, err: Optional[Tensor] = None, _retry: bool = False):
     """label [B] int64, noise [B,9,n_in] Exp(1) -> codes [B,3,3] int64 (+ logits [B,9,n_in])."""
     lib = _lib.load()
     dev = _require_gpu(label, noise, err)
@@ -361,8 +365,16 @@ def pixelcnn_sample(packed, label: Tensor, noise: Tensor, return_logits: bool = 
         check(lib.dvq_pixelcnn_sample(C.byref(packed.cstruct), label.data_ptr(), noise.data_ptr(), B, codes.data_ptr(),
                                       logits.data_ptr() if return_logits else None, err.data_ptr(), ws.data_ptr(),
                                       ws.numel(), _stream(dev)), "dvq_pixelcnn_sample")
-    if own_err and int(err.item()) != 0:
-        raise RuntimeError(f"label out of range for the prior's {packed.n_classes} classes")
+    if own_err:
+        e = int(err.item())
+        if e & 1:
+            raise RuntimeError(f"label out of range for the prior's {packed.n_classes} classes")
+        if (e & 4) and packed.kind == _lib.PLANES_F16X2 and not _retry:
+            # non-finite logits under the fp16 weight images: an activation left fp16's range (or the input is not finite): once
+            # more on the six-product bf16 split, which has fp32's range; the images return to the default kind at the next use
+            from . import packing
+            with packing.gemm_kind_as(_lib.PLANES_BF16X3):
+                return pixelcnn_sample(packed, label, noise, return_logits=return_logits, _retry=True)
     return (codes, logits) if return_logits else codes
 
 
@@ -384,7 +396,7 @@ def pixelcnn_forward(packed, x: Tensor, label: Tensor) -> Tensor:
     with torch.cuda.device(dev):
         check(lib.dvq_pixelcnn_forward(C.byref(packed.cstruct), x.data_ptr(), label.data_ptr(), B, logits.data_ptr(),
                                        err.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)), "dvq_pixelcnn_forward")
-    if int(err.item()) != 0:
+    if int(err.item()) & 1:
         raise RuntimeError("index out of range in self (token or class label)")
     return logits.view(B, 3, 3, packed.n_in).permute(0, 3, 1, 2)
 

@@ -47,11 +47,32 @@ def split_bf16x3(w: Tensor) -> Tensor:
     return out
 
 
+_KIND_OVERRIDE: list = []
+
+
+class gemm_kind_as:
+    """``with gemm_kind_as(_lib.PLANES_BF16X3): ...`` -- weight images are (re)built in the given kind inside the block
+    (GenNet.gen's range fallback); the images of the surrounding kind are rebuilt at the next use after it."""
+
+    def __init__(self, kind: int):
+        self.kind = kind
+
+    def __enter__(self):
+        _KIND_OVERRIDE.append(self.kind)
+        return self
+
+    def __exit__(self, *exc):
+        _KIND_OVERRIDE.pop()
+        return False
+
+
 def gemm_kind() -> int:
     """Which weight image the GEMM weights are packed into: the fp16 three-product split (default, DVQ_GEMM unset or
     "f16x2"), or the exact three-plane bf16 split with DVQ_GEMM=bf16x3 (and with DVQ_GEMM=fp32, where the library ignores
     the images and runs the fp32 matrix-core kernel)."""
     import os
+    if _KIND_OVERRIDE:
+        return _KIND_OVERRIDE[-1]
     v = os.environ.get("DVQ_GEMM", "").strip().lower()
     if v in ("", "f16x2"):
         return _lib.PLANES_F16X2
@@ -129,7 +150,7 @@ class _Packed:
         device = torch.device(device)
         if device.type == "cuda" and device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
-        if self.device == device:
+        if self.device == device and getattr(self, "kind", None) == self._kind():
             return self
         self.tensors = {k: (v.to(device) if v.dtype == torch.int16 else _dev(v, device)) for k, v in self.tensors.items()
                         if not k.endswith(("__planes", "__filter", "__scale"))}

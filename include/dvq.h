@@ -211,7 +211,9 @@ typedef struct {
 
 size_t dvq_pixelcnn_workspace_bytes(const dvq_pixelcnn_weights* w_host, int64_t B);
 /* label [B] int64 in [0,n_classes), noise q [B,9,n_in] -> codes [B,9] int64 (raster order).
- * logits_out (optional) [B,9,n_in] receives the logits each draw was made from. */
+ * logits_out (optional) [B,9,n_in] receives the logits each draw was made from.
+ * *err_flag (device int32, caller zeroes it): bit 0 = a label / token out of range; bit 2 = a draw from logits that were all NaN
+ * (the code is 0 then): with fp16 weight images, an activation beyond +-65 504 -- run the call again with bf16x3 images. */
 int dvq_pixelcnn_sample(const dvq_pixelcnn_weights* w_host, const int64_t* label, const float* noise,
                         int64_t B, int64_t* codes, float* logits_out, int32_t* err_flag,
                         void* workspace, size_t workspace_bytes, dvq_stream_t stream);
@@ -270,6 +272,11 @@ int dvq_transform_cloud(const float* pc /* [C,N] or [B,C,N] */, int64_t pc_batch
  * unsharded batch draws.  `stream_id` separates independent uses (objects, calls).  cols % 4 == 0. */
 int dvq_exp1_noise(uint64_t seed, uint32_t stream_id, int64_t row0, int64_t rows, int cols, float* out /* [rows,cols] */,
                    dvq_stream_t stream);
+/* The same draws in another row order: out[r, :] = the noise of global row row0 + perm[r] (perm: device int64 [rows], values in
+ * [0, rows)).  GenNet.gen evaluates the prior in the order of the object codes; drawing the noise in that order replaces a
+ * gather of the whole [B, 9 * 512] tensor. */
+int dvq_exp1_noise_rows(uint64_t seed, uint32_t stream_id, int64_t row0, const int64_t* perm, int64_t rows, int cols,
+                        float* out /* [rows,cols] */, dvq_stream_t stream);
 
 /* Self-test: out[0] (device) = an fp16 MFMA product with a SUBNORMAL input, out[1] = its exact value.  The fast VQ kernel's
  * error bound assumes the matrix core keeps fp16 subnormals (measured so on gfx950); tests assert out[0] == out[1]. */

@@ -251,11 +251,27 @@ def gen(sd: SD, obj: Tensor, q: Tensor, mano, return_aux: bool = False):
     if return_aux:
         E6 = sd["vqvae6.vector_quantization.embedding.weight"].double()
         d64 = (feat_type.double() ** 2).sum(1, keepdim=True) + (E6 ** 2).sum(1) - 2 * feat_type.double() @ E6.t()
-        top2 = torch.topk(d64, 2, dim=1, largest=False)[0]
+        top2, top2_k = torch.topk(d64, 2, dim=1, largest=False)
         return recon, recon_pos, dict(feat_type=feat_type, feat_pos=feat_pos, idx6=idx6, codes=codes,
                                       verts=verts, hand_feat=hand_feat, race_gap=race_gap,
-                                      idx6_gap=(top2[:, 1] - top2[:, 0]).float())
+                                      idx6_gap=(top2[:, 1] - top2[:, 0]).float(),
+                                      idx6_top2_spread=(E6[top2_k[:, 0]] - E6[top2_k[:, 1]]).norm(dim=1),   # |e_1 - e_2| (fp64)
+                                      idx6_emax=float(E6.norm(dim=1).max()))
     return recon, recon_pos
+
+
+def object_code_margin(aux, feat_type_other: Tensor) -> Tensor:
+    """Per grasp, how large the fp64 top-2 distance gap of the object code must be before two fp32 evaluations of the path can
+    be REQUIRED to agree on the argmin -- derived from what actually differs between them, not a round number:
+      * the other path's PointNet feature differs from this one's by delta (measured, row by row): the two distances move
+        apart by at most 2 |delta| |e_1 - e_2| (d_k = |z|^2 + |e_k|^2 - 2 z.e_k; |z|^2 cancels in the difference);
+      * each fp32 distance is three 1024-term sums evaluated in some order: 32 ulps of (|z|^2 + |e|^2) covers both sides
+        (observed: a few ulps).
+    ``feat_type_other`` = the feature the path under test computed for the same clouds."""
+    z = aux["feat_type"].double()
+    delta = (feat_type_other.double().cpu() - z).norm(dim=1)
+    fp32 = 32 * 2.0 ** -24 * ((z ** 2).sum(1) + aux["idx6_emax"] ** 2)
+    return (2.0 * delta * aux["idx6_top2_spread"] + fp32).float()
 
 
 def assemble61(recon: Tensor, recon_pos: Tensor) -> Tensor:

@@ -53,3 +53,50 @@ def test_kernels_are_built_without_the_slp_vectorizer():
     assert r.returncode == 0, r.stderr[-2000:]
     bad = [ln for ln in r.stdout.splitlines() if any(op in ln for op in ("v_pk_mul_f32", "v_pk_fma_f32", "v_pk_mov_b32", "v_pk_add_f32"))]
     assert not bad, f"packed-fp32 instructions in pointnet_filter.hip: {bad[:3]}"
+
+
+def test_no_packed_fp32_instructions_outside_the_gemm_epilogues():
+    """Same fault, whole library: every kernel of the built libdvq_hip.so is disassembled (the gfx950 code objects of its fat
+    binary) and searched for packed-fp32 multiply / fma / add / move.  Allowed only in the GEMM kernels, whose epilogues use
+    explicit four-float vector arithmetic (scale, bias, residual); the PointNet, VQ, MANO, PixelCNN-draw and contact kernels
+    must have none -- a compiler bump or a source change that brings them back fails here, on the CPU, before any GPU run."""
+    import collections, re, shutil, struct, subprocess, tempfile
+    objcopy, objdump = "/opt/rocm/lib/llvm/bin/llvm-objcopy", "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(objcopy) and os.path.exists(objdump)):
+        return
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    hits, kernels = collections.defaultdict(collections.Counter), 0
+    with tempfile.TemporaryDirectory() as tmp:
+        fat = os.path.join(tmp, "fat.bin")
+        subprocess.run([objcopy, "--dump-section", f".hip_fatbin={fat}", _lib.LIB_PATH, os.path.join(tmp, "copy.so")], check=True, capture_output=True)
+        data = open(fat, "rb").read()
+        magic, pos = b"__CLANG_OFFLOAD_BUNDLE__", 0
+        while True:
+            j = data.find(magic, pos)
+            if j < 0:
+                break
+            pos = j + 1
+            n, off = struct.unpack_from("<Q", data, j + 24)[0], j + 32
+            for _ in range(n):
+                o, size, ln = struct.unpack_from("<QQQ", data, off)
+                name = data[off + 24: off + 24 + ln].decode()
+                off += 24 + ln
+                if "gfx950" not in name or not size:
+                    continue
+                co = os.path.join(tmp, "dev.co")
+                open(co, "wb").write(data[j + o: j + o + size])
+                r = subprocess.run([objdump, "-d", "--mcpu=gfx950", co], capture_output=True, text=True, check=True)
+                fn = None
+                for line in r.stdout.splitlines():
+                    m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
+                    if m:
+                        fn, kernels = m.group(1), kernels + 1
+                        continue
+                    m = re.search(r"\b(v_pk_(?:mul|fma|add|mov)_(?:f32|b32))\b", line)
+                    if m:
+                        hits[fn][m.group(1)] += 1
+    assert kernels > 50, f"only {kernels} device functions found in {_lib.LIB_PATH}"
+    bad = {fn: dict(c) for fn, c in hits.items() if "gemm_" not in fn}
+    assert not bad, f"packed-fp32 instructions outside the GEMM kernels: {bad}"
+    assert not any("pn_" in fn or "vq_" in fn for fn in hits), "PointNet / VQ kernels must stay free of packed-fp32 instructions"

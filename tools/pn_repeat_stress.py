@@ -27,27 +27,27 @@ ref = {k: m(big_obj)[0] for k, m in mods.items()}
 del os.environ["DVQ_PN_EXHAUSTIVE"]
 lib.dvq_reload_env()
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 150
-bad, t0 = 0, time.time()
+bad_enc, t0 = 0, time.time()
 for it in range(iters):
     for k, m in mods.items():
         f = m(big_obj)[0]
         d = f != ref[k]
         if bool(d.any()):
-            bad += 1
+            bad_enc += 1
             for r in d.any(1).nonzero().flatten().tolist()[:3]:
                 ch = d[r].nonzero().flatten().tolist()
                 print(f"call {it} {k}: cloud {r} (= block cloud {r % blk}) channels {ch[:8]} got {f[r, ch[:3]].tolist()} want {ref[k][r, ch[:3]].tolist()}", flush=True)
-print(f"encoders: {bad} bad calls of {2 * iters} ({time.time() - t0:.1f} s)")
+print(f"encoders: {bad_enc} bad calls of {2 * iters} ({time.time() - t0:.1f} s)")
 gens = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 r0, p0, a0 = net.gen(big_obj, noise=big_q, return_aux=True)
 keep = {k: a0[k].clone() for k in ("feat_pos", "feat_type", "hand_feat", "codes", "idx6")}
 r0, p0 = r0.clone(), p0.clone()
-bad = 0
+bad_gen = 0
 for it in range(gens):
     r, p, a = net.gen(big_obj, noise=big_q, return_aux=True)
     diff = [k for k in keep if not torch.equal(a[k], keep[k])] + ([] if torch.equal(r, r0) and torch.equal(p, p0) else ["recon/recon_pos"])
     if diff:
-        bad += 1
+        bad_gen += 1
         print(f"gen call {it}: {diff} differ from the first call", flush=True)
-print(f"gen: {bad} bad calls of {gens}")
-sys.exit(1 if bad else 0)
+print(f"gen: {bad_gen} bad calls of {gens}")
+sys.exit(1 if (bad_enc or bad_gen) else 0)
