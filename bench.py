@@ -122,7 +122,7 @@ def pmc_traffic(kind, batch):
     names = {"vq_fast": "::vq_stream",         # vq_stream16_kernel (default) / vq_stream_kernel (DVQ_VQ_KERNEL=8)
              "pn_trunk": "pn_trunk_filter_kernel<4>", "pn_exact": "pn_exact_kernel",
              # template-argument lists print as "<2, true>": match up to the first argument
-             "gemm_gate": "gemm_f16x2_kernel<2,", "gemm_bias": "gemm_f16x2_kernel<0,", "gemm_resid": "gemm_f16x2_kernel<1,"}
+             "gemm_gate": "gemm_f16x2_pp_kernel<2>", "gemm_bias": "gemm_f16x2_pp_kernel<0>", "gemm_resid": "gemm_f16x2_pp_kernel<1>"}
     if GEMM_MODE == "bf16x3":
         names.update({"gemm_gate": "gemm_bf16x3_wide_kernel<2,", "gemm_bias": "gemm_bf16x3_wide_kernel<0,", "gemm_resid": "gemm_bf16x3_wide_kernel<1,"})
     try:
