@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdvq_hip.so")
 if os.environ.get("DVQ_DIAG_LIB") == "1":          # tools/ only: the diagnostics build (`make -C csrc diag`), never the product
-    LIB_PATH = os.path.join(_HERE, "libdvq_hip_diag.so")
+    LIB_PATH = os.path.join(os.path.dirname(_HERE), "tools", "diag", "libdvq_hip_diag.so")
     print("[dvq] DVQ_DIAG_LIB=1: loading the DIAGNOSTICS build; results are invalid when a DVQ_*_ABL variable is set",
           file=__import__("sys").stderr)
 CSRC = os.path.join(_HERE, "csrc")
