@@ -43,17 +43,23 @@ constexpr float LO_SCALE = 1.0f / 2048.0f;
 
 __device__ __forceinline__ int swz16(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 
-// a -> (fp16(a), fp16((a - fp16(a)) * 2^11)) for eight values; the subtraction is exact
+// a -> (fp16(a), fp16((a - fp16(a)) * 2^11)) for eight values.  The second piece is ONE rounding of the exact value
+// fma(h, -2048, a * 2048) (v_fma_mixlo / mixhi_f16 take the fp16 piece h as an operand and round the fp32 result to fp16):
+// 20 vector instructions per eight values where convert-back, subtract, scale, convert took 32; the same bits (1 M random pairs incl.
+// subnormal, out-of-range and non-finite values: tools/microbench, round 4).
 __device__ __forceinline__ void split2(const f32x4& lo, const f32x4& hi, h8& p1, h8& p2) {
+    unsigned hb[4], lb[4];
+    const float m2048 = -2048.0f;
 #pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-        const float a0 = j < 4 ? lo[j] : hi[j - 4], a1 = j < 4 ? lo[j + 1] : hi[j - 3];
-        const h2 h = __builtin_convertvector(f32x2{a0, a1}, h2);                       // v_cvt_pk_f16_f32, round to nearest even
-        const float r0 = a0 - (float)h[0], r1 = a1 - (float)h[1];
-        const h2 l = __builtin_convertvector(f32x2{r0 * 2048.0f, r1 * 2048.0f}, h2);
-        p1[j] = h[0]; p1[j + 1] = h[1];
-        p2[j] = l[0]; p2[j + 1] = l[1];
+    for (int j = 0; j < 4; ++j) {
+        const float a0 = j < 2 ? lo[2 * j] : hi[2 * j - 4], a1 = j < 2 ? lo[2 * j + 1] : hi[2 * j - 3];
+        hb[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a0, a1}, h2));         // v_cvt_pk_f16_f32, round to nearest even
+        const float t0 = a0 * 2048.0f, t1 = a1 * 2048.0f;
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lb[j]) : "v"(hb[j]), "v"(m2048), "v"(t0));
+        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lb[j]) : "v"(hb[j]), "v"(m2048), "v"(t1));
     }
+    p1 = __builtin_bit_cast(h8, uint4{hb[0], hb[1], hb[2], hb[3]});
+    p2 = __builtin_bit_cast(h8, uint4{lb[0], lb[1], lb[2], lb[3]});
 }
 
 struct TileCursor {
@@ -287,7 +293,11 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(const GemmParams p) 
 // MFMA sequence per output as gemm_f16x2_kernel: bit-identical.  Measured on the gated shape (M 16 384, N 1024, K 1536):
 // 300-307 TFLOP/s against 286-293 for the two-stage dephased kernel; in-kernel stamps (tools/microbench/gemm_f16x2_wide.hip):
 // load phase ~850 cycles + loop overhead against 803 for the compute phase at an in-kernel clock of 1.74 GHz; moving the split
-// into the compute phase's MFMA gaps (1 MFMA : 2 vector instructions) measured SLOWER (273).
+// into the compute phase's MFMA gaps (1 MFMA : 2 vector instructions) measured SLOWER (273).  Hand-counted waits (activation
+// loads as inline asm, vmcnt(4) / vmcnt(6) so that neither stream waits for the other's younger requests) measured 327 on the
+// microbench, where the activations stream from HBM, and NOTHING in the benchmark step (gated GEMMs 199.6 -> 200.5 ms: their
+// activations were written by the previous launch); the variant tried also let waves 0-3 read a tile whose DMA pieces waves 4-7
+// had not waited for yet (one differing result hash in four bench runs) -- not kept: every load phase starts with vmcnt(0).
 constexpr int PP_STAGES = 3;
 constexpr size_t PP_SMEM = PP_STAGES * STAGE;               // 147 456 B
 

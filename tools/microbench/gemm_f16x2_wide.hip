@@ -276,6 +276,16 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp(const P p) {
         alo = *reinterpret_cast<const f32x4*>(a_ptr + (long)t * BK);
         ahi = *reinterpret_cast<const f32x4*>(a_ptr + (long)t * BK + 4);
     };
+    // ABL 10 / 11 / 12 are TIMING experiments only: with the DMA wait at the end of the compute phase, waves 0-3 may read a tile whose
+    // DMA pieces waves 4-7 (half a period behind) have not waited for yet -- results can be wrong; not carried into the library.
+    auto load_a_asm = [&](int t) {                          // ABL 10: loads the compiler does not track (waits are counted by hand)
+        const float* q = a_ptr + (long)t * BK;
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"(alo), "=&v"(ahi) : "v"(q) : "memory");
+    };
+    auto load_b_asm = [&](int t) {
+        const float* q = a_ptr + (long)t * BK;
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16" : "=&v"(blo), "=&v"(bhi) : "v"(q) : "memory");
+    };
     auto load_b = [&](int t) {
         blo = *reinterpret_cast<const f32x4*>(a_ptr + (long)t * BK);
         bhi = *reinterpret_cast<const f32x4*>(a_ptr + (long)t * BK + 4);
@@ -313,10 +323,15 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp(const P p) {
     issue_w(smem, 0);
     store_a(smem);
     if (T > 1) { load_a(1); issue_w(smem + STAGE, 1); store_a(smem + STAGE); }
-    if (T > 2) load_a(2);
+    if (ABL == 10 || ABL == 11 || ABL == 12) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (T > 2) load_a_asm(2);
+        if (ABL != 10 && T > 3) load_b_asm(3);
+    } else if (T > 2) load_a(2);
     if (ABL == 4 && T > 3) load_b(3);
     if (ABL == 3 && T > 2) load_w(2);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (ABL == 10 || ABL == 11 || ABL == 12) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     f32x4 hi[4][4], lo[4][4];
@@ -349,14 +364,42 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp(const P p) {
         if (t + 2 < T) {
             char* nx = smem + ((t + 2) % NSTAGE_PP) * STAGE;
             if (ABL == 9) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+            if (ABL == 12) {                                // as 11 with the activation loads issued BEFORE the DMA pieces: they are older than
+                                                            // DMA(t) .. forced at the end of compute phase t - 1: no wait here except at the start
+                if (t < 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(alo), "+v"(ahi), "+v"(blo), "+v"(bhi) :: "memory");
+                else asm volatile("" : "+v"(alo), "+v"(ahi), "+v"(blo), "+v"(bhi) :: "memory");
+                if (SET) store_b(nx); else store_a(nx);
+                if (t + 4 < T) { if (SET) load_b_asm(t + 4); else load_a_asm(t + 4); }
+                issue_w(nx, t + 2);
+            } else
+            if (ABL == 11) {
+                // Issue order per load phase: four DMA pieces (tile t + 2), then two activation loads (tile t + 4, into the register
+                // set converted just above).  vmcnt counts in order: the activations of tile t + 2 -- issued two periods ago, behind
+                // the DMA of tile t and ahead of everything younger -- are ready when all but the 6 + 2... youngest have landed.
+                if (t < 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(alo), "+v"(ahi), "+v"(blo), "+v"(bhi) :: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" : "+v"(alo), "+v"(ahi), "+v"(blo), "+v"(bhi) :: "memory");
+                if (SET) store_b(nx); else store_a(nx);
+                issue_w(nx, t + 2);
+                if (t + 4 < T) { if (SET) load_b_asm(t + 4); else load_a_asm(t + 4); }
+            } else
+            if (ABL == 10) {
+                // activations of tile t + 2 (two loads, issued before the four DMA pieces of the previous load phase)
+                if (t == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(alo), "+v"(ahi) :: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" : "+v"(alo), "+v"(ahi) :: "memory");
+                store_a(nx);
+                if (t + 3 < T) load_a_asm(t + 3);
+                issue_w(nx, t + 2);
+            } else
             if (ABL == 4) { if (SET) store_b(nx); else store_a(nx); }
+            else if (ABL == 7) asm volatile("" :: "v"(alo), "v"(ahi));                  // loads kept, no split / LDS write
             else if (ABL != 2 && ABL != 5) store_a(nx);     // tile t + 2, loaded a period ago
             if (ABL == 9) { __builtin_amdgcn_sched_barrier(0); t3 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
             if (ABL == 3) store_w(nx);
-            else if (ABL != 1) issue_w(nx, t + 2);
+            else if (ABL != 1 && ABL != 10 && ABL != 11 && ABL != 12) issue_w(nx, t + 2);
             if (ABL == 4) { if (t + 4 < T) { if (SET) load_b(t + 4); else load_a(t + 4); } }
             else if (ABL == 5) { if (t + 3 < T) { if (SET) load_a(t + 3); else load_b(t + 3); } }      // the set that is NOT converted in this period
-            else if (t + 3 < T) { if (ABL != 2) load_a(t + 3); if (ABL == 3) load_w(t + 3); }
+            else if (ABL == 10 || ABL == 11 || ABL == 12) {}
+            else if (t + 3 < T) { if (ABL != 2 && ABL != 8) load_a(t + 3); if (ABL == 3) load_w(t + 3); }   // 8: split + write of stale registers, no loads
         }
         if (ABL == 9) { __builtin_amdgcn_sched_barrier(0); t4 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers before the phase ends
@@ -393,6 +436,18 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp(const P p) {
             __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
         }
         if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (ABL == 12) {                                    // DMA(t + 1) landed (and A(t + 3) before it): younger = A(t + 4), DMA(t + 2)
+            if (t + 4 < T) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (ABL == 11) {                                    // DMA(t + 1) landed: younger = A(t + 3), DMA(t + 2), A(t + 4)
+            if (t + 4 < T) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (ABL == 10) {                                    // the DMA pieces of tile t + 1 (issued a period and a half ago) have landed
+            if (t + 3 < T) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         if (ABL == 9) { __builtin_amdgcn_sched_barrier(0); t7 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         __builtin_amdgcn_s_barrier();
         if (ABL == 9 && t + 3 < T && t >= 2) {
@@ -568,6 +623,11 @@ int main(int argc, char** argv) {
                 printf(" total %.0f\n", tot);
             }
         }
+        us = run_pp<1, 10>(p, 40, dA, nbuf); printf("  f16x2 pp setprio, counted waits (loads and DMA decoupled) : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("pp counted", dout);
+        us = run_pp<1, 11>(p, 40, dA, nbuf); printf("  f16x2 pp setprio, counted waits, activations two periods ahead : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("pp counted x2", dout);
+        us = run_pp<1, 12>(p, 40, dA, nbuf); printf("  f16x2 pp setprio, counted waits, loads before DMA, 1.5 periods : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("pp counted 12", dout);
+        us = run_pp<1, 7>(p, 40, dA, nbuf); printf("  (timing only) pp setprio, activation loads but no split / LDS write : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6);
+        us = run_pp<1, 8>(p, 40, dA, nbuf); printf("  (timing only) pp setprio, split / LDS write but no activation loads : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6);
         us = run_pp<1, 1>(p, 40, dA, nbuf); printf("  (timing only) pp setprio, no weight DMA : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6);
         us = run_pp<1, 2>(p, 40, dA, nbuf); printf("  (timing only) pp setprio, no activation path : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6);
         us = run<32, false>(p, 40, dA, nbuf); printf("  f16x2 32x32x16          : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("32x32x16", dout);
