@@ -460,6 +460,12 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp_kernel(const GemmParams 
     f16x2_epilogue<EPI>(p, hi, lo, m0 + wm * 64, n0 + wn * 64, (n0 >> 1) + wn * 32, lane);
 }
 
+// Measured and not kept (round 4): a 128 x 128 tile with four waves and two 32 KiB stages, TWO workgroups per CU, for the short-K
+// launches (the PixelCNN's 1x1 residual conv and head, K = 512: 46 us per launch = 187 TFLOP/s; 100 MB of HBM traffic for 8.6 GFLOP).
+// Bit-identical, and no faster: residual GEMMs 22.6 -> 23.3 ms per step, gated GEMMs 192 -> 212 ms when forced on everything.  A
+// workgroup of those launches moves ~1 MB (activations 256 KB, weight planes 512 KB from L2, residual in, tile out) in 46 us =
+// 22 GB/s per CU, the rate one CU sustains from beyond L2 (MI355X_MICROARCH.md: 23-33 GB/s): they are bound by the per-CU memory
+// path, not by the overlap of prologue and epilogue, and the smaller tile reads every activation row twice as often.
 template <int EPI>
 int launch_tiled(const GemmParams& p, hipStream_t stream) {
     static DvqOncePerDevice attr_once;
