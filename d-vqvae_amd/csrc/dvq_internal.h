@@ -173,6 +173,7 @@ struct DvqKnobs {
     int gemm_wide;        // 0: 128 x 128 kernels only
     int gemm_dephase;
     int vq_kernel;        // 16 (default): vq_stream16.hip; 8: vq_stream.hip's eight-wave kernel; 32: vq_rows.hip (DVQ_VQ_KERNEL)
+    int vq_rows_delay;    // vq_rows.hip: start delay of the second half of the grid, 10 ns ticks (DVQ_VQ_ROWS_DELAY)
     int gemm_skinny_prefetch;   // 0: no helper workgroups (DVQ_GEMM_SKINNY_PREFETCH=0)
     int gemm_skinny;      // 0: tiled kernels also for M <= 256 (DVQ_GEMM_SKINNY=0; the two must agree bitwise)
     int gemm_skinny_cols; // f16x2 skinny kernel: output columns per wave, 16 / 8 / 4 (DVQ_GEMM_SKINNY_COLS; 0 = by the launch's size; same bits)

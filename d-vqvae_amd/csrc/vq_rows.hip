@@ -29,6 +29,7 @@
 // are evaluated in the canonical fp32 order, eight lanes per 256-step chain, exactly as in the other kernels.
 #include "dvq_internal.h"
 #include "vq_pack.h"
+#include <vector>
 
 #ifndef VQR_ABL
 #define VQR_ABL 0          // timing experiments (results invalid unless 0): 1 no refine tail, 2 no scoring, 4 no MFMA, 8 no stream
@@ -156,9 +157,19 @@ struct Top5 {
 
 __global__ __launch_bounds__(NT, 2) void vq_rows_kernel(const float* __restrict__ z, const float* __restrict__ E, long M,
                                                         const char* __restrict__ packed, int64_t* __restrict__ idx,
-                                                        unsigned long long* __restrict__ slow_rows) {
+                                                        unsigned long long* __restrict__ slow_rows, int delay_ticks, unsigned long long* __restrict__ dbg) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
+    // Stagger: the second half of the grid (the second workgroup of every CU when the dispatcher fills the chip breadth first;
+    // placement is for speed only) starts its row loads `delay_ticks` x 10 ns late.  Otherwise every wave of the chip waits for
+    // its rows at the same time and multiplies at the same time: 16 us of HBM stream with idle matrix cores, then the matrix work
+    // with an idle HBM.  Staggered, the first half's rows arrive at the full HBM rate, and its products and refine tail run
+    // while the second half's rows stream in.
+    const unsigned long long t_begin = dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    if (delay_ticks > 0 && blockIdx.x >= (gridDim.x + 1) / 2) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)delay_ticks) __builtin_amdgcn_s_sleep(32);
+    }
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r_l = lane & 31, h_l = lane >> 5;
     const long row0 = (long)blockIdx.x * ROWS_B;                          // first row of the workgroup
@@ -224,6 +235,7 @@ __global__ __launch_bounds__(NT, 2) void vq_rows_kernel(const float* __restrict_
             }
         }
     }
+    const unsigned long long t_rows = dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // the rows as MFMA B operand: lane (row r_l, half h_l) holds k = 16 s + 8 h .. + 7 of its row for every k-step s
     f16x8 bz[16];
     {
@@ -309,6 +321,7 @@ __global__ __launch_bounds__(NT, 2) void vq_rows_kernel(const float* __restrict_
     score(NBLK / 2 - 1, pb);
 #undef VQR_INTERLEAVE
 
+    const unsigned long long t_stream = dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // ---- phase 2: the two lane halves of a row -> decision or candidates (lanes 0..31, one row each)
     {
         auto upper = [](float v) { return __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false)[1]); };
@@ -380,6 +393,14 @@ __global__ __launch_bounds__(NT, 2) void vq_rows_kernel(const float* __restrict_
     }
     if (slow_rows && tid == 0 && n_slow > 0) atomicAdd(slow_rows, (unsigned long long)n_slow);
     __syncthreads();
+    if (dbg && tid == 0) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* o = dbg + (size_t)blockIdx.x * 8;
+        o[0] = t_begin; o[1] = t_rows; o[2] = t_stream; o[3] = __builtin_amdgcn_s_memrealtime(); o[4] = ((unsigned long long)xcc << 32) | hw;
+    }
     if (tid < ROWS_B) {
         const long gr = row0 + tid;
         const unsigned long long res = s_res[tid];
@@ -392,6 +413,9 @@ __global__ __launch_bounds__(NT, 2) void vq_rows_kernel(const float* __restrict_
 // called by dvq_vq_argmin_fast (vq_stream.hip) after argument validation
 int dvq_launch_vq_rows(const float* z, const float* E, const void* packed, long M, int64_t* idx, unsigned long long* slow_rows,
                        hipStream_t st) {
+    static unsigned long long* dbg_buf = nullptr;           // DVQ_VQ_ROWS_DBG=1: per-workgroup phase stamps, printed after the launch (syncs)
+    static const bool dbg_on = getenv("DVQ_VQ_ROWS_DBG") != nullptr;
+    if (dbg_on && !dbg_buf) (void)hipMalloc(&dbg_buf, 8 * 8 * 4096);
     static DvqOncePerDevice attr_once;
     {
         const hipError_t e = attr_once.run([] {
@@ -407,8 +431,26 @@ int dvq_launch_vq_rows(const float* z, const float* E, const void* packed, long 
     for (long b0 = 0; b0 < blocks; b0 += per_launch) {
         const long nb = blocks - b0 < per_launch ? blocks - b0 : per_launch;
         const long r0 = b0 * ROWS_B;
-        DVQ_LAUNCH(vq_rows_kernel, dim3((unsigned)nb), dim3(NT), LDS_BYTES, st, z + r0 * D, E, M - r0, (const char*)packed, idx + r0, slow_rows);
+        DVQ_LAUNCH(vq_rows_kernel, dim3((unsigned)nb), dim3(NT), LDS_BYTES, st, z + r0 * D, E, M - r0, (const char*)packed, idx + r0, slow_rows,
+                   nb >= 256 ? dvq_knobs().vq_rows_delay : 0, (dbg_on && nb <= 4096) ? dbg_buf : nullptr);
         DVQ_CHECK_LAUNCH("vq_rows");
+        if (dbg_on && nb <= 4096) {
+            static int printed = 0;
+            std::vector<unsigned long long> h((size_t)nb * 8);
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(h.data(), dbg_buf, h.size() * 8, hipMemcpyDeviceToHost);
+            if (printed++ == 12) {
+                unsigned long long t0 = ~0ull;
+                for (long b = 0; b < nb; ++b) t0 = h[8 * b] < t0 ? h[8 * b] : t0;
+                double acc[2][4] = {{0}};
+                for (long b = 0; b < nb; ++b) { const int g = b >= (nb + 1) / 2; for (int q = 0; q < 4; ++q) acc[g][q] += (double)(h[8 * b + q] - t0) * 0.01 / ((nb + 1) / 2); }
+                for (int g = 0; g < 2; ++g) fprintf(stderr, "[vq_rows dbg] %s half: start %.2f us, rows in registers %.2f, stream done %.2f, end %.2f\n", g ? "second" : "first", acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+                // do blocks b and b + nb/2 share a CU?
+                long same = 0;
+                for (long b = 0; b < nb / 2; ++b) same += (h[8 * b + 4] & 0xffffffff0000ff00ull) == (h[8 * (b + nb / 2) + 4] & 0xffffffff0000ff00ull);   // xcc, se/sh/cu bits
+                fprintf(stderr, "[vq_rows dbg] blocks b and b + %ld on the same (XCC, SE, CU): %ld of %ld; hw_id[0]=%llx hw_id[%ld]=%llx\n", nb / 2, same, nb / 2, h[4], nb / 2, h[8 * (nb / 2) + 4]);
+            }
+        }
     }
     return DVQ_OK;
 }
