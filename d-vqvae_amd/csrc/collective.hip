@@ -7,7 +7,15 @@
 #include "dvq_internal.h"
 #include <dlfcn.h>
 #include <string.h>
-#include <rccl/rccl.h>
+
+// The five RCCL entry points used here, declared locally (rccl.h's own declarations, ABI-stable since NCCL 2.0): the library
+// builds on a machine without the RCCL headers and, resolving the symbols by dlopen, loads on one without the library.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat32 = 7 } ncclDataType_t;
+}
 
 namespace {
 

@@ -69,16 +69,30 @@ def _abi_comm(device: torch.device):
         return _comms[idx]
     lib = _lib.load()
     world, rank = dist.get_world_size(), dist.get_rank()
+    # Every rank must end up with the same answer: a rank whose librccl cannot be resolved (or whose init fails) must not raise while
+    # the others sit in ncclCommInitRank or in the first collective.  So: every rank probes RCCL (making a unique id resolves it;
+    # rank 0's is THE id), the communicator is only initialised if EVERY rank could (all-reduce over the process group) and only
+    # used if EVERY rank's init succeeded (a second one); otherwise all ranks fall back to torch.distributed's all-gather together
+    # (the None is cached: asked once per device).
     uid = C.create_string_buffer(128)
-    if rank == 0:
-        _lib.check(lib.dvq_comm_unique_id(uid, 128), "dvq_comm_unique_id")
-    box = [bytes(uid.raw)]
+    have = lib.dvq_comm_unique_id(uid, 128) == 0
+    box = [bytes(uid.raw) if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
-    handle = C.c_void_p()
-    with torch.cuda.device(idx):
-        _lib.check(lib.dvq_comm_init(box[0], 128, world, rank, C.byref(handle)), "dvq_comm_init")
-    _comms[idx] = handle
-    return handle
+
+    def everybody(flag: bool) -> bool:
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item()) == 1
+
+    handle, good = C.c_void_p(), False
+    if everybody(have):
+        with torch.cuda.device(idx):
+            good = lib.dvq_comm_init(box[0], 128, world, rank, C.byref(handle)) == 0
+        if not everybody(good) and good:
+            lib.dvq_comm_destroy(handle)
+            good = False
+    _comms[idx] = handle if good else None
+    return _comms[idx]
 
 
 def _gather_equal(local: torch.Tensor, world: int) -> torch.Tensor:
@@ -88,9 +102,9 @@ def _gather_equal(local: torch.Tensor, world: int) -> torch.Tensor:
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     use_abi = (local.is_cuda and local.dtype == torch.float32 and local.dim() == 2 and dist.get_backend() == "nccl"
                and os.environ.get("DVQ_ALLGATHER", "abi") != "torch")
-    if use_abi:
+    comm = _abi_comm(local.device) if use_abi else None      # None: some rank could not build the communicator (all ranks agree)
+    if comm is not None:
         from . import _lib
-        comm = _abi_comm(local.device)
         with torch.cuda.device(local.device):
             _lib.check(_lib.load().dvq_allgather_params(comm, local.data_ptr(), local.shape[0], local.shape[1], out.data_ptr(),
                                                         torch.cuda.current_stream(local.device).cuda_stream), "dvq_allgather_params")
@@ -158,7 +172,8 @@ def shutdown():
     if _comms:
         from . import _lib
         for h in _comms.values():
-            _lib.load().dvq_comm_destroy(h)
+            if h is not None:
+                _lib.load().dvq_comm_destroy(h)
         _comms.clear()
     if dist.is_initialized():
         dist.destroy_process_group()
