@@ -1,4 +1,5 @@
-"""GEMM microbench (GPU box): TFLOP/s of the split-bf16 GEMM on the PixelCNN's shapes."""
+"""GEMM microbench (GPU box): TFLOP/s of the default GEMM arithmetic (fp16 three-product split; DVQ_GEMM=bf16x3: the six-product
+bf16 split) on the PixelCNN's shapes."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dvqvae_amd
@@ -6,7 +7,7 @@ from dvqvae_amd import ops, packing
 dev = "cuda:0"
 for M, N, K in ((16384, 1024, 1536), (16384, 512, 2560), (16384, 512, 1024), (16384, 256, 256)):
     x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev) * 0.03; b = torch.randn(N, device=dev)
-    pl = packing.split_bf16x3(w); out = torch.empty(M, N, device=dev)
+    pl = packing.split_planes(w); out = torch.empty(M, N, device=dev)
     for _ in range(5): ops.linear(x, w, b, out=out, planes=pl)
     torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()

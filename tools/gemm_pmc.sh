@@ -1,12 +1,12 @@
 #!/bin/bash
-# Runs ON THE GPU BOX: SQ counters of the split-bf16 GEMM kernels under tools/gemm_bench.py (wave cycles split into waiting /
+# Runs ON THE GPU BOX: SQ counters of the GEMM kernels (default: the fp16 three-product split) under tools/gemm_bench.py (wave cycles split into waiting /
 # issue-stalled / active, LDS conflicts, MFMA busy), passes of <= 8 SQ counters, counters only with --kernel-trace.
 set -u
 OUT=gpurun_out/${1:-gemm_pmc}
 mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS -d $OUT/a -o a --output-format csv -- python3 tools/gemm_bench.py > $OUT/a.json 2> $OUT/a.log
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU -d $OUT/b -o b --output-format csv -- python3 tools/gemm_bench.py > $OUT/b.json 2> $OUT/b.log
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU -d $OUT/b -o b --output-format csv -- python3 tools/gemm_bench.py > $OUT/b.json 2> $OUT/b.log
 python3 - <<'PY' $OUT
 import csv, glob, sys, collections
 out = sys.argv[1]
@@ -14,10 +14,10 @@ for sub in ("a", "b"):
     for p in glob.glob(f"{out}/{sub}/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(lambda: [0.0, 0])
         for row in csv.DictReader(open(p)):
-            if "gemm_bf16x3" not in row["Kernel_Name"]: continue
+            if "gemm_" not in row["Kernel_Name"]: continue
             key = (row["Kernel_Name"][27:60], row["Counter_Name"])
             a = acc[key]; a[0] += float(row["Counter_Value"]); a[1] += 1
         for k, (v, n) in sorted(acc.items()):
             print(f"{k[0]:34s} {k[1]:32s} per launch {v / n:16.0f}   ({n} launches)")
 PY
-tail -2 $OUT/a.log $OUT/b.log | cut -c1-200
+tail -n 2 $OUT/a.log | cut -c1-200; tail -n 2 $OUT/b.log | cut -c1-200

@@ -19,4 +19,4 @@ for sub in ("a", "b"):
         for k, (v, n) in sorted(acc.items()):
             print(f"{k:34s} per launch {v / n:16.0f}   ({n} launches)")
 PY
-tail -3 $OUT/a.log $OUT/b.log
+tail -n 3 $OUT/a.log; tail -n 3 $OUT/b.log
