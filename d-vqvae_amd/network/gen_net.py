@@ -125,17 +125,23 @@ class GenNet(nn.Module):
                     "gen_net.py:20-34); build GenNet(n_embeddings=...) to match the prior")
 
     @torch.no_grad()
-    def gen(self, obj, noise=None, return_aux=False, seed=None, row0=None, stream_id=None):
+    def gen(self, obj, noise=None, return_aux=False, seed=None, row0=None, stream_id=None, check=True):
         """obj [B,4,N] f32 on the GPU -> (recon [B,55], recon_pos [B,6]).
         ``noise`` [B,9,prior_tokens] ~ Exp(1) fixes the prior's draws (parity runs).  Without it the draws come from the
         device Philox generator keyed by (seed, stream_id, row0 + b): a batch sharded over ranks (``row0`` = first global
         row of the shard, same ``seed`` / ``stream_id``) generates exactly what the unsharded call generates.
         Defaults: seed = set_noise_seed's, else torch.initial_seed(); one stream per call; rows of this rank
-        (ops.default_noise_key), so ranks that name nothing never share noise."""
+        (ops.default_noise_key), so ranks that name nothing never share noise.
+        ``check=False``: no host synchronisation at all -- the call returns as soon as the work is enqueued (a loop of B = 1 calls
+        then overlaps the host side of call i + 1 with the device side of call i); the caller gives up the index-range error
+        and the fp16-range fallback below, and gets ``aux["err"]`` (device int32: bit 0 range, bit 2 all-NaN logits) to check later."""
         if obj.dim() != 3:
             raise RuntimeError(f"gen: expected obj [B,4,N], got {tuple(obj.shape)}")
         key = self._noise_key(seed, row0, stream_id) if noise is None else None
         recon, recon_pos, aux, err = self._gen_impl(obj, noise, key)
+        aux["err"] = err
+        if not check:
+            return (recon, recon_pos, aux) if return_aux else (recon, recon_pos)
         # one host synchronisation per call: the index-range flag and "every parameter is finite"
         status = int((err + 2 * (~(torch.isfinite(recon).all() & torch.isfinite(recon_pos).all())).to(torch.int32)).item())
         if status & 1:

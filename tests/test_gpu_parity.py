@@ -883,6 +883,16 @@ def test_gen_bench_config_vs_oracle():
     assert_close(pos.cpu()[both], o_pos[both], atol=TOL, what="wrist parameters")
 
 
+def test_gen_without_host_sync_returns_the_same_results():
+    """gen(check=False) enqueues and returns (no .item()): same tensors as the checked call, the error flag left on the device."""
+    net, _ = _gennet()
+    obj = gpu(synth.synthetic_clouds(5, 300, seed=31))
+    q = gpu(synth.exp1_noise(5, 9, 512, seed=32))
+    r0, p0 = net.gen(obj, noise=q)
+    r1, p1, aux = net.gen(obj, noise=q, check=False, return_aux=True)
+    assert torch.equal(r0, r1) and torch.equal(p0, p1) and int(aux["err"].item()) == 0
+
+
 def test_gen_falls_back_to_bf16x3_beyond_fp16_range():
     """The fp16 three-product GEMMs turn a row with an activation beyond +-65 504 into NaN; gen() notices (one finite check in
     its single host sync) and generates the batch again on the six-product bf16 split.  A decoder weight scaled so that the
