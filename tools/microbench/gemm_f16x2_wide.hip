@@ -24,6 +24,7 @@ struct P {
     int K, N; long M;
     const float* cs; const float* bias; float* out; long ldo;
     unsigned long long* dbg;     // ABL 9: per-wave phase stamps (8 sums per wave)
+    const uint16_t* Ap;          // ABL 13: the activations as fp16 plane pairs [M][2][K] (a row's pitch = the fp32 row's), both operands by LDS-DMA
 };
 
 constexpr int A_PL = 128 * 64, W_PL = 256 * 64, STAGE = 2 * A_PL + 2 * W_PL;   // 49 152 B
@@ -46,6 +47,19 @@ __device__ __forceinline__ void split2(const f32x4& lo, const f32x4& hi, h8& p1,
         p1[j] = h[0]; p1[j + 1] = h[1];
         p2[j] = l[0]; p2[j + 1] = l[1];
     }
+}
+
+// ABL 13: what a producing epilogue would store -- row m: K first pieces, then K second pieces (same bytes as the fp32 row)
+__global__ void presplit_rows(const float* __restrict__ A, uint16_t* __restrict__ Ap, long M, int K) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;            // one thread per eight values
+    const long per_row = K / 8, m = i / per_row;
+    if (m >= M) return;
+    const int k = (int)(i % per_row) * 8;
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(A + m * K + k), hi = *reinterpret_cast<const f32x4*>(A + m * K + k + 4);
+    h8 p1, p2;
+    split2(lo, hi, p1, p2);
+    *reinterpret_cast<h8*>(Ap + m * 2 * K + k) = p1;
+    *reinterpret_cast<h8*>(Ap + m * 2 * K + K + k) = p2;
 }
 
 __device__ __forceinline__ void dma_barrier() {
@@ -271,6 +285,24 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp(const P p) {
         w_dst[i] = 2 * A_PL + pl * W_PL + rb * 1024;
     }
     const int T = p.K / BK;
+    const uint16_t* ap_ptr[2];                              // ABL 13: two 1 KiB pieces of the activation planes per wave
+    int ap_dst[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = wave * 2 + i;
+        const int pl = id >> 3, rb = id & 7;
+        const int row = rb * 16 + (lane >> 2);
+        long m = m0 + row;
+        if (m >= p.M) m = p.M - 1;
+        ap_ptr[i] = p.Ap + m * 2 * p.K + pl * p.K + 8 * ((lane & 3) ^ swz<16>(row));
+        ap_dst[i] = pl * A_PL + rb * 1024;
+    }
+    auto issue_ap = [&](char* stage, int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ap_ptr[i] + (long)t * BK),
+                                             (__attribute__((address_space(3))) void*)(stage + ap_dst[i]), 16, 0, 0);
+    };
     f32x4 alo, ahi, blo, bhi;                               // ABL 4: a second register set, loads two periods ahead
     auto load_a = [&](int t) {
         alo = *reinterpret_cast<const f32x4*>(a_ptr + (long)t * BK);
@@ -319,10 +351,16 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp(const P p) {
         for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(stage + w_dst[i] + 16 * lane) = wreg[i];
     };
     // prologue: tiles 0 and 1 staged, tile 2's activations in registers
+    if (ABL == 13) {
+        issue_ap(smem, 0); issue_w(smem, 0);
+        if (T > 1) { issue_ap(smem + STAGE, 1); issue_w(smem + STAGE, 1); }
+    } else {
     load_a(0);
     issue_w(smem, 0);
     store_a(smem);
     if (T > 1) { load_a(1); issue_w(smem + STAGE, 1); store_a(smem + STAGE); }
+    }
+    if (ABL == 13) {} else
     if (ABL == 10 || ABL == 11 || ABL == 12) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         if (T > 2) load_a_asm(2);
@@ -364,6 +402,11 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp(const P p) {
         if (t + 2 < T) {
             char* nx = smem + ((t + 2) % NSTAGE_PP) * STAGE;
             if (ABL == 9) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+            if (ABL == 13) {                                // both operands by DMA: what this wave issued a period ago (tile t + 1) has landed
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                issue_ap(nx, t + 2);
+                issue_w(nx, t + 2);
+            } else
             if (ABL == 12) {                                // as 11 with the activation loads issued BEFORE the DMA pieces: they are older than
                                                             // DMA(t) .. forced at the end of compute phase t - 1: no wait here except at the start
                 if (t < 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(alo), "+v"(ahi), "+v"(blo), "+v"(bhi) :: "memory");
@@ -392,16 +435,17 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp(const P p) {
             } else
             if (ABL == 4) { if (SET) store_b(nx); else store_a(nx); }
             else if (ABL == 7) asm volatile("" :: "v"(alo), "v"(ahi));                  // loads kept, no split / LDS write
-            else if (ABL != 2 && ABL != 5) store_a(nx);     // tile t + 2, loaded a period ago
+            else if (ABL != 2 && ABL != 5 && ABL != 13) store_a(nx);     // tile t + 2, loaded a period ago
             if (ABL == 9) { __builtin_amdgcn_sched_barrier(0); t3 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
             if (ABL == 3) store_w(nx);
-            else if (ABL != 1 && ABL != 10 && ABL != 11 && ABL != 12) issue_w(nx, t + 2);
+            else if (ABL != 1 && ABL != 10 && ABL != 11 && ABL != 12 && ABL != 13) issue_w(nx, t + 2);
             if (ABL == 4) { if (t + 4 < T) { if (SET) load_b(t + 4); else load_a(t + 4); } }
             else if (ABL == 5) { if (t + 3 < T) { if (SET) load_a(t + 3); else load_b(t + 3); } }      // the set that is NOT converted in this period
-            else if (ABL == 10 || ABL == 11 || ABL == 12) {}
+            else if (ABL == 10 || ABL == 11 || ABL == 12 || ABL == 13) {}
             else if (t + 3 < T) { if (ABL != 2 && ABL != 8) load_a(t + 3); if (ABL == 3) load_w(t + 3); }   // 8: split + write of stale registers, no loads
         }
         if (ABL == 9) { __builtin_amdgcn_sched_barrier(0); t4 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+        if (ABL == 13 && t + 2 >= T) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers before the phase ends
         if (ABL == 9) { t5 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         __builtin_amdgcn_s_barrier();
@@ -487,6 +531,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp(const P p) {
 static double frand() { return (double)rand() / RAND_MAX; }
 static double nrand() { return sqrt(-2.0 * log(frand() + 1e-12)) * cos(6.283185307179586 * frand()); }
 
+static const uint16_t* g_Ap[3];
 template <int PRIO, int ABL>
 static double run_pp(const P& p, int iters, const float* const* Abufs, int nbuf) {
     const int smem_b = NSTAGE_PP * STAGE;
@@ -496,14 +541,14 @@ static double run_pp(const P& p, int iters, const float* const* Abufs, int nbuf)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     P q = p;
-    for (int i = 0; i < 5; ++i) { q.A = Abufs[i % nbuf]; hipLaunchKernelGGL((gemm_f16x2_pp<PRIO, ABL>), dim3((unsigned)grid), dim3(512), smem_b, 0, q); }
+    for (int i = 0; i < 5; ++i) { q.A = Abufs[i % nbuf]; q.Ap = g_Ap[i % nbuf]; hipLaunchKernelGGL((gemm_f16x2_pp<PRIO, ABL>), dim3((unsigned)grid), dim3(512), smem_b, 0, q); }
     CK(hipEventRecord(e0));
-    for (int i = 0; i < iters; ++i) { q.A = Abufs[i % nbuf]; hipLaunchKernelGGL((gemm_f16x2_pp<PRIO, ABL>), dim3((unsigned)grid), dim3(512), smem_b, 0, q); }
+    for (int i = 0; i < iters; ++i) { q.A = Abufs[i % nbuf]; q.Ap = g_Ap[i % nbuf]; hipLaunchKernelGGL((gemm_f16x2_pp<PRIO, ABL>), dim3((unsigned)grid), dim3(512), smem_b, 0, q); }
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms = 0;
     CK(hipEventElapsedTime(&ms, e0, e1));
-    q.A = Abufs[0];
+    q.A = Abufs[0]; q.Ap = g_Ap[0];
     hipLaunchKernelGGL((gemm_f16x2_pp<PRIO, ABL>), dim3((unsigned)grid), dim3(512), smem_b, 0, q);
     CK(hipDeviceSynchronize());
     return ms * 1e3 / iters;
@@ -576,7 +621,14 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&dp3, (size_t)3 * N * K * 2));
         CK(hipMalloc(&dout, (size_t)M * N * 4)); CK(hipMalloc(&dout2, (size_t)M * N * 4));
         unsigned long long* ddbg; CK(hipMalloc(&ddbg, 8192 * 8)); CK(hipMemset(ddbg, 0, 8192 * 8));
-        P p{dA[0], K, dp, (long)N * K, K, K, N, M, dcs, db, dout, N, ddbg};
+        uint16_t* dAp[nbuf];
+        for (int i = 0; i < nbuf; ++i) {
+            CK(hipMalloc(&dAp[i], (size_t)M * K * 4));
+            hipLaunchKernelGGL(presplit_rows, dim3((unsigned)((M * (K / 8) + 255) / 256)), dim3(256), 0, 0, dA[i], dAp[i], M, K);
+        }
+        CK(hipDeviceSynchronize());
+        for (int i = 0; i < nbuf; ++i) g_Ap[i] = dAp[i];
+        P p{dA[0], K, dp, (long)N * K, K, K, N, M, dcs, db, dout, N, ddbg, dAp[0]};
         const double flop = 2.0 * M * N * K;
         std::vector<float> hout((size_t)M * N);
         auto check = [&](const char* name, float* dev) {
@@ -599,6 +651,8 @@ int main(int argc, char** argv) {
         us = run<16, true>(p, 40, dA, nbuf);  printf("  f16x2 16x16x32 dephased : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("16x16x32 dephased", dout);
         us = run_pp<0, 0>(p, 40, dA, nbuf); printf("  f16x2 ping-pong         : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("ping-pong", dout);
         us = run_pp<1, 0>(p, 40, dA, nbuf); printf("  f16x2 ping-pong setprio : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("ping-pong setprio", dout);
+        us = run_pp<1, 13>(p, 40, dA, nbuf); printf("  f16x2 pp setprio, activations as plane pairs by LDS-DMA : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("pp A planes", dout);
+        us = run_pp<1, 13>(p, 40, dA, 1); printf("  f16x2 pp setprio, A plane pairs by DMA, ONE buffer (cache-resident) : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6);
         us = run_pp<1, 5>(p, 40, dA, nbuf); printf("  f16x2 pp setprio, split in the compute phase : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("pp split in C", dout);
         us = run_pp<0, 5>(p, 40, dA, nbuf); printf("  f16x2 pp (no setprio), split in the compute phase : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("pp split in C", dout);
         us = run_pp<1, 4>(p, 40, dA, nbuf); printf("  f16x2 pp setprio, activations two periods ahead : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("pp A x2", dout);
@@ -644,7 +698,7 @@ int main(int argc, char** argv) {
             src.x = dA[0]; lin(&src, 1, M, N, db, 0, dout2, N, nullptr); CK(hipDeviceSynchronize());
             printf("  bf16x3 (library)        : %7.1f us  %6.1f TF\n", ms * 1e3 / 40, flop / (ms * 1e3 / 40) * 1e-6); check("bf16x3", dout2);
         }
-        for (int i = 0; i < nbuf; ++i) CK(hipFree(dA[i]));
+        for (int i = 0; i < nbuf; ++i) { CK(hipFree(dA[i])); CK(hipFree(dAp[i])); }
         CK(hipFree(dW)); CK(hipFree(db)); CK(hipFree(dcs)); CK(hipFree(dp)); CK(hipFree(dp3)); CK(hipFree(dout)); CK(hipFree(dout2));
     }
     return 0;
