@@ -163,6 +163,11 @@ __device__ __forceinline__ bool dvq_argmin_better(float v, int i, float bv, int 
 int dvq_launch_gemm(const GemmParams& p, GemmEpilogue epi, hipStream_t stream);
 int dvq_launch_gemm_bf16x3(const GemmParams& p, GemmEpilogue epi, hipStream_t stream);
 int dvq_launch_gemm_f16x2(const GemmParams& p, GemmEpilogue epi, hipStream_t stream);
+// 1 .. DVQ_GEMM_GROUP_MAX gated GEMMs that do not depend on each other: one launch where the launch COUNT is what costs (fp16
+// planes, same M <= 256 and N), a launch each otherwise.  Results are those of dvq_launch_gemm(ps[i], EPI_GATE) bit for bit.
+constexpr int DVQ_GEMM_GROUP_MAX = 3;
+int dvq_launch_gemm_gate_group(const GemmParams* ps, int n, hipStream_t stream);
+int dvq_launch_gemm_f16x2_gate_group(const GemmParams* ps, int n, hipStream_t stream);   // < 0: not applicable, nothing launched
 // 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split-bf16 (default); env DVQ_GEMM=fp32|bf16x3
 int dvq_gemm_mode();
 

@@ -575,7 +575,7 @@ __device__ __forceinline__ int skinny_col(int g, int j) {
 // NB column groups per wave (2 when the launch has several row groups: they share the activation split, the larger part of a
 // k-step's instructions)
 template <int EPI, int R, int NB, int PF>
-__global__ __launch_bounds__(64) void gemm_f16x2_skinny_kernel(const GemmParams p, int T, int groups) {
+__device__ __forceinline__ void skinny_body(const GemmParams& p, int T, int groups) {
     const int lane = threadIdx.x;
     const int lr = lane & 15, lc = lane >> 4;
     const long mb0 = (long)blockIdx.y * 16;
@@ -656,6 +656,23 @@ __global__ __launch_bounds__(64) void gemm_f16x2_skinny_kernel(const GemmParams 
     }
 }
 
+template <int EPI, int R, int NB, int PF>
+__global__ __launch_bounds__(64) void gemm_f16x2_skinny_kernel(const GemmParams p, int T, int groups) {
+    skinny_body<EPI, R, NB, PF>(p, T, groups);
+}
+
+// Up to three gated GEMMs of one shape that do not depend on each other -- the three columns of a row of the PixelCNN's vertical
+// stack (pixelcnn.hip) -- in ONE launch, problem = blockIdx.z: a B = 1 call is a chain of dependent launches of ~9 us each, and
+// this takes 90 of its ~470 GEMM launches away.  Every output is computed by the instruction sequence of the single launch.
+struct GemmGroup {
+    GemmParams p[DVQ_GEMM_GROUP_MAX];
+    int T[DVQ_GEMM_GROUP_MAX];
+};
+template <int R, int NB, int PF>
+__global__ __launch_bounds__(64) void gemm_f16x2_skinny_gate_group_kernel(const GemmGroup g, int groups) {
+    skinny_body<EPI_GATE, R, NB, PF>(g.p[blockIdx.z], g.T[blockIdx.z], groups);
+}
+
 constexpr long SKINNY_MAX_M = 256;     // above this the tiled kernel wins (every row group re-reads the weight panel from L2)
 
 template <int EPI, int R>
@@ -690,6 +707,33 @@ int launch_skinny(const GemmParams& p, hipStream_t stream) {
         }
     }
     DVQ_CHECK_LAUNCH("gemm_f16x2_skinny");
+    return DVQ_OK;
+}
+
+template <int R>
+void launch_skinny_gate_group_r(const GemmGroup& g, int n, int gy, hipStream_t stream) {
+    const int groups = (g.p[0].N / 64) * (32 / R);
+    if (gy >= 3) DVQ_LAUNCH((gemm_f16x2_skinny_gate_group_kernel<R, 2, 4>), dim3((unsigned)((groups + 1) / 2), (unsigned)gy, (unsigned)n), dim3(64), 0, stream, g, groups);
+    else DVQ_LAUNCH((gemm_f16x2_skinny_gate_group_kernel<R, 1, 8>), dim3((unsigned)groups, (unsigned)gy, (unsigned)n), dim3(64), 0, stream, g, groups);
+}
+
+int launch_skinny_gate_group(const GemmParams* ps, int n, hipStream_t stream) {
+    GemmGroup g = {};
+    double flops = 0, bytes = 0;
+    for (int i = 0; i < n; ++i) {
+        g.p[i] = ps[i];
+        double ksum = 0;
+        for (int s = 0; s < ps[i].nsrc; ++s) { ksum += ps[i].src[s].K; g.T[i] += ps[i].src[s].K / BK; }
+        flops += 2.0 * (double)ps[i].M * ps[i].N * ksum;
+        bytes += ((double)ps[i].M + ps[i].N) * ksum * 4;
+    }
+    const int gy = (int)((ps[0].M + 15) / 16);
+    const int want = dvq_knobs().gemm_skinny_cols;          // as launch_skinny: the same width, hence the same kernel body per output
+    {
+        DVQ_PROF("gemm_gate", flops, bytes, stream);
+        if (want == 4) launch_skinny_gate_group_r<4>(g, n, gy, stream); else launch_skinny_gate_group_r<8>(g, n, gy, stream);
+    }
+    DVQ_CHECK_LAUNCH("gemm_f16x2_skinny_group");
     return DVQ_OK;
 }
 
@@ -745,7 +789,7 @@ __global__ void f16x2_split_kernel(const float* __restrict__ w, long total, int 
 }  // namespace
 
 // Called by dvq_launch_gemm (gemm_f32.hip) after argument validation, when every source carries f16x2 planes.
-int dvq_launch_gemm_f16x2(const GemmParams& p, GemmEpilogue epi, hipStream_t stream) {
+static int check_f16x2(const GemmParams& p, GemmEpilogue epi) {
     DVQ_REQUIRE(p.wscale, "gemm_f16x2: planes without row scales");
     for (int s = 0; s < p.nsrc; ++s) {
         const GemmSrc& g = p.src[s];
@@ -756,6 +800,20 @@ int dvq_launch_gemm_f16x2(const GemmParams& p, GemmEpilogue epi, hipStream_t str
     DVQ_REQUIRE(a_ok, "gemm_f16x2: activation rows are not 16-byte aligned");
     if (epi == EPI_GATE)
         DVQ_REQUIRE(dvq_aligned16(p.out) && p.ldo % 4 == 0 && (!p.pre || (dvq_aligned16(p.pre) && p.ldpre % 4 == 0)), "gemm_f16x2: gate outputs are not 16-byte aligned");
+    return DVQ_OK;
+}
+
+// Called by dvq_launch_gemm_gate_group (gemm_f32.hip) with 2 .. DVQ_GEMM_GROUP_MAX validated gated problems of one (M, N), all on
+// fp16 planes.  Returns DVQ_OK after ONE launch, or a negative value when the group has to run as single launches (M beyond the
+// skinny kernel, DVQ_GEMM_SKINNY=0).
+int dvq_launch_gemm_f16x2_gate_group(const GemmParams* ps, int n, hipStream_t stream) {
+    if (!dvq_knobs().gemm_skinny || ps[0].M > SKINNY_MAX_M) return -1;
+    for (int i = 0; i < n; ++i) DVQ_PROPAGATE(check_f16x2(ps[i], EPI_GATE));
+    return launch_skinny_gate_group(ps, n, stream);
+}
+
+int dvq_launch_gemm_f16x2(const GemmParams& p, GemmEpilogue epi, hipStream_t stream) {
+    DVQ_PROPAGATE(check_f16x2(p, epi));
     if (dvq_knobs().gemm_skinny && p.M <= SKINNY_MAX_M) switch (epi) {
         case EPI_BIAS: return launch_skinny<EPI_BIAS>(p, stream);
         case EPI_RESID: return launch_skinny<EPI_RESID>(p, stream);

@@ -165,7 +165,7 @@ int dvq_gemm_mode() {
     return mode;
 }
 
-int dvq_launch_gemm(const GemmParams& p, GemmEpilogue epi, hipStream_t stream) {
+static int check_gemm(const GemmParams& p) {
     DVQ_REQUIRE(p.nsrc >= 1 && p.nsrc <= DVQ_MAX_SRC, "gemm: nsrc=%d out of range", p.nsrc);
     DVQ_REQUIRE(p.M > 0 && p.N > 0, "gemm: empty problem M=%ld N=%d", p.M, p.N);
     DVQ_REQUIRE(((p.M + BM - 1) / BM + 7) / 8 * 8 * ((p.N + BN - 1) / BN) < (1L << 31), "gemm: grid too large");
@@ -176,17 +176,47 @@ int dvq_launch_gemm(const GemmParams& p, GemmEpilogue epi, hipStream_t stream) {
         DVQ_REQUIRE(dvq_aligned16(g.A) && dvq_aligned16(g.W) && g.lda % 4 == 0 && g.ldw % 4 == 0,
                     "gemm: source %d rows are not 16-byte aligned", s);
     }
+    return DVQ_OK;
+}
+
+// fp16 three-product planes (the default packing): every source must carry them, with one row-scale array for the launch.
+// *use = 1 when the problem runs on them (validated), 0 when no source carries them.
+static int check_f16x2_planes(const GemmParams& p, GemmEpilogue epi, int* use) {
+    *use = 0;
+    int n16 = 0;
+    for (int s = 0; s < p.nsrc; ++s) n16 += (p.src[s].Wp && p.src[s].wp_kind == DVQ_PLANES_F16X2) ? 1 : 0;
+    if (!n16) return DVQ_OK;
+    DVQ_REQUIRE(n16 == p.nsrc, "gemm: %d of %d sources carry fp16 planes (all or none)", n16, p.nsrc);
+    DVQ_REQUIRE(p.out && (epi != EPI_RESID || p.resid), "gemm: null output/residual");
+    DVQ_REQUIRE(epi != EPI_GATE || (p.N % BN == 0 && (!p.cls || p.label)), "gemm: gated epilogue needs N %% 128 == 0 (N=%d) and labels with a class bias", p.N);
+    *use = 1;
+    return DVQ_OK;
+}
+
+int dvq_launch_gemm_gate_group(const GemmParams* ps, int n, hipStream_t stream) {
+    DVQ_REQUIRE(ps && n >= 1 && n <= DVQ_GEMM_GROUP_MAX, "gemm group: %d problems", n);
+    bool one = n >= 2 && dvq_gemm_mode() == 1;
+    for (int i = 0; i < n && one; ++i) {
+        int use = 0;
+        DVQ_PROPAGATE(check_gemm(ps[i]));
+        DVQ_PROPAGATE(check_f16x2_planes(ps[i], EPI_GATE, &use));
+        one = use && ps[i].M == ps[0].M && ps[i].N == ps[0].N;
+    }
+    if (one) {
+        const int rc = dvq_launch_gemm_f16x2_gate_group(ps, n, stream);
+        if (rc >= 0) return rc;
+    }
+    for (int i = 0; i < n; ++i) DVQ_PROPAGATE(dvq_launch_gemm(ps[i], EPI_GATE, stream));
+    return DVQ_OK;
+}
+
+int dvq_launch_gemm(const GemmParams& p, GemmEpilogue epi, hipStream_t stream) {
+    DVQ_PROPAGATE(check_gemm(p));
     const bool split = dvq_gemm_mode() == 1 && epi != EPI_ARGMIN;     // the exact VQ argmin stays on the fp32 chain
     if (split && (epi == EPI_BIAS || epi == EPI_RESID || epi == EPI_GATE)) {
-        // fp16 three-product planes (the default packing): every source must carry them, with one row-scale array for the launch
-        int n16 = 0;
-        for (int s = 0; s < p.nsrc; ++s) n16 += (p.src[s].Wp && p.src[s].wp_kind == DVQ_PLANES_F16X2) ? 1 : 0;
-        if (n16) {
-            DVQ_REQUIRE(n16 == p.nsrc, "gemm: %d of %d sources carry fp16 planes (all or none)", n16, p.nsrc);
-            DVQ_REQUIRE(p.out && (epi != EPI_RESID || p.resid), "gemm: null output/residual");
-            DVQ_REQUIRE(epi != EPI_GATE || (p.N % BN == 0 && (!p.cls || p.label)), "gemm: gated epilogue needs N %% 128 == 0 (N=%d) and labels with a class bias", p.N);
-            return dvq_launch_gemm_f16x2(p, epi, stream);
-        }
+        int use = 0;
+        DVQ_PROPAGATE(check_f16x2_planes(p, epi, &use));
+        if (use) return dvq_launch_gemm_f16x2(p, epi, stream);
     }
     switch (epi) {
         case EPI_BIAS:

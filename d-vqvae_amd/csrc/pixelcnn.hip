@@ -177,8 +177,11 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
             for (int l = 0; l < L; ++l) {
                 const dvq_pixelcnn_layer& ly = w->layers_host[l];
                 const int k = (l == 0) ? 5 : 3, pad = k / 2, KR = k / 2 + 1;
+                GemmParams grp[GRID];                                    // the row's columns do not depend on each other: one launch where
+                int ngrp = 0;                                            // the launch count is what costs (dvq_launch_gemm_gate_group)
                 for (int c = 0; c < GRID; ++c) {
-                    GemmParams g = {};
+                    GemmParams& g = grp[ngrp];
+                    g = GemmParams{};
                     int ns = 0;
                     for (int kr = 0; kr < KR; ++kr) {
                         if (l == 0 && kr == KR - 1) continue;            // mask 'A': last kernel row
@@ -214,8 +217,9 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
                     g.ldo = dim;
                     g.pre = pre;
                     g.ldpre = 2 * dim;
-                    DVQ_PROPAGATE(dvq_launch_gemm(g, EPI_GATE, st));
+                    ++ngrp;
                 }
+                if (ngrp) DVQ_PROPAGATE(dvq_launch_gemm_gate_group(grp, ngrp, st));
             }
             // ---- horizontal stack + head + draw, position by position
             for (int c = 0; c < GRID; ++c) {
