@@ -183,6 +183,7 @@ struct DvqKnobs {
     int gemm_skinny;      // 0: tiled kernels also for M <= 256 (DVQ_GEMM_SKINNY=0; the two must agree bitwise)
     int gemm_skinny_cols; // f16x2 skinny kernel: output columns per wave, 16 / 8 / 4 (DVQ_GEMM_SKINNY_COLS; 0 = by the launch's size; same bits)
     int pn_filter;        // 0 six-product trunk, 1 default, 2 filtered trunk whatever the tile fill
+    int pn_tail;          // 1 (default): a cloud's 1 .. 32 points beyond a multiple of 256 as a one-block tail tile (DVQ_PN_TAIL=0: a full tile)
     int pn_exhaustive;    // 1: exact stage evaluates every point (what the filter must reproduce bit for bit)
     int pn_caps[2];       // candidate-list capacities (tests shrink them to reach the overflow paths); <= 0: default
     long pn_chunk;        // samples per PointNet launch (<= 0: what 6 GB of scratch hold)

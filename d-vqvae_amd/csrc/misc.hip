@@ -33,6 +33,7 @@ DvqKnobs* read_knobs() {
     k->gemm_skinny_cols = (int)num("DVQ_GEMM_SKINNY_COLS");
     k->vq_rows_delay = getenv("DVQ_VQ_ROWS_DELAY") ? (int)num("DVQ_VQ_ROWS_DELAY") : 0;
     k->pn_filter = is("DVQ_PN_FILTER", '0') ? 0 : (is("DVQ_PN_FILTER", '2') ? 2 : 1);
+    k->pn_tail = is("DVQ_PN_TAIL", '0') ? 0 : 1;
     k->pn_exhaustive = is("DVQ_PN_EXHAUSTIVE", '1');
     k->pn_caps[0] = k->pn_caps[1] = -1;
     if (const char* e = getenv("DVQ_PN_CAPS")) {

@@ -122,7 +122,10 @@ int trunk(const float* pc, int C, int N, long Bc, const float* trans, const floa
     // filtered trunk (pointnet_filter.hip) when its 256-point tiles are at least 3/4 full: padding slots repeat real points, and
     // many repeats mean many ties for the exact stage (N = 300 in two tiles: 4.6 ms against 3.6 ms for the six-product trunk)
     const int fm = filter_mode();
-    if (w2p && w3f && dvq_gemm_mode() == 1 && fm && N <= 16384 && (fm == 2 || 4L * N >= 3L * ((N + 255) / 256) * 256))
+    const int tiles256 = (N + 255) / 256, over = N - 256 * (tiles256 - 1);
+    // slots the filtered trunk evaluates: whole tiles, or whole tiles + a 32-point tail block (pointnet_filter.hip)
+    const long slots = (tiles256 >= 2 && over <= 32 && dvq_knobs().pn_tail) ? 256L * (tiles256 - 1) + 32 : 256L * tiles256;
+    if (w2p && w3f && dvq_gemm_mode() == 1 && fm && N <= 16384 && (fm == 2 || 4L * N >= 3L * slots))
         return dvq_launch_pn_trunk_filter(pc, C, N, s.Npad, Bc, trans, w1, b1, w2, w2p, b2, w3f, w3, b3, relu3, s.h2, s.part, s.tstat,
                                           s.cbuf, feat, ld_feat, dvq_knobs().pn_stats ? s.stats : nullptr, st);
     if (w2p && w3p && dvq_gemm_mode() == 1) {       // fused trunk; w3p is the k-permuted plane image (see pn_trunk_kernel)

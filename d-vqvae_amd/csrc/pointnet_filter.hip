@@ -51,6 +51,7 @@ constexpr int F_OFF_TI = F_OFF_SC + 64;                   // [1024] 1 / (channel
 constexpr int F_OFF_CS = F_OFF_TI + 4096;                 // [128] centre of the sample
 constexpr int F_OFF_WS = F_OFF_CS + 512;                  // [3][4] per-wave |h|max, |d|max, |rd|max
 constexpr int F_LDS = F_OFF_WS + 64;                      // 72 064 B -> 2 workgroups per CU
+constexpr int F_LDS_TAIL = F_LDS + 4 * 512;               // tail kernel: one centre per wave (its own sample) behind the common image
 static_assert(F_OFF_W1 >= 2 * F_STAGE2, "the conv3 stages and the triple buffer cover the W2 region");
 
 // h - x with h the low (HI = 0) or high (HI = 1) fp16 half of hp: one v_fma_mix_f32, exact
@@ -153,16 +154,24 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // Points are dealt to the tiles round robin and to the 256 slots of a tile (wave, block, lane) through a multiplicative
 // permutation: neighbours in the cloud's order -- often neighbours in space, i.e. near ties -- land in different waves.
-__device__ __forceinline__ int point_of_slot(int tile, int slot, int tiles) { return ((slot * 67) & 255) * tiles + tile; }
+// ``deal`` tiles share the first 256 * deal points this way.  A cloud with 1 .. 32 points beyond a multiple of 256 (the 778 hand
+// vertices: 3 * 256 + 10) gets them as a TAIL tile (index deal) of ONE 32-point block instead of a fourth full tile that is
+// three quarters padding: point 256 * deal + (slot & 31) (callers fold indices >= N back with % N, as for every padding slot).
+__device__ __forceinline__ int point_of_slot(int tile, int slot, int deal) {
+    return tile < deal ? ((slot * 67) & 255) * deal + tile : 256 * deal + (slot & 31);
+}
 // id bits of a tracked score: [3:0] accumulator register, [4] point block, [5] lane half, [7:6] wave -> slot inside the tile
 __device__ __forceinline__ int slot_of_id(unsigned id) {
     const int e = id & 15, pb = (id >> 4) & 1, h = (id >> 5) & 1, w = (id >> 6) & 3;
     return w * 64 + pb * 32 + 8 * (e >> 2) + 4 * h + (e & 3);
 }
 
-template <int C>
+// TAIL = false: one workgroup per (sample, dealt tile), blockIdx.x = sample * deal + tile (no workgroup for a tail tile: launched
+// and left at once they would all sit on two of the eight XCDs -- blockIdx % 4 == 3 -- and idle a quarter of the chip).  TAIL = true: the tail tiles of FOUR samples per workgroup, one per wave (one 32-point block each;
+// the staged W2 / W3 images are shared, everything per sample is per wave: centre, scales, records).
+template <int C, bool TAIL>
 __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __restrict__ pc, const float* __restrict__ trans,
-                                                                 int N, int Npad, int tiles, const float* __restrict__ W1,
+                                                                 int N, int Npad, int tiles, int deal, long B, const float* __restrict__ W1,
                                                                  const float* __restrict__ b1, const uint16_t* __restrict__ W2p,
                                                                  const float* __restrict__ b2, const char* __restrict__ w3f,
                                                                  float* __restrict__ h2buf, f32x4* __restrict__ part,
@@ -176,13 +185,17 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     float* b2s = reinterpret_cast<float*>(fl + F_OFF_B2);
     float* scs = reinterpret_cast<float*>(fl + F_OFF_SC);
     float* tis = reinterpret_cast<float*>(fl + F_OFF_TI);
-    float* cs = reinterpret_cast<float*>(fl + F_OFF_CS);
     float* wst = reinterpret_cast<float*>(fl + F_OFF_WS);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const long b = blockIdx.x / tiles;
-    const int tile = blockIdx.x % tiles;
+    constexpr int NPB = TAIL ? 1 : 2;                       // 32-point blocks per wave
+    const long b_raw = TAIL ? (long)blockIdx.x * 4 + wave : (long)(blockIdx.x / deal);
+    const bool live = !TAIL || b_raw < B;                  // tail: the last workgroup's surplus waves work on sample B - 1, store nothing
+    const long b = live ? b_raw : B - 1;
+    const int tile = TAIL ? deal : (int)(blockIdx.x % deal);
+    const long rec = b * tiles + tile;                     // (sample, tile) record
+    float* cs = reinterpret_cast<float*>(fl + (TAIL ? F_LDS + 512 * wave : F_OFF_CS));
 
     const unsigned long long t_start = (abl & 4096) ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long t_a = 0, t_b = 0, t_c = 0;
@@ -192,13 +205,14 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     if (tid < 64) b1s[tid] = b1[tid];
     if (tid < 128) b2s[tid] = b2[tid];
     *reinterpret_cast<f32x4*>(tis + 4 * tid) = *reinterpret_cast<const f32x4*>(w3f + 1024 * 256 + 16 * tid);
-    if (tid < 128) cs[tid] = cbuf[b * 128 + tid];
+    if (TAIL) { cs[lane] = cbuf[b * 128 + lane]; cs[64 + lane] = cbuf[b * 128 + 64 + lane]; }
+    else if (tid < 128) cs[tid] = cbuf[b * 128 + tid];
 
-    float xin[2][4];
-    int pidx[2];
+    float xin[NPB][4];
+    int pidx[NPB];
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb) {
-        int p = point_of_slot(tile, wave * 64 + pb * 32 + r, tiles);
+    for (int pb = 0; pb < NPB; ++pb) {
+        int p = point_of_slot(tile, TAIL ? r : wave * 64 + pb * 32 + r, deal);
         pidx[pb] = p;
         if (p >= N) p %= N;                               // padding slots repeat real points cyclically (a max ignores repeats; a point
                                                           // repeated once costs nothing: both copies carry ids that map back to it)
@@ -225,9 +239,9 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     }
 
     // ---- conv1 + conv2 (six-product split-bf16), h2 = relu(conv2 + b2) kept in fp32: hv[pb][16 t4 + e]
-    float hv[2][64];
+    float hv[NPB][64];
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb) {
+    for (int pb = 0; pb < NPB; ++pb) {
         qbf16x8 h1f[4][3];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -263,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
                 const int ch = 32 * t4 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 hv[pb][16 * t4 + e] = fmaxf(acc[e] + b2s[ch], 0.f);
             }
-            if (pidx[pb] < N && !(abl & 1)) {             // natural channel order: 4 consecutive channels per 16-byte store
+            if (pidx[pb] < N && live && !(abl & 1)) {     // natural channel order: 4 consecutive channels per 16-byte store
                 float* dst = h2buf + ((b * Npad + pidx[pb]) * 128 + 32 * t4 + 4 * h);
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
@@ -282,12 +296,12 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
             const f32x4 c4 = *reinterpret_cast<const f32x4*>(cs + 32 * t4 + 8 * g + 4 * h);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                hv[0][16 * t4 + 4 * g + i] -= c4[i];
-                hv[1][16 * t4 + 4 * g + i] -= c4[i];
+#pragma unroll
+                for (int pb = 0; pb < NPB; ++pb) hv[pb][16 * t4 + 4 * g + i] -= c4[i];
             }
         }
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb) {
+    for (int pb = 0; pb < NPB; ++pb) {
         float sq = 0.f;
 #pragma unroll
         for (int i = 0; i < 64; ++i) sq = fmaf(hv[pb][i], hv[pb][i], sq);
@@ -304,10 +318,10 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     }
     // conv3's A operand, one fp16 plane: step = 2 t4 + q, k order inside a step as conv2's accumulator delivers it;
     // rn2 = largest squared norm of a row's rounding residual (scaled units)
-    qf16x8 a3[2][8];
+    qf16x8 a3[NPB][8];
     float rn2 = 0.f;
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb) {
+    for (int pb = 0; pb < NPB; ++pb) {
         float sq = 0.f;
         const float s_pb = s_w;
 #pragma unroll
@@ -335,9 +349,11 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         const float hm = (dmx + cnorm) * 1.0001f;          // |h_p| <= |h_p - c| + |c|
         scs[wave] = 1.0f / s_w;
         wst[wave] = hm; wst[4 + wave] = dmx; wst[8 + wave] = rdm;
-        atomicMax(tstat + 4 * blockIdx.x + 0, __float_as_uint(hm));
-        atomicMax(tstat + 4 * blockIdx.x + 1, __float_as_uint(dmx));
-        atomicMax(tstat + 4 * blockIdx.x + 2, __float_as_uint(rdm));
+        if (live) {
+            atomicMax(tstat + 4 * rec + 0, __float_as_uint(hm));
+            atomicMax(tstat + 4 * rec + 1, __float_as_uint(dmx));
+            atomicMax(tstat + 4 * rec + 2, __float_as_uint(rdm));
+        }
     }
     __syncthreads();                                      // everybody is done with W2 in the stages; scs visible
     if (abl & 4096) t_c = __builtin_amdgcn_s_memtime();
@@ -355,18 +371,24 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         const float* src = tb + (c & 7) * 1024;
         const float ti = tis[64 * c + lane];
         const float pub_wn = wnorm_g[64 * c + lane], pub_rn = rnorm_g[64 * c + lane];
-        const float hm = fmaxf(fmaxf(wst[0], wst[1]), fmaxf(wst[2], wst[3])) * 1.00001f;
-        const float dmx = fmaxf(fmaxf(wst[4], wst[5]), fmaxf(wst[6], wst[7])) * 1.00001f;
-        const float rdm = fmaxf(fmaxf(wst[8], wst[9]), fmaxf(wst[10], wst[11])) * 1.00001f;
+        // the tile's maxima: over its four waves -- over the publishing wave alone where every wave is a tile of its own (TAIL)
+        const float hm = (TAIL ? wst[wave] : fmaxf(fmaxf(wst[0], wst[1]), fmaxf(wst[2], wst[3]))) * 1.00001f;
+        const float dmx = (TAIL ? wst[4 + wave] : fmaxf(fmaxf(wst[4], wst[5]), fmaxf(wst[6], wst[7]))) * 1.00001f;
+        const float rdm = (TAIL ? wst[8 + wave] : fmaxf(fmaxf(wst[8], wst[9]), fmaxf(wst[10], wst[11]))) * 1.00001f;
         const float e2 = 2.0f * fmaf(pub_rn, dmx, fmaf(pub_wn, rdm, fmaf(C_ID * pub_wn, dmx, 2.0f * DELTA * pub_wn * hm)));
         float v1[4], v2[4], u0[4], u1[4];
         float c1 = NEG_BIG, c2 = NEG_BIG, c3 = NEG_BIG;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            const float q0 = src[w * 256 + lane], q1 = src[w * 256 + 64 + lane];
-            const float f = scs[w] * ti;
-            u0[w] = src[w * 256 + 128 + lane] * f;
-            u1[w] = src[w * 256 + 192 + lane] * f;
+            if (TAIL && w > 0) {                           // one wave = the whole tile: it is "wave 0" of its record
+                u0[w] = NEG_BIG; u1[w] = NEG_BIG; v1[w] = NEG_BIG; v2[w] = NEG_BIG;
+                continue;
+            }
+            const int ws = TAIL ? wave : w;                // whose triples
+            const float q0 = src[ws * 256 + lane], q1 = src[ws * 256 + 64 + lane];
+            const float f = scs[ws] * ti;
+            u0[w] = src[ws * 256 + 128 + lane] * f;
+            u1[w] = src[ws * 256 + 192 + lane] * f;
             v1[w] = __uint_as_float((__float_as_uint(q0 * f) & ~0xC0u) | (unsigned)(w << 6));
             v2[w] = __uint_as_float((__float_as_uint(q1 * f) & ~0xC0u) | (unsigned)(w << 6));
             c3 = __builtin_amdgcn_fmed3f(c2, c3, v1[w]); c2 = __builtin_amdgcn_fmed3f(c1, c2, v1[w]); c1 = max_nc(c1, v1[w]);
@@ -386,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
                 if (v2[w] >= thr && v2[w] < c3) flags |= 1u << (2 * w + ((__float_as_uint(v2[w]) >> 5) & 1u));
             }
         }
-        part[((long)blockIdx.x) * 1024 + 64 * c + lane] = f32x4{c1, c2, c3, __uint_as_float(flags)};
+        if (live) part[rec * 1024 + 64 * c + lane] = f32x4{c1, c2, c3, __uint_as_float(flags)};
     };
     // one 32-point x 32-channel block: 8 MFMAs; its 32 scores per lane go through the top-three chain (4 vector
     // instructions per score) while the NEXT block's MFMAs run: 1 MFMA (32 cycles of the matrix pipe) per 8 chain instructions
@@ -433,6 +455,37 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         }
     };
     int stage = 0;
+    if constexpr (TAIL) {
+        // one point block per wave: two MFMA blocks (channels 0..31, 32..63) and two chains per chunk; every wave publishes the
+        // eight chunks of ITS sample after chunk 7 and after chunk 15
+#pragma unroll 1
+        for (int c = 0; c < 16; ++c) {
+            __syncthreads();                              // chunk c is in its stage; the other stage and tb parity are free
+            if (c + 1 < 16) wreg = w3_load(w3h, 64 * (c + 1), wave, lane);
+            if (c == 8) {
+#pragma unroll 1
+                for (int q = 0; q < 8; ++q) publish(q);
+                __syncthreads();                          // before chunk 8's triples overwrite slot 0
+            }
+            const char* st = fl + stage * F_STAGE3;
+            qf16x8 wf0[8], wf1[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) wf0[s] = w3_frag(st, r, 2 * s + h);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) wf1[s] = w3_frag(st, 32 + r, 2 * s + h);
+            f32x16 accA, accB;
+            float a1 = NEG_BIG, a2 = NEG_BIG, a3m = NEG_BIG, q1 = NEG_BIG, q2 = NEG_BIG, q3 = NEG_BIG;
+            F_MFMA_BLOCK(accA, 0, wf0);
+            F_MFMA_BLOCK(accB, 0, wf1);
+            F_CHAIN_BLOCK(accA, 0, a1, a2, a3m);
+            F_INTERLEAVE();
+            F_CHAIN_BLOCK(accB, 0, q1, q2, q3);
+            finish(c, 0, a1, a2, a3m);
+            finish(c, 1, q1, q2, q3);
+            if (c + 1 < 16) w3_store(fl + (stage ^ 1) * F_STAGE3, wave, lane, wreg);
+            stage ^= 1;
+        }
+    } else {
     f32x16 accP;                                          // the chunk's last accumulator block, scored under the next chunk's first MFMAs
     float pb1 = NEG_BIG, pb2 = NEG_BIG, pb3 = NEG_BIG;
     bool pending = false;
@@ -484,18 +537,22 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         if (c + 1 < 16 && !(abl & 1024)) w3_store(fl + (stage ^ 1) * F_STAGE3, wave, lane, wreg);
         stage ^= 1;
     }
+    }
 #undef F_MFMA_BLOCK
 #undef F_CHAIN_BLOCK
 #undef F_INTERLEAVE
     __syncthreads();
-    if (!(abl & 256)) {
+    if constexpr (TAIL) {
+#pragma unroll 1
+        for (int q = 8; q < 16; ++q) publish(q);
+    } else if (!(abl & 256)) {
         publish(8 + 2 * wave);
         publish(8 + 2 * wave + 1);
     }
     if ((abl & 4096) && tid == 0) {                        // diagnostics: phase durations in units of 64 ticks, 8 bits each
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
         auto q = [](unsigned long long d) { d >>= 6; return (unsigned)(d > 255 ? 255 : d); };
-        tstat[4 * blockIdx.x + 3] = q(t_a - t_start) | (q(t_b - t_a) << 8) | (q(t_c - t_b) << 16) | (q((t_end - t_c) >> 3) << 24);
+        tstat[4 * rec + 3] = q(t_a - t_start) | (q(t_b - t_a) << 8) | (q(t_c - t_b) << 16) | (q((t_end - t_c) >> 3) << 24);
     }
 }
 
@@ -545,7 +602,7 @@ __device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k &
 constexpr int PAIR_CAP = 1024;
 constexpr int FB_CAP = 512;
 constexpr int SORT_CAP = 3072;                            // (channel, point) pairs evaluated in point order; more: channel order
-__global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restrict__ part, int tiles, const float* __restrict__ h2buf,
+__global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restrict__ part, int tiles, int deal, const float* __restrict__ h2buf,
                                                        int N, int Npad, const float* __restrict__ w3, const float* __restrict__ b3,
                                                        const float* __restrict__ wnorm, const float* __restrict__ rnorm,
                                                        const unsigned* __restrict__ tstat, int relu, int exhaustive,
@@ -627,7 +684,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
 #pragma unroll
             for (int k = 0; k < 3; ++k)
                 if (q[k] + et >= lb) {
-                    int p = point_of_slot(t, slot_of_id(__float_as_uint(q[k]) & 255u), tiles);
+                    int p = point_of_slot(t, slot_of_id(__float_as_uint(q[k]) & 255u), deal);
                     if (p >= N) p %= N;                      // a padding slot: the real point it repeats
                     if (abl & 16) p &= 63;
                     bool seen = false;                       // a repeated point (padding slots) is evaluated once
@@ -794,7 +851,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
 #pragma unroll
             for (int u = 0; u < 8; ++u) {                   // this group's 8 of the half's 32 points (both point blocks)
                 const int i = 8 * (g & 3) + u, e = i & 15;
-                int p = point_of_slot(t, 64 * w + 32 * (i >> 4) + 8 * (e >> 2) + 4 * hh + (e & 3), tiles);
+                int p = point_of_slot(t, 64 * w + 32 * (i >> 4) + 8 * (e >> 2) + 4 * hh + (e & 3), deal);   // tail tile: both halves of i name its one block
                 if (p >= N) p %= N;
                 const float* hr = h2 + (long)p * 128 + 8 * j;
                 ha[u] = *reinterpret_cast<const f32x4*>(hr);
@@ -943,24 +1000,32 @@ int dvq_launch_pn_trunk_filter(const float* pc, int C, int N, int Npad, long B, 
                                unsigned long long* stats, hipStream_t st) {
     const int tiles = (N + 255) / 256;
     DVQ_REQUIRE(tiles <= MAX_TILES, "pointnet: the filtered trunk takes at most %d points", MAX_TILES * 256);
+    // 1 .. 32 points beyond a multiple of 256 (the 778 MANO vertices: 3 x 256 + 10): a tail tile of one block, four samples per
+    // workgroup, instead of a last full tile of padding (DVQ_PN_TAIL=0: the full tile, for A/B runs; same features bit for bit)
+    const int over = N - 256 * (tiles - 1);
+    const int deal = (tiles >= 2 && over <= 32 && dvq_knobs().pn_tail) ? tiles - 1 : tiles;
     static DvqOncePerDevice attr_once;
     {
         const hipError_t e = attr_once.run([] {
-            const hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_trunk_filter_kernel<3>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
-            const hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_trunk_filter_kernel<4>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
-            return e3 != hipSuccess ? e3 : e4;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_trunk_filter_kernel<3, false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_trunk_filter_kernel<4, false>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_trunk_filter_kernel<3, true>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_TAIL);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_trunk_filter_kernel<4, true>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_TAIL);
+            return e;
         });
         if (e != hipSuccess) {
             dvq_set_error("pointnet: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return DVQ_ELAUNCH;
         }
     }
-    const long grid = B * tiles;
-    DVQ_REQUIRE(grid < (1L << 31), "pointnet: grid too large");
+    const long grid = B * deal;
+    DVQ_REQUIRE(B * tiles < (1L << 31), "pointnet: grid too large");
     DVQ_REQUIRE(Npad >= N, "pointnet: bad padded row count");
-    if (hipMemsetAsync(tstat, 0, (size_t)grid * 16, st) != hipSuccess ||
+    if (hipMemsetAsync(tstat, 0, (size_t)B * tiles * 16, st) != hipSuccess ||
         (stats && hipMemsetAsync(stats, 0, 64, st) != hipSuccess)) {
         dvq_set_error("pointnet: hipMemsetAsync failed");
         return DVQ_ELAUNCH;
@@ -972,7 +1037,7 @@ int dvq_launch_pn_trunk_filter(const float* pc, int C, int N, int Npad, long B, 
         else DVQ_LAUNCH(pn_center_kernel<4>, dim3(cgrid), dim3(256), 0, st, pc, trans, N, B, W1, b1, W2, b2, cbuf);
     }
     DVQ_CHECK_LAUNCH("pn_center");
-    const double pts = (double)B * tiles * 256;
+    const double pts = (double)B * (deal * 256 + (deal < tiles ? 32 : 0));
 #ifdef DVQ_DIAG
     const char* abl_e = getenv("DVQ_PN_ABL");              // timing-only ablations / phase stamps: diagnostics build only
     const int abl = abl_e ? atoi(abl_e) : 0;
@@ -982,11 +1047,20 @@ int dvq_launch_pn_trunk_filter(const float* pc, int C, int N, int Npad, long B, 
     {
         DVQ_PROF("pn_trunk", 2.0 * pts * (4.0 * 64 + 64.0 * 128 + 128.0 * 1024), pts * (16 + 512) + (double)grid * 16384, st);
         if (C == 3)
-            DVQ_LAUNCH(pn_trunk_filter_kernel<3>, dim3((unsigned)grid), dim3(256), F_LDS, st, pc, trans, N, Npad, tiles, W1, b1, W2p,
+            DVQ_LAUNCH((pn_trunk_filter_kernel<3, false>), dim3((unsigned)grid), dim3(256), F_LDS, st, pc, trans, N, Npad, tiles, deal, B, W1, b1, W2p,
                        b2, (const char*)w3f, h2buf, (f32x4*)part, tstat, cbuf, abl);
         else
-            DVQ_LAUNCH(pn_trunk_filter_kernel<4>, dim3((unsigned)grid), dim3(256), F_LDS, st, pc, trans, N, Npad, tiles, W1, b1, W2p,
+            DVQ_LAUNCH((pn_trunk_filter_kernel<4, false>), dim3((unsigned)grid), dim3(256), F_LDS, st, pc, trans, N, Npad, tiles, deal, B, W1, b1, W2p,
                        b2, (const char*)w3f, h2buf, (f32x4*)part, tstat, cbuf, abl);
+        if (deal < tiles) {
+            const unsigned tgrid = (unsigned)((B + 3) / 4);
+            if (C == 3)
+                DVQ_LAUNCH((pn_trunk_filter_kernel<3, true>), dim3(tgrid), dim3(256), F_LDS_TAIL, st, pc, trans, N, Npad, tiles, deal, B, W1, b1, W2p,
+                           b2, (const char*)w3f, h2buf, (f32x4*)part, tstat, cbuf, abl);
+            else
+                DVQ_LAUNCH((pn_trunk_filter_kernel<4, true>), dim3(tgrid), dim3(256), F_LDS_TAIL, st, pc, trans, N, Npad, tiles, deal, B, W1, b1, W2p,
+                           b2, (const char*)w3f, h2buf, (f32x4*)part, tstat, cbuf, abl);
+        }
     }
     DVQ_CHECK_LAUNCH("pn_trunk_filter");
     const DvqKnobs& kn = dvq_knobs();
@@ -998,23 +1072,24 @@ int dvq_launch_pn_trunk_filter(const float* pc, int C, int N, int Npad, long B, 
     }
     {
         DVQ_PROF("pn_exact", 2.0 * (double)B * 1024 * 128, (double)B * (tiles * 16384.0 + 1024.0 * 512 + 4096), st);
-        DVQ_LAUNCH(pn_exact_kernel, dim3((unsigned)B), dim3(256), 0, st, (const f32x4*)part, tiles, h2buf, N, Npad, w3, b3,
+        DVQ_LAUNCH(pn_exact_kernel, dim3((unsigned)B), dim3(256), 0, st, (const f32x4*)part, tiles, deal, h2buf, N, Npad, w3, b3,
                    reinterpret_cast<const float*>((const char*)w3f + 1024 * 256 + 4096),
                    reinterpret_cast<const float*>((const char*)w3f + 1024 * 256 + 8192), tstat, relu, exhaustive, pair_cap, fb_cap,
                    feat, ld_feat, stats, abl);
     }
     DVQ_CHECK_LAUNCH("pn_exact");
     if (stats && (abl & 4096)) {
-        std::vector<unsigned> ts((size_t)grid * 4);
+        const long nrec = B * tiles;                       // a tail tile's record carries its workgroup's stamps too
+        std::vector<unsigned> ts((size_t)nrec * 4);
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(ts.data(), tstat, ts.size() * 4, hipMemcpyDeviceToHost);
         double a = 0, b2_ = 0, c = 0, d = 0;
-        for (long i = 0; i < grid; ++i) {
+        for (long i = 0; i < nrec; ++i) {
             const unsigned v = ts[4 * i + 3];
             a += v & 255; b2_ += (v >> 8) & 255; c += (v >> 16) & 255; d += (v >> 24) & 255;
         }
         fprintf(stderr, "[dvq pn] mean phase ticks per workgroup (s_memtime, 100 MHz?): start->loaded %.0f, conv1+conv2 %.0f, centre/convert %.0f, conv3 loop %.0f\n",
-                a / grid * 64, b2_ / grid * 64, c / grid * 64, d / grid * 512);
+                a / nrec * 64, b2_ / nrec * 64, c / nrec * 64, d / nrec * 512);
     }
     if (stats) {                                          // diagnostics (DVQ_PN_STATS=1): synchronises
         unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -268,7 +268,8 @@ def _with_env(key, val, fn):
         _lib.load().dvq_reload_env()
 
 
-@pytest.mark.parametrize("C,N,B", [(4, 1024, 6), (3, 778, 5), (4, 100, 3), (4, 3000, 2), (3, 257, 3), (4, 1, 2)])
+@pytest.mark.parametrize("C,N,B", [(4, 1024, 6), (3, 778, 5), (4, 100, 3), (4, 3000, 2), (3, 257, 3), (4, 1, 2),
+                                   (4, 769, 5), (3, 800, 6), (4, 801, 3), (3, 288, 7), (4, 2056, 2)])
 def test_pointnet_filter_equals_exhaustive_exact_evaluation(C, N, B):
     """The fp16 matrix-core filter of conv3 + max never changes the result: the feature is bit-identical to the maximum of
     the exact fp32 score over ALL points (DVQ_PN_EXHAUSTIVE=1 makes pn_exact_kernel evaluate exactly that), and within the
@@ -283,6 +284,23 @@ def test_pointnet_filter_equals_exhaustive_exact_evaluation(C, N, B):
     feat6, trans6, _ = _with_env("DVQ_PN_FILTER", "0", lambda: net(x))
     assert_close(trans, trans6, atol=TOL, what="filtered trunk vs six-product trunk (trans)")
     assert_close(feat, feat6, atol=TOL, what="filtered trunk vs six-product trunk (feat)")
+
+
+@pytest.mark.parametrize("C,N,B", [(3, 778, 1030), (4, 769, 9), (3, 800, 6), (4, 257, 5), (3, 2080, 3)])
+def test_pointnet_filter_tail_tile_equals_full_tile(C, N, B):
+    """A cloud with 1 .. 32 points beyond a multiple of 256 (the 778 MANO vertices) runs its last points as a ONE-block tail tile,
+    four samples per workgroup (B = 1030: a last workgroup with two surplus waves), instead of a last full tile of padding
+    (DVQ_PN_TAIL=0).  Both are the exact maximum over all points of the same conv2 rows: the features must agree bit for bit, and
+    with the exhaustive evaluation."""
+    net, _ = _pointnet(C, SEED + 3 * C)
+    x = gpu(synth.synthetic_clouds(B, N, seed=900 + N, channels=C))
+    # DVQ_PN_FILTER=2: the filtered trunk also where, without the tail tile, the default prefers the six-product one (N = 257)
+    feat, trans, _ = _with_env("DVQ_PN_FILTER", "2", lambda: net(x))
+    feat0, trans0, _ = _with_env("DVQ_PN_FILTER", "2", lambda: _with_env("DVQ_PN_TAIL", "0", lambda: net(x)))
+    assert torch.equal(trans, trans0) and torch.equal(feat, feat0), "tail tile != full tile"
+    n = min(B, 64)
+    feat_all, trans_all, _ = _with_env("DVQ_PN_FILTER", "2", lambda: _with_env("DVQ_PN_EXHAUSTIVE", "1", lambda: net(x[:n].contiguous())))
+    assert torch.equal(trans[:n], trans_all) and torch.equal(feat[:n], feat_all), "tail tile != exhaustive"
 
 
 def test_pointnet_filter_full_machine_repeatability():
@@ -317,6 +335,15 @@ def test_pointnet_filter_fresh_clouds_full_machine_stress():
             d = (feat != want).any(1)
             assert not bool(d.any()), (f"seed {seed}, {name}, call {call}: clouds {d.nonzero().flatten().tolist()[:5]} of 65 536 differ "
                                        f"from the exhaustive evaluation")
+    # the hand encoder's shape: 778 points = three dealt tiles + the one-block tail tile (four samples per workgroup)
+    blk = gpu(synth.synthetic_clouds(4096, 778, seed=seed + 1, channels=3))
+    big = blk.repeat(16, 1, 1).contiguous()
+    want = _with_env("DVQ_PN_EXHAUSTIVE", "1", lambda: net.recon_encoder(blk)[0]).repeat(16, 1)
+    for call in range(3):
+        feat = net.recon_encoder(big)[0]
+        d = (feat != want).any(1)
+        assert not bool(d.any()), (f"seed {seed}, recon_encoder (N = 778), call {call}: clouds {d.nonzero().flatten().tolist()[:5]} of 65 536 "
+                                   f"differ from the exhaustive evaluation")
 
 
 def test_pointnet_filter_list_overflow_paths():
