@@ -22,6 +22,7 @@ _lock = threading.Lock()
 _lib = None
 
 DVQ_MAX_SRC = 8
+ABI_VERSION = 6            # DVQ_ABI_VERSION of include/dvq.h, which the struct mirrors below follow (tests/test_abi.py compares both with the library's)
 PLANES_BF16X3, PLANES_F16X2 = 0, 1
 
 c_f32p = C.c_void_p      # device pointers travel as integers
@@ -159,6 +160,10 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)     # AttributeError here = header and library out of sync
             fn.restype = res
             fn.argtypes = args
+        got = lib.dvq_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} implements ABI version {got}, these bindings mirror version {ABI_VERSION} of include/dvq.h: "
+                               "rebuild the library (`make -C d-vqvae_amd/csrc`)")
         _lib = lib
         return lib
 

@@ -12,7 +12,7 @@ void dvq_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* dvq_last_error(void) { return g_err; }
-extern "C" int dvq_abi_version(void) { return 6; }
+extern "C" int dvq_abi_version(void) { return DVQ_ABI_VERSION; }
 
 // ---------------------------------------------------------------- environment knobs, read once (dvq_internal.h)
 namespace {

@@ -37,6 +37,9 @@ typedef enum {
     DVQ_ENODEVICE = 4
 } dvq_status;
 
+/* The version of this header.  dvq_abi_version() returns the library's: a binding checks the two for equality at load time
+ * (struct layouts change between versions). */
+#define DVQ_ABI_VERSION 6
 int dvq_abi_version(void);
 const char* dvq_last_error(void);
 /* number of visible HIP devices, or -1; does not create a context */

@@ -1,6 +1,7 @@
 """CPU-side checks of the C-ABI library: it is built, loads, and exports every symbol include/dvq.h declares
 (no compute calls: there is no GPU here)."""
 import os
+import sys
 import re
 
 from dvqvae_amd import _lib
@@ -16,7 +17,15 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in sorted(declared) if not hasattr(lib, n)]
     assert not missing, f"declared in dvq.h but not exported: {missing}"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert lib.dvq_abi_version() == 6
+    header_version = int(re.search(r"#define\s+DVQ_ABI_VERSION\s+(\d+)", text).group(1))
+    assert lib.dvq_abi_version() == header_version == _lib.ABI_VERSION, "library, header and Python struct mirrors must be one ABI version"
+
+
+def test_graft_entry_build_passes():
+    """The driver's build check: compiles every HIP source, the oracle's C part, loads the library and imports the package."""
+    import importlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    importlib.import_module("__graft_entry__").build()
 
 
 def test_workspace_queries_need_no_gpu():
