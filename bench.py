@@ -119,18 +119,21 @@ def pmc_traffic(kind, batch):
     (None, None) if there is none.  Not measured in this run: PMC collection needs rocprofv3 around the process."""
     if batch != 65536:
         return None, None
-    names = {"vq_fast": "::vq_stream",         # vq_stream16_kernel (default) / vq_stream_kernel (DVQ_VQ_KERNEL=8)
-             "pn_trunk": "pn_trunk_filter_kernel<4>", "pn_exact": "pn_exact_kernel",
-             # template-argument lists print as "<2, true>": match up to the first argument
-             "gemm_gate": "gemm_f16x2_pp_kernel<2>", "gemm_bias": "gemm_f16x2_pp_kernel<0>", "gemm_resid": "gemm_f16x2_pp_kernel<1>"}
+    # template-argument lists print as "<2, 4>" (epilogue, 16-column blocks per wave; "<2>" in files collected before the
+    # 128 x 128 variant existed): every spelling a committed file may hold
+    names = {"vq_fast": ("::vq_stream",),      # vq_stream16_kernel (default) / vq_stream_kernel (DVQ_VQ_KERNEL=8)
+             "pn_trunk": ("pn_trunk_filter_kernel<4, false>", "pn_trunk_filter_kernel<4>"), "pn_exact": ("pn_exact_kernel",),
+             "gemm_gate": ("gemm_f16x2_pp_kernel<2, 4>", "gemm_f16x2_pp_kernel<2>"),
+             "gemm_bias": ("gemm_f16x2_pp_kernel<0, 4>", "gemm_f16x2_pp_kernel<0>"),
+             "gemm_resid": ("gemm_f16x2_pp_kernel<1, 4>", "gemm_f16x2_pp_kernel<1>")}
     if GEMM_MODE == "bf16x3":
-        names.update({"gemm_gate": "gemm_bf16x3_wide_kernel<2,", "gemm_bias": "gemm_bf16x3_wide_kernel<0,", "gemm_resid": "gemm_bf16x3_wide_kernel<1,"})
+        names.update({"gemm_gate": ("gemm_bf16x3_wide_kernel<2,",), "gemm_bias": ("gemm_bf16x3_wide_kernel<0,",), "gemm_resid": ("gemm_bf16x3_wide_kernel<1,",)})
     try:
         import glob
         path = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))[-1]
         doc = json.load(open(path))
         for row in doc["per_launch_bytes"]:
-            if names.get(kind, "?") in row["kernel"]:
+            if any(nm in row["kernel"] for nm in names.get(kind, ())):
                 return row["hbm_bytes_corrected"], f"profiles/{os.path.basename(path)} (rocprofv3 PMC passes of {doc.get('collected', 'an earlier run')})"
     except Exception:
         pass

@@ -160,6 +160,20 @@ __device__ __forceinline__ bool dvq_argmin_better(float v, int i, float bv, int 
     return v < bv || (v == bv && i < bi);
 }
 
+// compute units of the current device (cached per device; 256 if the runtime does not say)
+inline int dvq_num_cus() {
+    static int cus[128] = {0};
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d &= 127;
+    int v = __atomic_load_n(&cus[d], __ATOMIC_RELAXED);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) v = 256;
+        __atomic_store_n(&cus[d], v, __ATOMIC_RELAXED);
+    }
+    return v;
+}
+
 int dvq_launch_gemm(const GemmParams& p, GemmEpilogue epi, hipStream_t stream);
 int dvq_launch_gemm_bf16x3(const GemmParams& p, GemmEpilogue epi, hipStream_t stream);
 int dvq_launch_gemm_f16x2(const GemmParams& p, GemmEpilogue epi, hipStream_t stream);
@@ -177,6 +191,7 @@ int dvq_gemm_mode();
 struct DvqKnobs {
     int gemm_wide;        // 0: 128 x 128 kernels only
     int gemm_dephase;
+    int gemm_tn;          // 0 (default): the tiled f16x2 kernel picks 128 x 256 or 128 x 128 tiles per launch; 128 / 256 force one (DVQ_GEMM_TN)
     int vq_kernel;        // 16 (default): vq_stream16.hip; 8: vq_stream.hip's eight-wave kernel; 32: vq_rows.hip (DVQ_VQ_KERNEL)
     int vq_rows_delay;    // vq_rows.hip: start delay of the second half of the grid, 10 ns ticks (DVQ_VQ_ROWS_DELAY)
     int gemm_skinny_prefetch;   // 0: no helper workgroups (DVQ_GEMM_SKINNY_PREFETCH=0)

@@ -168,9 +168,10 @@ __device__ __forceinline__ void f16x2_store_gate(const GemmParams& p, long m, in
     *reinterpret_cast<f32x4*>(p.out + m * p.ldo + c) = o;
 }
 
-template <int EPI>
-__device__ __forceinline__ void f16x2_epilogue(const GemmParams& p, f32x4 (&hi)[4][4], f32x4 (&lo)[4][4], long m0w, int n0w, int c0w,
+template <int EPI, int NJ = 4>
+__device__ __forceinline__ void f16x2_epilogue(const GemmParams& p, f32x4 (&hi)[NJ][4], f32x4 (&lo)[NJ][4], long m0w, int n0w, int c0w,
                                                int lane) {
+    static_assert(NJ == 4 || EPI != EPI_GATE, "the gate pairs a wave's tanh columns with their partners 32 columns further");
     const int lr = lane & 15, lc = lane >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -179,13 +180,14 @@ __device__ __forceinline__ void f16x2_epilogue(const GemmParams& p, f32x4 (&hi)[
         if constexpr (EPI == EPI_BIAS || EPI == EPI_RESID) {
             const bool vec_ok = (p.N % 4 == 0) && (p.ldo % 4 == 0) && (EPI != EPI_RESID || p.ldr % 4 == 0);
 #pragma unroll
-            for (int jn = 0; jn < 4; ++jn) {
+            for (int jn = 0; jn < NJ; ++jn) {
                 const int n = n0w + jn * 16 + 4 * lc;
                 if (n >= p.N) continue;
                 const bool full = vec_ok && n + 3 < p.N;
                 f16x2_store_block<EPI>(p, m, n, f16x2_combine(hi[jn][i], lo[jn][i], p.wscale, n, full), full);
             }
         } else if constexpr (EPI == EPI_GATE) {
+            if constexpr (NJ == 4) {
             if (n0w >= p.N) continue;                      // N % 128 == 0: a wave's 64 columns are all inside or all outside
             const float* crow = p.cls ? p.cls + (long)p.label[m] * p.N : nullptr;
 #pragma unroll
@@ -194,6 +196,7 @@ __device__ __forceinline__ void f16x2_epilogue(const GemmParams& p, f32x4 (&hi)[
                 const int na = n0w + nl;
                 f16x2_store_gate(p, m, na, c0w + nl, f16x2_combine(hi[jn][i], lo[jn][i], p.wscale, na, true),
                                  f16x2_combine(hi[jn + 2][i], lo[jn + 2][i], p.wscale, na + 32, true), crow);
+            }
             }
         }
     }
@@ -300,6 +303,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(const GemmParams p) 
 // had not waited for yet (one differing result hash in four bench runs) -- not kept: every load phase starts with vmcnt(0).
 constexpr int PP_STAGES = 3;
 constexpr size_t PP_SMEM = PP_STAGES * STAGE;               // 147 456 B
+constexpr size_t PP_SMEM_N128 = PP_STAGES * (2 * A_PL + 2 * 128 * 64);   // 98 304 B (128 x 128 tile)
 
 struct PpCursorA {
     int s, k_left;
@@ -321,18 +325,21 @@ struct PpCursorA {
     }
 };
 
+// NJ = 16-column blocks per wave: 4 -> the 128 x 256 tile, 2 -> a 128 x 128 tile (launches whose 128 x 256 tiles would leave half
+// the CUs idle: the short-N GEMMs of an 8 192-row batch -- one rank's share of the benchmark batch on eight GPUs)
+template <int NJ>
 struct PpCursorW {
     int s, k_left;
-    const uint16_t* w_ptr[4];
+    const uint16_t* w_ptr[NJ];
     __device__ __forceinline__ void open(const GemmParams& p, int src_i, int n0, int wave, int lane) {
         s = src_i;
         if (s >= p.nsrc) { k_left = 0; return; }
         const GemmSrc& src = p.src[s];
         k_left = src.K;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {                      // 32 pieces of 16 rows x 64 B (two planes x 256 rows), four per wave
-            const int id = wave * 4 + i;
-            const int pl = id >> 4, rb = id & 15;
+        for (int i = 0; i < NJ; ++i) {                     // 8 NJ pieces of 16 rows x 64 B (two planes x 64 NJ rows), NJ per wave
+            const int id = wave * NJ + i;
+            const int pl = id / (4 * NJ), rb = id % (4 * NJ);
             const int row = rb * 16 + (lane >> 2);
             int n = n0 + row;
             if (n >= p.N) n = p.N - 1;
@@ -341,24 +348,25 @@ struct PpCursorW {
     }
     __device__ __forceinline__ void issue(char* stage, int wave) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int id = wave * 4 + i;
-            const int pl = id >> 4, rb = id & 15;
+        for (int i = 0; i < NJ; ++i) {
+            const int id = wave * NJ + i;
+            const int pl = id / (4 * NJ), rb = id % (4 * NJ);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)w_ptr[i],
-                                             (__attribute__((address_space(3))) void*)(stage + 2 * A_PL + pl * W_PL + rb * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(stage + 2 * A_PL + pl * (64 * NJ * 64) + rb * 1024), 16, 0, 0);
         }
     }
     __device__ __forceinline__ void advance(const GemmParams& p, int n0, int wave, int lane) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w_ptr[i] += BK;
+        for (int i = 0; i < NJ; ++i) w_ptr[i] += BK;
         k_left -= BK;
         if (k_left <= 0) open(p, s + 1, n0, wave, lane);
     }
 };
 
-template <int EPI>
+template <int EPI, int NJ>
 __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp_kernel(const GemmParams p, int T) {
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    constexpr int TN = 64 * NJ, W_PL = TN * 64, STAGE = 2 * A_PL + 2 * W_PL;      // this kernel's tile width (shadows the file's)
     const int tid = threadIdx.x;
     const int tiles_n = (p.N + TN - 1) / TN;
     const long tiles_m = (p.M + TM - 1) / TM;
@@ -374,7 +382,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp_kernel(const GemmParams 
     const int wm = wave >> 2, wn = wave & 3;
 
     PpCursorA ca;
-    PpCursorW cw;
+    PpCursorW<NJ> cw;
     ca.open(p, 0, m0, tid);
     cw.open(p, 0, n0, wave, lane);
     const int a_dst = (tid >> 2) * 64 + 16 * ((tid & 3) ^ swz16(tid >> 2));
@@ -405,9 +413,9 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp_kernel(const GemmParams 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    f32x4 hi[4][4], lo[4][4];                               // [jn][i]
+    f32x4 hi[NJ][4], lo[NJ][4];                             // [jn][i]
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NJ; ++a)
 #pragma unroll
         for (int c = 0; c < 4; ++c) { hi[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
@@ -417,13 +425,13 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp_kernel(const GemmParams 
     for (int t = 0; t < T; ++t) {
         // ---- load phase
         const char* st = smem_c + cur_st * STAGE;
-        h8 af[4][2], wf[4][2];
+        h8 af[4][2], wf[NJ][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
                 af[i][pl] = *reinterpret_cast<const h8*>(st + pl * A_PL + (wm * 64 + i * 16) * 64 + rd);
-                wf[i][pl] = *reinterpret_cast<const h8*>(st + 2 * A_PL + pl * W_PL + (wn * 64 + i * 16) * 64 + rd);
+                if (i < NJ) wf[i][pl] = *reinterpret_cast<const h8*>(st + 2 * A_PL + pl * W_PL + (wn * 16 * NJ + i * 16) * 64 + rd);
             }
         // Everything this wave issued in its previous load phase (a period ago) has landed before it passes this phase's barrier:
         // the DMA pieces of tile t + 1 -- read by everybody from the next load phase on -- and the activations converted below.
@@ -440,15 +448,15 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp_kernel(const GemmParams 
         // ---- compute phase: hi: (a1 w1); lo: (a1 w2) then (a2 w1) -- per output the order of gemm_f16x2_kernel
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int jn = 0; jn < 4; ++jn)
+        for (int jn = 0; jn < NJ; ++jn)
 #pragma unroll
             for (int i = 0; i < 4; ++i) hi[jn][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[jn][0], af[i][0], hi[jn][i], 0, 0, 0);
 #pragma unroll
-        for (int jn = 0; jn < 4; ++jn)
+        for (int jn = 0; jn < NJ; ++jn)
 #pragma unroll
             for (int i = 0; i < 4; ++i) lo[jn][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[jn][1], af[i][0], lo[jn][i], 0, 0, 0);
 #pragma unroll
-        for (int jn = 0; jn < 4; ++jn)
+        for (int jn = 0; jn < NJ; ++jn)
 #pragma unroll
             for (int i = 0; i < 4; ++i) lo[jn][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[jn][0], af[i][1], lo[jn][i], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
@@ -457,7 +465,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp_kernel(const GemmParams 
         nx_st = nx_st == PP_STAGES - 1 ? 0 : nx_st + 1;
     }
     if (wave < 4) __builtin_amdgcn_s_barrier();            // pairs with the late half's extra barrier
-    f16x2_epilogue<EPI>(p, hi, lo, m0 + wm * 64, n0 + wn * 64, (n0 >> 1) + wn * 32, lane);
+    f16x2_epilogue<EPI, NJ>(p, hi, lo, m0 + wm * 64, n0 + wn * 16 * NJ, (n0 >> 1) + wn * 32, lane);
 }
 
 // Measured and not kept (round 4): a 128 x 128 tile with four waves and two 32 KiB stages, TWO workgroups per CU, for the short-K
@@ -475,8 +483,11 @@ int launch_tiled(const GemmParams& p, hipStream_t stream) {
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM);
             const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_kernel<EPI, true>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM);
-            const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_pp_kernel<EPI>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_SMEM);
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_pp_kernel<EPI, 4>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_SMEM);
+            if constexpr (EPI != EPI_GATE)
+                if (e2 == hipSuccess) e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_pp_kernel<EPI, 2>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_SMEM_N128);
             return e0 != hipSuccess ? e0 : (e1 != hipSuccess ? e1 : e2);
         });
         if (e != hipSuccess) {
@@ -487,6 +498,16 @@ int launch_tiled(const GemmParams& p, hipStream_t stream) {
     const long tiles_m = (p.M + TM - 1) / TM;
     const long tiles_n = (p.N + TN - 1) / TN;
     const long grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
+    // 128 x 128 tiles where they take fewer rounds of workgroups per unit of work (one workgroup per CU either way): e.g. M = 8 192,
+    // N = 512 is 128 tiles of 128 x 256 -- half the chip -- or 256 of 128 x 128.  DVQ_GEMM_TN=128 / 256 forces one (A/B runs, same bits).
+    bool narrow = false;
+    if constexpr (EPI != EPI_GATE) {
+        const long tiles_n2 = (p.N + 127) / 128, cus = dvq_num_cus();
+        const long r256 = (tiles_m * tiles_n + cus - 1) / cus, r128 = (tiles_m * tiles_n2 + cus - 1) / cus;
+        narrow = r128 < 2 * r256;
+        if (dvq_knobs().gemm_tn == 128) narrow = true;
+        if (dvq_knobs().gemm_tn == 256) narrow = false;
+    }
     static const char* const names[] = {"gemm_bias", "gemm_resid", "gemm_gate"};
     double ksum = 0;
     int T = 0;
@@ -494,7 +515,12 @@ int launch_tiled(const GemmParams& p, hipStream_t stream) {
     {
         DVQ_PROF(names[EPI], 2.0 * (double)p.M * p.N * ksum, ((double)p.M + p.N) * ksum * 4, stream);
         const int mode = dvq_knobs().gemm_dephase;          // DVQ_GEMM_DEPHASE: 2 (default) ping-pong, 1 two stages dephased, 0 two stages in lock step
-        if (mode == 2) DVQ_LAUNCH((gemm_f16x2_pp_kernel<EPI>), dim3((unsigned)grid), dim3(512), PP_SMEM, stream, p, T);
+        if (mode == 2 && narrow) {
+            if constexpr (EPI != EPI_GATE) {
+                const long grid2 = ((tiles_m + 7) / 8) * 8 * ((p.N + 127) / 128);
+                DVQ_LAUNCH((gemm_f16x2_pp_kernel<EPI, 2>), dim3((unsigned)grid2), dim3(512), PP_SMEM_N128, stream, p, T);
+            }
+        } else if (mode == 2) DVQ_LAUNCH((gemm_f16x2_pp_kernel<EPI, 4>), dim3((unsigned)grid), dim3(512), PP_SMEM, stream, p, T);
         else if (mode == 1) DVQ_LAUNCH((gemm_f16x2_kernel<EPI, true>), dim3((unsigned)grid), dim3(512), SMEM, stream, p);
         else DVQ_LAUNCH((gemm_f16x2_kernel<EPI, false>), dim3((unsigned)grid), dim3(512), SMEM, stream, p);
     }

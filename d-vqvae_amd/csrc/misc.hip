@@ -23,6 +23,7 @@ DvqKnobs* read_knobs() {
     auto is = [](const char* name, char c) { const char* e = getenv(name); return e && e[0] == c; };
     auto num = [](const char* name) { const char* e = getenv(name); return e ? atol(e) : 0L; };
     k->gemm_wide = !is("DVQ_GEMM_WIDE", '0');
+    k->gemm_tn = (int)num("DVQ_GEMM_TN");
     k->gemm_dephase = is("DVQ_GEMM_DEPHASE", '0') ? 0 : (is("DVQ_GEMM_DEPHASE", '1') ? 1 : 2);    // f16x2 tiled kernel: 2 = ping-pong (default)
     k->gemm_skinny = is("DVQ_GEMM_SKINNY", '0') ? 0 : (is("DVQ_GEMM_SKINNY", '2') ? 2 : 1);   // 2: the register-staged variant
     {

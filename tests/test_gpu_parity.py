@@ -1020,6 +1020,8 @@ net = GatedPixelCNN(512, 512, 15, 128); load_synth(net, 5); net = net.to(dev)
 g = torch.Generator().manual_seed(1)
 x = torch.randint(0, 512, (150, 3, 3), generator=g).to(dev); lab = torch.randint(0, 128, (150,), generator=g).to(dev)
 out["pixelcnn_logits"] = net(x, lab).cpu()
+x = torch.randint(0, 512, (700, 3, 3), generator=g).to(dev); lab = torch.randint(0, 128, (700,), generator=g).to(dev)
+out["pixelcnn_logits_700"] = net(x, lab).cpu()                  # beyond the small-batch kernel: the tiled kernels' variants
 torch.save(out, sys.argv[1])
 """
 
@@ -1035,9 +1037,13 @@ def test_gemm_tile_variants_agree_bitwise(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for mode, knob in (("bf16x3", "DVQ_GEMM_WIDE"), ("f16x2", "DVQ_GEMM_DEPHASE")):
         outs = []
-        for tag, val in ((("a", "1"), ("b", "0"), ("a2", "1")) if mode == "bf16x3" else (("pp", "2"), ("two-stage", "0"), ("pp2", "2"), ("dephased", "1"))):
+        # f16x2 also: the ping-pong kernel's tile width (DVQ_GEMM_TN: 128 x 128 / 128 x 256 forced; default = chosen per launch)
+        variants = ((("a", "1"), ("b", "0"), ("a2", "1")) if mode == "bf16x3" else
+                    (("pp", "2"), ("two-stage", "0"), ("pp2", "2"), ("dephased", "1"), ("tn128", "2"), ("tn256", "2")))
+        for tag, val in variants:
             path = str(tmp_path / f"{mode}_{tag}.pt")
-            r = subprocess.run([sys.executable, "-c", _GEMM_VARIANT_SCRIPT, path, root], env=dict(os.environ, DVQ_GEMM=mode, **{knob: val}),
+            extra = {"DVQ_GEMM_TN": tag[2:]} if tag.startswith("tn") else {}
+            r = subprocess.run([sys.executable, "-c", _GEMM_VARIANT_SCRIPT, path, root], env=dict(os.environ, DVQ_GEMM=mode, **{knob: val}, **extra),
                                capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
             outs.append(torch.load(path))
