@@ -346,23 +346,25 @@ def test_pointnet_filter_fresh_clouds_full_machine_stress():
                                    f"differ from the exhaustive evaluation")
 
 
-def test_pointnet_filter_list_overflow_paths():
+@pytest.mark.parametrize("N", [1500, 1290])
+def test_pointnet_filter_list_overflow_paths(N):
     """pn_exact_kernel's candidate lists are finite; with the capacities shrunk (DVQ_PN_CAPS) the overflow paths -- a wave
-    evaluated instead of a dropped pair, a thread walking a wave by itself -- must give the same bits."""
+    evaluated instead of a dropped pair, a thread walking a wave by itself -- must give the same bits (N = 1290: with a tail tile)."""
     net, _ = _pointnet(4, SEED + 5)
-    x = gpu(synth.synthetic_clouds(3, 1500, seed=11, channels=4))
+    x = gpu(synth.synthetic_clouds(3, N, seed=11, channels=4))
     feat, trans, _ = net(x)
     for caps in ("7,2048", "4096,3", "0,0", "100,1"):
         f2, t2, _ = _with_env("DVQ_PN_CAPS", caps, lambda: net(x))
         assert torch.equal(trans, t2) and torch.equal(feat, f2), f"caps {caps}"
 
 
-def test_pointnet_filter_ties_scales_and_degenerate_clouds():
+@pytest.mark.parametrize("N", [700, 780])
+def test_pointnet_filter_ties_scales_and_degenerate_clouds(N):
     """Duplicate points (exact ties: all three tracked scores equal -> whole-cloud evaluation), clouds scaled by 1e-4 and
-    1e4 (per-wave power-of-two scaling), an all-zero cloud, one huge outlier point."""
+    1e4 (per-wave power-of-two scaling), an all-zero cloud, one huge outlier point.  N = 780: three dealt tiles + a tail tile."""
     net, _ = _pointnet(4, SEED + 77)
-    base = synth.synthetic_clouds(4, 700, seed=5, channels=4)
-    cases = {"dup": base[:, :, torch.randint(0, 40, (700,), generator=torch.Generator().manual_seed(1))],
+    base = synth.synthetic_clouds(4, N, seed=5, channels=4)
+    cases = {"dup": base[:, :, torch.randint(0, 40, (N,), generator=torch.Generator().manual_seed(1))],
              "tiny": base * 1e-4, "huge": base * 1e4, "zero": torch.zeros_like(base)}
     out = base.clone()
     out[:, :3, 13] = 5e3
@@ -1062,9 +1064,9 @@ def test_pointnet_large_clouds_nonfinite_inputs_and_missing_filter_image():
     f_big, _, _ = net(big)
     f_big6, _, _ = _with_env("DVQ_PN_FILTER", "0", lambda: net(big))
     assert torch.equal(f_big, f_big6)
-    x = gpu(synth.synthetic_clouds(3, 500, seed=4, channels=4))
+    x = gpu(synth.synthetic_clouds(3, 520, seed=4, channels=4))        # two dealt tiles + a tail tile of 8 points
     x[1, 0, 17] = float("nan")
-    x[2, 2, 400] = float("inf")
+    x[2, 2, 515] = float("inf")                                        # in the tail tile
     feat, _, _ = net(x)
     ref, _, _ = net(x[:1].contiguous())
     assert torch.equal(feat[0], ref[0]) and torch.isfinite(feat[0]).all(), "a finite sample next to non-finite ones must not change"
