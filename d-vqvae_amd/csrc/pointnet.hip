@@ -69,9 +69,9 @@ struct PnScratch {
 PnScratch plan(int64_t B, int N, void* ws) {
     PnScratch s;
     s.Npad = (N + 255) / 256 * 256;                       // tiles of 128 (fused / unfused trunk) and of 256 (filtered trunk)
-    const size_t per_sample = (size_t)s.Npad * (64 + 128) * 4 + (size_t)s.Npad * 64 + (size_t)(s.Npad / 256) * 16 + 512 +
+    const size_t per_sample = (size_t)s.Npad * (64 + 128) * 4 + (size_t)s.Npad * 96 + (size_t)(s.Npad / 256) * 16 + 512 +
                               (1024 + 512 + 256 + 16 + 1) * 4;
-    const size_t budget = (size_t)6 << 30;
+    const size_t budget = (size_t)13 << 29;               // 6.5 GB: the benchmark batch in nine launches of 7 282 samples
     long chunk = (long)(budget / per_sample);
     {                                                     // samples per launch (default: what 6 GB of scratch hold)
         const long v = dvq_knobs().pn_chunk;
@@ -87,7 +87,7 @@ PnScratch plan(int64_t B, int N, void* ws) {
     auto take = [&](size_t n) { char* q = p; p += dvq_round_up(n, 256); return (float*)q; };
     s.h1 = take((size_t)chunk * s.Npad * 64 * 4);
     s.h2 = take((size_t)chunk * s.Npad * 128 * 4);
-    s.part = take((size_t)chunk * s.Npad * 64);           // [tiles128][1024] floats or [tiles256][1024] float4
+    s.part = take((size_t)chunk * s.Npad * 96);           // [tiles128][1024] floats, or [tiles256][1024] float4 + [tiles256][1024] float2
     s.tstat = (unsigned*)take((size_t)chunk * (s.Npad / 256) * 16);
     s.cbuf = take((size_t)chunk * 128 * 4);
     s.stats = (unsigned long long*)take(64);

@@ -5,7 +5,7 @@
 //      pn_trunk_kernel; the fp32 h2 rows [point][128] go to HBM.  conv3 (94 % of the trunk's FLOPs) is then evaluated as ONE
 //      fp16 product per term on CENTRED rows: d_p = h2_p - c (c = pn_center_kernel's mean of four rows of the sample; the
 //      argmax over the points does not depend on it), d scaled by a per-wave power of two, W3 by a per-channel power of
-//      two, both rounded to fp16.  Per (sample, 256-point tile, channel) the kernel emits the three largest approximate
+//      two, both rounded to fp16.  Per (sample, 256-point tile, channel) the kernel emits the FIVE largest approximate
 //      scores that carry the id of their point in the low mantissa bits, and one flag per wave (64 points) that holds
 //      further points in range whose ids were not kept.
 //   2. pn_exact_kernel: per (sample, channel) the estimate of a point's score is  approx + exact_dot(w_n, c)  with
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
                                                                  int N, int Npad, int tiles, int deal, long B, const float* __restrict__ W1,
                                                                  const float* __restrict__ b1, const uint16_t* __restrict__ W2p,
                                                                  const float* __restrict__ b2, const char* __restrict__ w3f,
-                                                                 float* __restrict__ h2buf, f32x4* __restrict__ part,
+                                                                 float* __restrict__ h2buf, f32x4* __restrict__ part, qf32x2* __restrict__ part2,
                                                                  unsigned* __restrict__ tstat, const float* __restrict__ cbuf,
                                                                  int abl_arg /* timing diagnostics only (DVQ_PN_ABL, -DDVQ_DIAG builds) */) {
     const int abl = DVQ_DIAG_ON ? abl_arg : 0;
@@ -364,7 +364,9 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     w3_store(fl, wave, lane, wreg);
     const float* wnorm_g = reinterpret_cast<const float*>(w3f + 1024 * 256 + 4096);
     const float* rnorm_g = reinterpret_cast<const float*>(w3f + 1024 * 256 + 8192);
-    // per channel of chunk c the three largest id-carrying scores of the tile (real units) and, per lane half of every wave
+    // per channel of chunk c the FIVE largest id-carrying scores of the tile (real units: three + the flags in a 16-byte record, the
+    // fourth and fifth in an 8-byte one that pn_exact_kernel reads only where the third is in range; with three, a tile holding a
+    // fourth point in range had its 32-point half evaluated in full -- 60 % of those evaluations) and, per lane half of every wave
     // (32 points), a flag "holds a point within 2 E of the tile's largest score that is not among the three".  Every wave publishes two chunks after
     // chunk 7 and after chunk 15 (all four busy at the same time: no wave waits for a publisher at the chunk barriers).
     auto publish = [&](int c) {
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         const float rdm = (TAIL ? wst[8 + wave] : fmaxf(fmaxf(wst[8], wst[9]), fmaxf(wst[10], wst[11]))) * 1.00001f;
         const float e2 = 2.0f * fmaf(pub_rn, dmx, fmaf(pub_wn, rdm, fmaf(C_ID * pub_wn, dmx, 2.0f * DELTA * pub_wn * hm)));
         float v1[4], v2[4], u0[4], u1[4];
-        float c1 = NEG_BIG, c2 = NEG_BIG, c3 = NEG_BIG;
+        float c1 = NEG_BIG, c2 = NEG_BIG, c3 = NEG_BIG, c4 = NEG_BIG, c5 = NEG_BIG;   // the tile's FIVE largest id-carrying scores
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             if (TAIL && w > 0) {                           // one wave = the whole tile: it is "wave 0" of its record
@@ -391,7 +393,9 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
             u1[w] = src[ws * 256 + 192 + lane] * f;
             v1[w] = __uint_as_float((__float_as_uint(q0 * f) & ~0xC0u) | (unsigned)(w << 6));
             v2[w] = __uint_as_float((__float_as_uint(q1 * f) & ~0xC0u) | (unsigned)(w << 6));
+            c5 = __builtin_amdgcn_fmed3f(c4, c5, v1[w]); c4 = __builtin_amdgcn_fmed3f(c3, c4, v1[w]);
             c3 = __builtin_amdgcn_fmed3f(c2, c3, v1[w]); c2 = __builtin_amdgcn_fmed3f(c1, c2, v1[w]); c1 = max_nc(c1, v1[w]);
+            c5 = __builtin_amdgcn_fmed3f(c4, c5, v2[w]); c4 = __builtin_amdgcn_fmed3f(c3, c4, v2[w]);
             c3 = __builtin_amdgcn_fmed3f(c2, c3, v2[w]); c2 = __builtin_amdgcn_fmed3f(c1, c2, v2[w]); c1 = max_nc(c1, v2[w]);
         }
         const float thr = c1 - e2;                         // NaN -> no flag here; pn_exact_kernel sees the non-finite bound
@@ -401,14 +405,17 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
             flags |= (u0[w] >= thr) ? (1u << (2 * w)) : 0u;
             flags |= (u1[w] >= thr) ? (2u << (2 * w)) : 0u;
         }
-        if (__builtin_amdgcn_ballot_w64(c3 >= thr) != 0) {  // three kept scores in range somewhere in the wave: a fourth id-carrying
+        if (__builtin_amdgcn_ballot_w64(c5 >= thr) != 0) {  // five kept scores in range somewhere in the wave: a sixth id-carrying
 #pragma unroll                                               // one may be in range and not kept -- its half is flagged too
             for (int w = 0; w < 4; ++w) {
-                if (v1[w] >= thr && v1[w] < c3) flags |= 1u << (2 * w + ((__float_as_uint(v1[w]) >> 5) & 1u));
-                if (v2[w] >= thr && v2[w] < c3) flags |= 1u << (2 * w + ((__float_as_uint(v2[w]) >> 5) & 1u));
+                if (v1[w] >= thr && v1[w] < c5) flags |= 1u << (2 * w + ((__float_as_uint(v1[w]) >> 5) & 1u));
+                if (v2[w] >= thr && v2[w] < c5) flags |= 1u << (2 * w + ((__float_as_uint(v2[w]) >> 5) & 1u));
             }
         }
-        if (live) part[rec * 1024 + 64 * c + lane] = f32x4{c1, c2, c3, __uint_as_float(flags)};
+        if (live) {
+            part[rec * 1024 + 64 * c + lane] = f32x4{c1, c2, c3, __uint_as_float(flags)};
+            part2[rec * 1024 + 64 * c + lane] = qf32x2{c4, c5};
+        }
     };
     // one 32-point x 32-channel block: 8 MFMAs; its 32 scores per lane go through the top-three chain (4 vector
     // instructions per score) while the NEXT block's MFMAs run: 1 MFMA (32 cycles of the matrix pipe) per 8 chain instructions
@@ -602,7 +609,8 @@ __device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k &
 constexpr int PAIR_CAP = 1024;
 constexpr int FB_CAP = 512;
 constexpr int SORT_CAP = 3072;                            // (channel, point) pairs evaluated in point order; more: channel order
-__global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restrict__ part, int tiles, int deal, const float* __restrict__ h2buf,
+__global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restrict__ part, const qf32x2* __restrict__ part2, int tiles, int deal,
+                                                       const float* __restrict__ h2buf,
                                                        int N, int Npad, const float* __restrict__ w3, const float* __restrict__ b3,
                                                        const float* __restrict__ wnorm, const float* __restrict__ rnorm,
                                                        const unsigned* __restrict__ tstat, int relu, int exhaustive,
@@ -635,6 +643,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
     __syncthreads();
     const float* h2 = h2buf + b * (long)Npad * 128;
     const f32x4* pt = part + b * (long)tiles * 1024;
+    const qf32x2* pt2 = part2 + b * (long)tiles * 1024;     // the fourth and fifth id-carrying scores: read only where the third is in range
     // ---- phase A
     unsigned n_single = 0, n_multi = 0, n_cand = 0, n_wave = 0;
     for (int n = tid; n < 1024; n += 256) {
@@ -681,23 +690,29 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
             const float et = bound(t);
             if (!(q[0] + et >= lb)) return;                 // the tile's largest score is out of range: so is the rest of it
             unsigned flags = __float_as_uint(q[3]) & 255u;
+            auto take = [&](float v) {                       // a kept score in range: its point becomes a candidate of the channel
+                int p = point_of_slot(t, slot_of_id(__float_as_uint(v) & 255u), deal);
+                if (p >= N) p %= N;                          // a padding slot: the real point it repeats
+                if (abl & 16) p &= 63;
+                bool seen = false;                           // a repeated point (padding slots) is evaluated once
+                for (int c2 = 0; c2 < min(cands, 4); ++c2) seen = seen || cand[n][c2] == (unsigned short)p;
+                if (seen) return;
+                if (cands < 4) cand[n][cands] = (unsigned short)p;
+                else {
+                    const int slot = atomicAdd(&pair_count, 1);
+                    if (slot < pair_cap) pair_list[slot] = n | (p << 10);
+                    else flags |= 1u << ((__float_as_uint(v) >> 5) & 7u);   // list full (never seen): evaluate its 32-point half instead
+                }
+                ++cands;
+            };
 #pragma unroll
             for (int k = 0; k < 3; ++k)
-                if (q[k] + et >= lb) {
-                    int p = point_of_slot(t, slot_of_id(__float_as_uint(q[k]) & 255u), deal);
-                    if (p >= N) p %= N;                      // a padding slot: the real point it repeats
-                    if (abl & 16) p &= 63;
-                    bool seen = false;                       // a repeated point (padding slots) is evaluated once
-                    for (int c2 = 0; c2 < min(cands, 4); ++c2) seen = seen || cand[n][c2] == (unsigned short)p;
-                    if (seen) continue;
-                    if (cands < 4) cand[n][cands] = (unsigned short)p;
-                    else {
-                        const int slot = atomicAdd(&pair_count, 1);
-                        if (slot < pair_cap) pair_list[slot] = n | (p << 10);
-                        else flags |= 1u << ((__float_as_uint(q[k]) >> 5) & 7u);   // list full (never seen): evaluate its 32-point half instead
-                    }
-                    ++cands;
-                }
+                if (q[k] + et >= lb) take(q[k]);
+            if (q[2] + et >= lb) {                           // all three in range: the record's second part (descending: c4 >= c5)
+                const qf32x2 q45 = pt2[(long)t * 1024 + n];
+                if (q45[0] + et >= lb) take(q45[0]);
+                if (q45[1] + et >= lb) take(q45[1]);
+            }
             while (flags) {
                 const int wh = __ffs(flags) - 1;             // 2 * wave + lane half
                 flags &= flags - 1;
@@ -1022,6 +1037,7 @@ int dvq_launch_pn_trunk_filter(const float* pc, int C, int N, int Npad, long B, 
             return DVQ_ELAUNCH;
         }
     }
+    qf32x2* part2 = reinterpret_cast<qf32x2*>((char*)part + (size_t)B * tiles * 1024 * 16);   // behind the float4 records (pointnet.hip: 96 B per padded point)
     const long grid = B * deal;
     DVQ_REQUIRE(B * tiles < (1L << 31), "pointnet: grid too large");
     DVQ_REQUIRE(Npad >= N, "pointnet: bad padded row count");
@@ -1048,18 +1064,18 @@ int dvq_launch_pn_trunk_filter(const float* pc, int C, int N, int Npad, long B, 
         DVQ_PROF("pn_trunk", 2.0 * pts * (4.0 * 64 + 64.0 * 128 + 128.0 * 1024), pts * (16 + 512) + (double)grid * 16384, st);
         if (C == 3)
             DVQ_LAUNCH((pn_trunk_filter_kernel<3, false>), dim3((unsigned)grid), dim3(256), F_LDS, st, pc, trans, N, Npad, tiles, deal, B, W1, b1, W2p,
-                       b2, (const char*)w3f, h2buf, (f32x4*)part, tstat, cbuf, abl);
+                       b2, (const char*)w3f, h2buf, (f32x4*)part, part2, tstat, cbuf, abl);
         else
             DVQ_LAUNCH((pn_trunk_filter_kernel<4, false>), dim3((unsigned)grid), dim3(256), F_LDS, st, pc, trans, N, Npad, tiles, deal, B, W1, b1, W2p,
-                       b2, (const char*)w3f, h2buf, (f32x4*)part, tstat, cbuf, abl);
+                       b2, (const char*)w3f, h2buf, (f32x4*)part, part2, tstat, cbuf, abl);
         if (deal < tiles) {
             const unsigned tgrid = (unsigned)((B + 3) / 4);
             if (C == 3)
                 DVQ_LAUNCH((pn_trunk_filter_kernel<3, true>), dim3(tgrid), dim3(256), F_LDS_TAIL, st, pc, trans, N, Npad, tiles, deal, B, W1, b1, W2p,
-                           b2, (const char*)w3f, h2buf, (f32x4*)part, tstat, cbuf, abl);
+                           b2, (const char*)w3f, h2buf, (f32x4*)part, part2, tstat, cbuf, abl);
             else
                 DVQ_LAUNCH((pn_trunk_filter_kernel<4, true>), dim3(tgrid), dim3(256), F_LDS_TAIL, st, pc, trans, N, Npad, tiles, deal, B, W1, b1, W2p,
-                           b2, (const char*)w3f, h2buf, (f32x4*)part, tstat, cbuf, abl);
+                           b2, (const char*)w3f, h2buf, (f32x4*)part, part2, tstat, cbuf, abl);
         }
     }
     DVQ_CHECK_LAUNCH("pn_trunk_filter");
@@ -1072,7 +1088,7 @@ int dvq_launch_pn_trunk_filter(const float* pc, int C, int N, int Npad, long B, 
     }
     {
         DVQ_PROF("pn_exact", 2.0 * (double)B * 1024 * 128, (double)B * (tiles * 16384.0 + 1024.0 * 512 + 4096), st);
-        DVQ_LAUNCH(pn_exact_kernel, dim3((unsigned)B), dim3(256), 0, st, (const f32x4*)part, tiles, deal, h2buf, N, Npad, w3, b3,
+        DVQ_LAUNCH(pn_exact_kernel, dim3((unsigned)B), dim3(256), 0, st, (const f32x4*)part, part2, tiles, deal, h2buf, N, Npad, w3, b3,
                    reinterpret_cast<const float*>((const char*)w3f + 1024 * 256 + 4096),
                    reinterpret_cast<const float*>((const char*)w3f + 1024 * 256 + 8192), tstat, relu, exhaustive, pair_cap, fb_cap,
                    feat, ld_feat, stats, abl);
