@@ -382,6 +382,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp(const P p) {
     const int rd = lr * 64 + 16 * (lc ^ swz<16>(lr));
     unsigned long long clk0 = 0, rt0 = 0;
     if (ABL == 9) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+    if (PRIO == 2 && wave >= 4) __builtin_amdgcn_s_setprio(1);   // static priority for the younger half, no per-phase flips
     if (wave >= 4) __builtin_amdgcn_s_barrier();           // the second half runs half a period behind
     unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto phase = [&](int t, auto setc) {
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp(const P p) {
         __builtin_amdgcn_s_barrier();
         if (ABL == 9) { t6 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         // ---- compute phase
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
         if (ABL == 5) {                                     // conversion of tile t + 2 (loaded a period ago) in the MFMA shadow; past the
                                                             // last tile it rewrites a stage nobody reads (no branch: one scheduling region)
             char* nx = smem + ((t + 2) % NSTAGE_PP) * STAGE;
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp(const P p) {
             __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);         // the two LDS writes
             __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
         }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
         if (ABL == 12) {                                    // DMA(t + 1) landed (and A(t + 3) before it): younger = A(t + 4), DMA(t + 2)
             if (t + 4 < T) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -651,6 +652,7 @@ int main(int argc, char** argv) {
         us = run<16, true>(p, 40, dA, nbuf);  printf("  f16x2 16x16x32 dephased : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("16x16x32 dephased", dout);
         us = run_pp<0, 0>(p, 40, dA, nbuf); printf("  f16x2 ping-pong         : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("ping-pong", dout);
         us = run_pp<1, 0>(p, 40, dA, nbuf); printf("  f16x2 ping-pong setprio : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("ping-pong setprio", dout);
+        us = run_pp<2, 0>(p, 40, dA, nbuf); printf("  f16x2 pp, static priority for waves 4-7, no flips : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("pp static prio", dout);
         us = run_pp<1, 13>(p, 40, dA, nbuf); printf("  f16x2 pp setprio, activations as plane pairs by LDS-DMA : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("pp A planes", dout);
         us = run_pp<1, 13>(p, 40, dA, 1); printf("  f16x2 pp setprio, A plane pairs by DMA, ONE buffer (cache-resident) : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6);
         us = run_pp<1, 5>(p, 40, dA, nbuf); printf("  f16x2 pp setprio, split in the compute phase : %7.1f us  %6.1f TF\n", us, flop / us * 1e-6); check("pp split in C", dout);
