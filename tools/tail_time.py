@@ -1,3 +1,5 @@
+"""GPU box: time of one PointNet encoder call (STN trunk + encoder trunk) at N = 778 and N = 1024 with the tail tile on / off
+(DVQ_PN_TAIL): `python tools/tail_time.py`; under rocprofv3 --kernel-trace --stats it gives the per-kernel split."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(sys.path[0], "tests"))
 import dvqvae_amd
