@@ -120,6 +120,9 @@ struct GemmSrc {
     int wp_kind;          // DVQ_PLANES_BF16X3: Wp = three bf16 planes; DVQ_PLANES_F16X2: two fp16 planes of w * 2^t[row] (+ GemmParams::wscale)
     const uint16_t* Wp;   // optional: W pre-split into planes [planes][N][ldw] (plane stride wp_plane elements)
     long wp_plane;
+    // optional (fp16-plane kernels only): output row m reads activation row arow[m] instead of row m -- rows that are a function of
+    // a class label only are computed once per class and read through the label (pixelcnn.hip)
+    const int64_t* arow;
 };
 
 struct GemmParams {
@@ -204,6 +207,7 @@ struct DvqKnobs {
     long pn_chunk;        // samples per PointNet launch (<= 0: what 6 GB of scratch hold)
     int pn_stats;
     long pixelcnn_chunk;  // <= 0: default
+    int pixelcnn_tables;  // 1 (default): what depends on the class label only is evaluated once per class (DVQ_PIXELCNN_TABLES=0: per row)
 };
 const DvqKnobs& dvq_knobs();
 int dvq_launch_vq_stream16(const float* z, const float* E, const void* packed, long M, int64_t* idx, unsigned long long* slow_rows,

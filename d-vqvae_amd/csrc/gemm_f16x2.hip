@@ -75,6 +75,7 @@ struct TileCursor {
         {
             long m = m0 + (tid >> 2);
             if (m >= p.M) m = p.M - 1;                     // clamped rows / columns only feed outputs the epilogue masks
+            if (src.arow) m = src.arow[m];
             a_ptr = src.A + m * src.lda + 8 * (tid & 3);
         }
 #pragma unroll
@@ -315,6 +316,7 @@ struct PpCursorA {
         k_left = src.K;
         long m = m0 + (tid >> 2);
         if (m >= p.M) m = p.M - 1;                         // clamped rows / columns only feed outputs the epilogue masks
+        if (src.arow) m = src.arow[m];
         a_ptr = src.A + m * src.lda + 8 * (tid & 3);
     }
     __device__ __forceinline__ bool valid() const { return k_left > 0; }
@@ -559,7 +561,7 @@ struct SkinnyCursor16 {
         s = src_i;
         const GemmSrc& src = p.src[s];
         k_left = src.K;
-        a_ptr = src.A + m * src.lda + 8 * lc;
+        a_ptr = src.A + (src.arow ? src.arow[m] : m) * src.lda + 8 * lc;
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll

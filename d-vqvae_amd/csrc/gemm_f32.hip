@@ -218,6 +218,7 @@ int dvq_launch_gemm(const GemmParams& p, GemmEpilogue epi, hipStream_t stream) {
         DVQ_PROPAGATE(check_f16x2_planes(p, epi, &use));
         if (use) return dvq_launch_gemm_f16x2(p, epi, stream);
     }
+    for (int s = 0; s < p.nsrc; ++s) DVQ_REQUIRE(!p.src[s].arow, "gemm: row-indexed activations need the fp16-plane kernels (source %d)", s);
     switch (epi) {
         case EPI_BIAS:
             DVQ_REQUIRE(p.out, "gemm: null output");

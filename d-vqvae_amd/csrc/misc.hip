@@ -44,6 +44,7 @@ DvqKnobs* read_knobs() {
     k->pn_chunk = num("DVQ_PN_CHUNK");
     k->pn_stats = getenv("DVQ_PN_STATS") != nullptr;
     k->pixelcnn_chunk = num("DVQ_PIXELCNN_CHUNK");
+    k->pixelcnn_tables = is("DVQ_PIXELCNN_TABLES", '0') ? 0 : 1;
     return k;
 }
 }  // namespace

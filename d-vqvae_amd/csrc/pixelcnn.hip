@@ -55,11 +55,11 @@ __global__ void sample_kernel(const float* __restrict__ logits, const float* __r
                               int pos, int n_in, long Bc, const int64_t* __restrict__ forced /* [B,9] or null */,
                               int64_t* __restrict__ codes /* [B,9] */, const float* __restrict__ tok_emb, int dim,
                               float* __restrict__ x0 /* [Bc,dim] */, float* __restrict__ logits_out /* [B,9,n_in] or null */,
-                              int32_t* err_flag) {
+                              int32_t* err_flag, const int64_t* __restrict__ lrow /* null, or: sample b's logits are row lrow[b] */) {
     const int lane = threadIdx.x & 63;
     const long b = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= Bc) return;
-    const float* lg = logits + b * n_in;
+    const float* lg = logits + (lrow ? lrow[b] : b) * n_in;
     int64_t code;
     if (logits_out)
         for (int k = lane; k < n_in; k += 64) logits_out[(b * NPOS + pos) * n_in + k] = lg[k];
@@ -103,12 +103,28 @@ __global__ void sample_kernel(const float* __restrict__ logits, const float* __r
     for (int c = lane * 4; c < dim; c += 256) *reinterpret_cast<f32x4*>(x0 + b * dim + c) = *reinterpret_cast<const f32x4*>(e + c);
 }
 
+__global__ void iota_kernel(int64_t* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+
 struct Plan {
     long chunk;
     int L, dim;
     float *xv, *xh, *hv, *g, *hid, *lg;
     int64_t* lab;
     size_t bytes;
+    // Class tables.  Row 0 of the grid sees nothing above it and position (0, 0) nothing before it, so the vertical stack of row 0
+    // (all layers, three columns) and the whole horizontal stack + head of position (0, 0) are functions of the CLASS LABEL alone:
+    // they are evaluated once per class (nc rows instead of one per sample) and read through the label wherever the batch needs
+    // them (GemmSrc::arow, the draw kernel's row index) -- the same kernels per row, hence the same bits.
+    bool tab;
+    int nc;
+    float *xvc, *hvc, *xhc, *gc, *hidc, *lgc;
+    int64_t* iota;
+    float* XVC(int level, int c) const { return xvc + ((size_t)(level - 1) * GRID + c) * nc * dim; }      // level 1 .. L, row 0, column c
+    float* HVC(int layer, int c) const { return hvc + ((size_t)layer * GRID + c) * nc * 2 * dim; }
+    float* XHC(int level) const { return xhc + (size_t)(level - 1) * nc * dim; }                          // level 1 .. L, position (0, 0)
     float* XV(int level, int pos) const { return xv + ((size_t)level * NPOS + pos) * chunk * dim; }
     float* XH(int level, int pos) const { return level == 0 ? XV(0, pos) : xh + ((size_t)(level - 1) * NPOS + pos) * chunk * dim; }
     float* HV(int layer, int col) const { return hv + ((size_t)layer * GRID + col) * chunk * 2 * dim; }
@@ -132,6 +148,21 @@ Plan make_plan(const dvq_pixelcnn_weights* w, int64_t B, void* ws) {
     p.hid = (float*)take((size_t)chunk * w->n_hidden * 4);
     p.lg = (float*)take((size_t)chunk * w->n_in * 4);
     p.lab = (int64_t*)take((size_t)chunk * 8);
+    // class tables: fp16-plane kernels only (they read activation rows through an index), batches that are larger than the table
+    p.nc = w->n_classes;
+    p.tab = dvq_knobs().pixelcnn_tables && w->planes_kind == DVQ_PLANES_F16X2 && w->w0_p && dvq_gemm_mode() == 1 && B >= 2L * w->n_classes;
+    p.xvc = p.hvc = p.xhc = p.gc = p.hidc = p.lgc = nullptr;
+    p.iota = nullptr;
+    if (p.tab) {
+        const size_t nc = (size_t)p.nc;
+        p.xvc = (float*)take((size_t)p.L * GRID * nc * p.dim * 4);
+        p.hvc = (float*)take((size_t)p.L * GRID * nc * 2 * p.dim * 4);
+        p.xhc = (float*)take((size_t)p.L * nc * p.dim * 4);
+        p.gc = (float*)take(nc * p.dim * 4);
+        p.hidc = (float*)take(nc * w->n_hidden * 4);
+        p.lgc = (float*)take(nc * w->n_in * 4);
+        p.iota = (int64_t*)take(nc * 8);
+    }
     p.bytes = (size_t)(c - (char*)ws);
     return p;
 }
@@ -163,6 +194,133 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
     }
     const int dim = w->dim, L = w->n_layers;
     const int kind = w->planes_kind;                      // DVQ_PLANES_*: what every *_p image of this network holds
+
+    // An activation tensor as a GEMM source: rows of the chunk, or rows of a class table read through the chunk's labels.
+    struct Act { const float* p; const int64_t* arow; };
+    // ---- one layer of the vertical stack at grid row r for the M rows of (label, xv, out, pre): the row's columns do not depend on
+    // each other -- one launch where the launch count is what costs (dvq_launch_gemm_gate_group)
+    auto vertical_layer = [&](int r, int l, long M, const int64_t* lab, auto xv_of /* (level, pos) -> Act */,
+                              auto out_of /* (col) -> float* (level l + 1) */, auto pre_of /* (col) -> float* */) -> int {
+        const dvq_pixelcnn_layer& ly = w->layers_host[l];
+        const int k = (l == 0) ? 5 : 3, pad = k / 2, KR = k / 2 + 1;
+        GemmParams grp[GRID];
+        int ngrp = 0;
+        for (int c = 0; c < GRID; ++c) {
+            GemmParams& g = grp[ngrp];
+            g = GemmParams{};
+            int ns = 0;
+            for (int kr = 0; kr < KR; ++kr) {
+                if (l == 0 && kr == KR - 1) continue;            // mask 'A': last kernel row
+                const int ir = r - pad + kr;
+                if (ir < 0) continue;
+                for (int kc = 0; kc < k; ++kc) {
+                    const int ic = c - pad + kc;
+                    if (ic < 0 || ic >= GRID) continue;
+                    const size_t tap = (size_t)(kr * k + kc), wsz = (size_t)2 * dim * dim;
+                    const Act a = xv_of(l, ir * GRID + ic);
+                    g.src[ns++] = GemmSrc{a.p, ly.wv + tap * wsz, (long)dim, (long)dim, dim, kind,
+                                          ly.wv_p ? ly.wv_p + tap * wsz : nullptr, (long)(KR * k) * (long)wsz, a.arow};
+                }
+            }
+            float* out = out_of(c);
+            float* pre = pre_of(c);
+            if (ns == 0) {
+                const long tot = M * dim;
+                DVQ_LAUNCH(bias_gate_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, ly.bv, ly.cls, lab, M, dim, out, pre);
+                DVQ_CHECK_LAUNCH("bias_gate");
+                continue;
+            }
+            g.nsrc = ns;
+            g.M = M;
+            g.N = 2 * dim;
+            g.bias = ly.bv;
+            g.wscale = ly.sv;
+            g.cls = ly.cls;
+            g.label = lab;
+            g.out = out;
+            g.ldo = dim;
+            g.pre = pre;
+            g.ldpre = 2 * dim;
+            ++ngrp;
+        }
+        if (ngrp) DVQ_PROPAGATE(dvq_launch_gemm_gate_group(grp, ngrp, st));
+        return DVQ_OK;
+    };
+    // ---- the horizontal stack + head of one position for M rows; logits -> lg
+    auto horizontal_position = [&](int r, int c, long M, const int64_t* lab, auto hv_of /* (layer, col) -> Act */,
+                                   auto xh_of /* (level, pos) -> Act */, auto xh_out /* (level) -> float* at this position */,
+                                   float* gbuf, float* hid, float* lg) -> int {
+        const int pos = r * GRID + c;
+        for (int l = 0; l < L; ++l) {
+            const dvq_pixelcnn_layer& ly = w->layers_host[l];
+            const int k = (l == 0) ? 5 : 3, pad = k / 2, KC = k / 2 + 1;
+            GemmParams g = {};
+            int ns = 0;
+            {
+                const Act a = hv_of(l, c);
+                g.src[ns++] = GemmSrc{a.p, ly.wv2h, (long)2 * dim, (long)2 * dim, 2 * dim, kind, ly.wv2h_p, (long)4 * dim * dim, a.arow};
+            }
+            for (int kc = 0; kc < KC; ++kc) {
+                if (l == 0 && kc == KC - 1) continue;            // mask 'A': last kernel column
+                const int ic = c - pad + kc;
+                if (ic < 0) continue;
+                const size_t wsz = (size_t)2 * dim * dim;
+                const Act a = xh_of(l, r * GRID + ic);
+                g.src[ns++] = GemmSrc{a.p, ly.wh + kc * wsz, (long)dim, (long)dim, dim, kind,
+                                      ly.wh_p ? ly.wh_p + kc * wsz : nullptr, (long)KC * (long)wsz, a.arow};
+            }
+            g.nsrc = ns;
+            g.M = M;
+            g.N = 2 * dim;
+            g.bias = ly.bh;
+            g.wscale = ly.sh;
+            g.cls = ly.cls;
+            g.label = lab;
+            g.out = gbuf;
+            g.ldo = dim;
+            DVQ_PROPAGATE(dvq_launch_gemm(g, EPI_GATE, st));
+            GemmParams q = {};
+            q.src[0] = GemmSrc{gbuf, ly.wr, (long)dim, (long)dim, dim, kind, ly.wr_p, (long)dim * dim, nullptr};
+            q.wscale = ly.sr;
+            q.nsrc = 1;
+            q.M = M;
+            q.N = dim;
+            q.bias = ly.br;
+            q.out = xh_out(l + 1);
+            q.ldo = dim;
+            if (l > 0) {                                        // residual only for layers >= 1 (:82-86)
+                q.resid = xh_of(l, pos).p;                      // this position's own level-l activations: never a table read through labels
+                q.ldr = dim;
+                DVQ_PROPAGATE(dvq_launch_gemm(q, EPI_RESID, st));
+            } else {
+                DVQ_PROPAGATE(dvq_launch_gemm(q, EPI_BIAS, st));
+            }
+        }
+        GemmParams h0 = {};
+        h0.src[0] = GemmSrc{xh_out(L), w->w0, (long)dim, (long)dim, dim, kind, w->w0_p, (long)w->n_hidden * dim, nullptr};
+        h0.wscale = w->s0;
+        h0.nsrc = 1; h0.M = M; h0.N = w->n_hidden; h0.bias = w->b0; h0.out = hid; h0.ldo = w->n_hidden; h0.relu = 1;
+        DVQ_PROPAGATE(dvq_launch_gemm(h0, EPI_BIAS, st));
+        GemmParams h2 = {};
+        h2.src[0] = GemmSrc{hid, w->w2, (long)w->n_hidden, (long)w->n_hidden, w->n_hidden, kind, w->w2_p, (long)w->n_in * w->n_hidden, nullptr};
+        h2.wscale = w->s2;
+        h2.nsrc = 1; h2.M = M; h2.N = w->n_in; h2.bias = w->b2; h2.out = lg; h2.ldo = w->n_in;
+        DVQ_PROPAGATE(dvq_launch_gemm(h2, EPI_BIAS, st));
+        return DVQ_OK;
+    };
+
+    if (pl.tab) {
+        // ---- once per call: row 0's vertical stack and position (0, 0)'s horizontal stack + head for every class (label = row)
+        const long nc = pl.nc;
+        DVQ_LAUNCH(iota_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, pl.iota, (int)nc);
+        DVQ_CHECK_LAUNCH("iota");
+        auto xv_c = [&](int level, int pos) { return Act{pl.XVC(level, pos), nullptr}; };     // row 0 only reads row 0 (levels >= 1)
+        for (int l = 0; l < L; ++l)
+            DVQ_PROPAGATE(vertical_layer(0, l, nc, pl.iota, xv_c, [&](int c) { return pl.XVC(l + 1, c); }, [&](int c) { return pl.HVC(l, c); }));
+        auto hv_c = [&](int layer, int col) { return Act{pl.HVC(layer, col), nullptr}; };
+        auto xh_c = [&](int level, int pos) { (void)pos; return Act{pl.XHC(level), nullptr}; }; // position (0, 0) reads itself only, levels >= 1
+        DVQ_PROPAGATE(horizontal_position(0, 0, nc, pl.iota, hv_c, xh_c, [&](int level) { return pl.XHC(level); }, pl.gc, pl.hidc, pl.lgc));
+    }
     for (int64_t b0 = 0; b0 < B; b0 += pl.chunk) {
         const long Bc = (long)((B - b0 < pl.chunk) ? (B - b0) : pl.chunk);
         DVQ_LAUNCH(sanitize_labels_kernel, dim3((unsigned)((Bc + 255) / 256)), dim3(256), 0, st, label + b0, Bc,
@@ -172,117 +330,40 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
             for (int pos = 0; pos < NPOS; ++pos)
                 DVQ_PROPAGATE(dvq_launch_gather_rows(w->tok_emb, forced + b0 * NPOS + pos, NPOS, Bc, w->n_in, dim,
                                                      pl.XV(0, pos), dim, err_flag, st));
+        // where the batch finds an activation tensor: level 0 = the token embeddings (always per row); row 0's vertical levels >= 1
+        // and position (0, 0)'s horizontal levels >= 1 in the class tables, through the labels
+        auto xv_b = [&](int level, int pos) {
+            if (pl.tab && level >= 1 && pos < GRID) return Act{pl.XVC(level, pos), pl.lab};
+            return Act{pl.XV(level, pos), nullptr};
+        };
+        auto hv_b = [&](int layer, int col, int r) {
+            if (pl.tab && r == 0) return Act{pl.HVC(layer, col), pl.lab};
+            return Act{pl.HV(layer, col), nullptr};
+        };
+        auto xh_b = [&](int level, int pos) {
+            if (pl.tab && level >= 1 && pos == 0) return Act{pl.XHC(level), pl.lab};
+            return Act{pl.XH(level, pos), nullptr};
+        };
         for (int r = 0; r < GRID; ++r) {
             // ---- vertical stack of row r, all layers (depends on rows < r only)
-            for (int l = 0; l < L; ++l) {
-                const dvq_pixelcnn_layer& ly = w->layers_host[l];
-                const int k = (l == 0) ? 5 : 3, pad = k / 2, KR = k / 2 + 1;
-                GemmParams grp[GRID];                                    // the row's columns do not depend on each other: one launch where
-                int ngrp = 0;                                            // the launch count is what costs (dvq_launch_gemm_gate_group)
-                for (int c = 0; c < GRID; ++c) {
-                    GemmParams& g = grp[ngrp];
-                    g = GemmParams{};
-                    int ns = 0;
-                    for (int kr = 0; kr < KR; ++kr) {
-                        if (l == 0 && kr == KR - 1) continue;            // mask 'A': last kernel row
-                        const int ir = r - pad + kr;
-                        if (ir < 0) continue;
-                        for (int kc = 0; kc < k; ++kc) {
-                            const int ic = c - pad + kc;
-                            if (ic < 0 || ic >= GRID) continue;
-                            {
-                                const size_t tap = (size_t)(kr * k + kc), wsz = (size_t)2 * dim * dim;
-                                g.src[ns++] = GemmSrc{pl.XV(l, ir * GRID + ic), ly.wv + tap * wsz, (long)dim, (long)dim, dim, kind,
-                                                      ly.wv_p ? ly.wv_p + tap * wsz : nullptr, (long)(KR * k) * (long)wsz};
-                            }
-                        }
-                    }
-                    float* out = pl.XV(l + 1, r * GRID + c);
-                    float* pre = pl.HV(l, c);
-                    if (ns == 0) {
-                        const long tot = Bc * dim;
-                        DVQ_LAUNCH(bias_gate_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, ly.bv,
-                                           ly.cls, pl.lab, Bc, dim, out, pre);
-                        DVQ_CHECK_LAUNCH("bias_gate");
-                        continue;
-                    }
-                    g.nsrc = ns;
-                    g.M = Bc;
-                    g.N = 2 * dim;
-                    g.bias = ly.bv;
-                    g.wscale = ly.sv;
-                    g.cls = ly.cls;
-                    g.label = pl.lab;
-                    g.out = out;
-                    g.ldo = dim;
-                    g.pre = pre;
-                    g.ldpre = 2 * dim;
-                    ++ngrp;
-                }
-                if (ngrp) DVQ_PROPAGATE(dvq_launch_gemm_gate_group(grp, ngrp, st));
-            }
+            if (!(pl.tab && r == 0))
+                for (int l = 0; l < L; ++l)
+                    DVQ_PROPAGATE(vertical_layer(r, l, Bc, pl.lab, xv_b, [&](int c) { return pl.XV(l + 1, r * GRID + c); },
+                                                 [&](int c) { return pl.HV(l, c); }));
             // ---- horizontal stack + head + draw, position by position
             for (int c = 0; c < GRID; ++c) {
                 const int pos = r * GRID + c;
-                for (int l = 0; l < L; ++l) {
-                    const dvq_pixelcnn_layer& ly = w->layers_host[l];
-                    const int k = (l == 0) ? 5 : 3, pad = k / 2, KC = k / 2 + 1;
-                    GemmParams g = {};
-                    int ns = 0;
-                    g.src[ns++] = GemmSrc{pl.HV(l, c), ly.wv2h, (long)2 * dim, (long)2 * dim, 2 * dim, kind, ly.wv2h_p, (long)4 * dim * dim};
-                    for (int kc = 0; kc < KC; ++kc) {
-                        if (l == 0 && kc == KC - 1) continue;            // mask 'A': last kernel column
-                        const int ic = c - pad + kc;
-                        if (ic < 0) continue;
-                        {
-                            const size_t wsz = (size_t)2 * dim * dim;
-                            g.src[ns++] = GemmSrc{pl.XH(l, r * GRID + ic), ly.wh + kc * wsz, (long)dim, (long)dim, dim, kind,
-                                                  ly.wh_p ? ly.wh_p + kc * wsz : nullptr, (long)KC * (long)wsz};
-                        }
-                    }
-                    g.nsrc = ns;
-                    g.M = Bc;
-                    g.N = 2 * dim;
-                    g.bias = ly.bh;
-                    g.wscale = ly.sh;
-                    g.cls = ly.cls;
-                    g.label = pl.lab;
-                    g.out = pl.g;
-                    g.ldo = dim;
-                    DVQ_PROPAGATE(dvq_launch_gemm(g, EPI_GATE, st));
-                    GemmParams q = {};
-                    q.src[0] = GemmSrc{pl.g, ly.wr, (long)dim, (long)dim, dim, kind, ly.wr_p, (long)dim * dim};
-                    q.wscale = ly.sr;
-                    q.nsrc = 1;
-                    q.M = Bc;
-                    q.N = dim;
-                    q.bias = ly.br;
-                    q.out = pl.XH(l + 1, pos);
-                    q.ldo = dim;
-                    if (l > 0) {                                        // residual only for layers >= 1 (:82-86)
-                        q.resid = pl.XH(l, pos);
-                        q.ldr = dim;
-                        DVQ_PROPAGATE(dvq_launch_gemm(q, EPI_RESID, st));
-                    } else {
-                        DVQ_PROPAGATE(dvq_launch_gemm(q, EPI_BIAS, st));
-                    }
-                }
-                GemmParams h0 = {};
-                h0.src[0] = GemmSrc{pl.XH(L, pos), w->w0, (long)dim, (long)dim, dim, kind, w->w0_p, (long)w->n_hidden * dim};
-                h0.wscale = w->s0;
-                h0.nsrc = 1; h0.M = Bc; h0.N = w->n_hidden; h0.bias = w->b0; h0.out = pl.hid; h0.ldo = w->n_hidden; h0.relu = 1;
-                DVQ_PROPAGATE(dvq_launch_gemm(h0, EPI_BIAS, st));
-                GemmParams h2 = {};
-                h2.src[0] = GemmSrc{pl.hid, w->w2, (long)w->n_hidden, (long)w->n_hidden, w->n_hidden, kind, w->w2_p, (long)w->n_in * w->n_hidden};
-                h2.wscale = w->s2;
-                h2.nsrc = 1; h2.M = Bc; h2.N = w->n_in; h2.bias = w->b2; h2.out = pl.lg; h2.ldo = w->n_in;
-                DVQ_PROPAGATE(dvq_launch_gemm(h2, EPI_BIAS, st));
+                const bool from_table = pl.tab && pos == 0;     // its logits are the class table's rows
+                if (!from_table)
+                    DVQ_PROPAGATE(horizontal_position(r, c, Bc, pl.lab, [&](int layer, int col) { return hv_b(layer, col, r); }, xh_b,
+                                                      [&](int level) { return pl.XH(level, pos); }, pl.g, pl.hid, pl.lg));
                 {
                 DVQ_PROF("pixelcnn_draw", 0, (double)Bc * (2.0 * w->n_in + dim) * 4, st);
-                DVQ_LAUNCH(sample_kernel, dim3((unsigned)((Bc + 3) / 4)), dim3(256), 0, st, pl.lg,
+                DVQ_LAUNCH(sample_kernel, dim3((unsigned)((Bc + 3) / 4)), dim3(256), 0, st, from_table ? pl.lgc : pl.lg,
                                    noise ? noise + b0 * NPOS * w->n_in : nullptr, pos, w->n_in, Bc,
                                    forced ? forced + b0 * NPOS : nullptr, codes ? codes + b0 * NPOS : nullptr, w->tok_emb, dim,
-                                   pl.XV(0, pos), logits_out ? logits_out + b0 * NPOS * w->n_in : nullptr, err_flag);
+                                   pl.XV(0, pos), logits_out ? logits_out + b0 * NPOS * w->n_in : nullptr, err_flag,
+                                   from_table ? pl.lab : nullptr);
                 }
                 DVQ_CHECK_LAUNCH("pixelcnn_sample_step");
             }

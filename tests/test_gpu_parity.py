@@ -422,6 +422,36 @@ def test_pixelcnn_full_golden(golden):
     assert torch.equal(tf, logits)
 
 
+@pytest.mark.parametrize("cfg,B", [((32, 64, 3, 16), 40), ((512, 512, 15, 128), 300), ((512, 512, 15, 128), 700)])
+def test_pixelcnn_class_tables_equal_per_row_evaluation(cfg, B):
+    """Row 0 of the grid sees nothing above it and position (0, 0) nothing before it: their activations depend on the class label
+    only.  Batches of at least two rows per class evaluate them once per class and read them through the labels
+    (GemmSrc::arow, the draw kernel's row index); DVQ_PIXELCNN_TABLES=0 evaluates them per row.  Same kernels per row: the
+    teacher-forced logits, the sampled codes and the logits they were drawn from must agree bit for bit (B = 40: the
+    small-batch kernels read through the index, 300 / 700: the tiled ones, two and six row tiles)."""
+    net, _ = _prior(cfg, SEED + 21)
+    n_tok, n_cls = cfg[0], cfg[3]
+    g = torch.Generator().manual_seed(B)
+    x = gpu(torch.randint(0, n_tok, (B, 3, 3), generator=g))
+    lab = gpu(torch.randint(0, n_cls, (B,), generator=g))
+    q = gpu(synth.exp1_noise(B, 9, n_tok, seed=B))
+
+    def run():
+        codes, logits = net.generate(None, lab, batch_size=B, noise=q, return_logits=True)
+        return net(x, lab), codes, logits
+    a = run()
+    b = _with_env("DVQ_PIXELCNN_TABLES", "0", run)
+    for name, u, v in zip(("teacher-forced logits", "sampled codes", "sampling logits"), a, b):
+        assert torch.equal(u, v), f"{name}: class tables != per-row evaluation"
+    # and the class tables must be in use at this size (the workspace is larger with them)
+    import ctypes
+    from dvqvae_amd import _lib
+    pk = net.packed()
+    with_tab = _lib.load().dvq_pixelcnn_workspace_bytes(ctypes.byref(pk.cstruct), B)
+    without = _with_env("DVQ_PIXELCNN_TABLES", "0", lambda: _lib.load().dvq_pixelcnn_workspace_bytes(ctypes.byref(pk.cstruct), B))
+    assert with_tab > without
+
+
 def test_pixelcnn_label_out_of_range():
     net, _ = _prior((32, 64, 3, 16), SEED + 1)
     with pytest.raises(RuntimeError, match="out of range"):
