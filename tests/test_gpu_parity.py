@@ -422,7 +422,8 @@ def test_pixelcnn_full_golden(golden):
     assert torch.equal(tf, logits)
 
 
-@pytest.mark.parametrize("cfg,B", [((32, 64, 3, 16), 40), ((512, 512, 15, 128), 300), ((512, 512, 15, 128), 700)])
+@pytest.mark.parametrize("cfg,B", [((32, 64, 3, 16), 40), ((512, 512, 15, 128), 300), ((512, 512, 15, 128), 700),
+                                   ((64, 128, 4, 8), 16384 + 37)])          # two chunks: 16 384 rows and a small-batch one
 def test_pixelcnn_class_tables_equal_per_row_evaluation(cfg, B):
     """Row 0 of the grid sees nothing above it and position (0, 0) nothing before it: their activations depend on the class label
     only.  Batches of at least two rows per class evaluate them once per class and read them through the labels
