@@ -109,7 +109,8 @@ enum GemmEpilogue {
     EPI_RESID = 1,   // out = acc + bias + resid
     EPI_GATE = 2,    // out = tanh(a) * sigmoid(b) over gate-packed channel pairs (+ optional pre-gate store)
     EPI_COLMAX = 3,  // per-tile column max over valid rows -> partial[tile_m][N]
-    EPI_ARGMIN = 4   // A = codebook, W = z rows: per z row, (min, argmin) of (zz+ee)-2*acc over the tile's entries
+    EPI_ARGMIN = 4,  // A = codebook, W = z rows: per z row, (min, argmin) of (zz+ee)-2*acc over the tile's entries
+    EPI_STATE = 5    // fp16-plane kernels: the raw accumulator pair after the launch's k-steps -> out (first sums), pre (second sums)
 };
 
 struct GemmSrc {
@@ -152,6 +153,13 @@ struct GemmParams {
     const float* col_norm;   // zz[N]
     float* part_val;         // [tiles_m][N]
     int* part_idx;           // [tiles_m][N]
+    // fp16-plane kernels: the accumulator pair starts from a stored state (EPI_STATE of a launch over the FIRST sources of the full
+    // product) instead of zero; output row m continues row acc_row[m] (or m).  Continuing a state gives the bits of the one-launch
+    // product: every accumulator sees the same MFMA sequence.
+    const float* acc_hi;
+    const float* acc_lo;
+    long ldacc;
+    const int64_t* acc_row;
     int dbg_abl;             // diagnostics only (env DVQ_GEMM_ABL): 2 = no MFMAs
     unsigned long long* dbg_clk;   // diagnostics only (env DVQ_GEMM_CLK=1): block 0 stores {memtime, memrealtime} x {begin, end}
 };

@@ -169,6 +169,36 @@ __device__ __forceinline__ void f16x2_store_gate(const GemmParams& p, long m, in
     *reinterpret_cast<f32x4*>(p.out + m * p.ldo + c) = o;
 }
 
+// accumulators of a wave's 64 x (16 NJ) block from a stored state (GemmParams::acc_*), or zero
+template <int NJ, bool INIT>
+__device__ __forceinline__ void f16x2_init_acc(const GemmParams& p, f32x4 (&hi)[NJ][4], f32x4 (&lo)[NJ][4], long m0w, int n0w, int lane) {
+    if constexpr (!INIT) {                                  // the plain launch: exactly the code it always was
+#pragma unroll
+        for (int a = 0; a < NJ; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { hi[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        return;
+    }
+    const int lr = lane & 15, lc = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long m = m0w + i * 16 + lr;
+        const bool row_ok = p.acc_hi && m < p.M;
+        const long r = row_ok ? (p.acc_row ? p.acc_row[m] : m) : 0;
+#pragma unroll
+        for (int jn = 0; jn < NJ; ++jn) {
+            const int n = n0w + jn * 16 + 4 * lc;
+            if (row_ok && n < p.N) {                        // N % 4 == 0 with a state (checked by the launcher)
+                hi[jn][i] = *reinterpret_cast<const f32x4*>(p.acc_hi + r * p.ldacc + n);
+                lo[jn][i] = *reinterpret_cast<const f32x4*>(p.acc_lo + r * p.ldacc + n);
+            } else {
+                hi[jn][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                lo[jn][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+}
+
 template <int EPI, int NJ = 4>
 __device__ __forceinline__ void f16x2_epilogue(const GemmParams& p, f32x4 (&hi)[NJ][4], f32x4 (&lo)[NJ][4], long m0w, int n0w, int c0w,
                                                int lane) {
@@ -187,6 +217,14 @@ __device__ __forceinline__ void f16x2_epilogue(const GemmParams& p, f32x4 (&hi)[
                 const bool full = vec_ok && n + 3 < p.N;
                 f16x2_store_block<EPI>(p, m, n, f16x2_combine(hi[jn][i], lo[jn][i], p.wscale, n, full), full);
             }
+        } else if constexpr (EPI == EPI_STATE) {
+#pragma unroll
+            for (int jn = 0; jn < NJ; ++jn) {
+                const int n = n0w + jn * 16 + 4 * lc;
+                if (n >= p.N) continue;
+                *reinterpret_cast<f32x4*>(p.out + m * p.ldo + n) = hi[jn][i];
+                *reinterpret_cast<f32x4*>(p.pre + m * p.ldpre + n) = lo[jn][i];
+            }
         } else if constexpr (EPI == EPI_GATE) {
             if constexpr (NJ == 4) {
             if (n0w >= p.N) continue;                      // N % 128 == 0: a wave's 64 columns are all inside or all outside
@@ -203,7 +241,7 @@ __device__ __forceinline__ void f16x2_epilogue(const GemmParams& p, f32x4 (&hi)[
     }
 }
 
-template <int EPI, bool DEPHASE>
+template <int EPI, bool DEPHASE, bool INIT>
 __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     const int tid = threadIdx.x;
@@ -221,10 +259,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_kernel(const GemmParams p) 
     const int wm = wave >> 2, wn = wave & 3;
 
     f32x4 hi[4][4], lo[4][4];                               // [jn][i]
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { hi[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    f16x2_init_acc<4, INIT>(p, hi, lo, m0 + wm * 64, n0 + wn * 64, lane);
 
     TileCursor cur;
     cur.open(p, 0, m0, n0, tid, wave, lane);
@@ -365,7 +400,7 @@ struct PpCursorW {
     }
 };
 
-template <int EPI, int NJ>
+template <int EPI, int NJ, bool INIT>
 __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp_kernel(const GemmParams p, int T) {
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     constexpr int TN = 64 * NJ, W_PL = TN * 64, STAGE = 2 * A_PL + 2 * W_PL;      // this kernel's tile width (shadows the file's)
@@ -416,10 +451,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp_kernel(const GemmParams 
     __builtin_amdgcn_s_barrier();
 
     f32x4 hi[NJ][4], lo[NJ][4];                             // [jn][i]
-#pragma unroll
-    for (int a = 0; a < NJ; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { hi[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[a][c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    f16x2_init_acc<NJ, INIT>(p, hi, lo, m0 + wm * 64, n0 + wn * 16 * NJ, lane);
 
     const int rd = (lane & 15) * 64 + 16 * ((lane >> 4) ^ swz16(lane & 15));       // fragment read: row lane & 15, chunk lane >> 4
     if (wave >= 4) __builtin_amdgcn_s_barrier();           // the second half runs half a period behind
@@ -476,19 +508,19 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp_kernel(const GemmParams 
 // workgroup of those launches moves ~1 MB (activations 256 KB, weight planes 512 KB from L2, residual in, tile out) in 46 us =
 // 22 GB/s per CU, the rate one CU sustains from beyond L2 (MI355X_MICROARCH.md: 23-33 GB/s): they are bound by the per-CU memory
 // path, not by the overlap of prologue and epilogue, and the smaller tile reads every activation row twice as often.
-template <int EPI>
+template <int EPI, bool INIT = false>
 int launch_tiled(const GemmParams& p, hipStream_t stream) {
     static DvqOncePerDevice attr_once;
     {
         const hipError_t e = attr_once.run([] {
-            const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_kernel<EPI, false>),
+            const hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_kernel<EPI, false, INIT>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM);
-            const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_kernel<EPI, true>),
+            const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_kernel<EPI, true, INIT>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM);
-            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_pp_kernel<EPI, 4>),
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_pp_kernel<EPI, 4, INIT>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_SMEM);
             if constexpr (EPI != EPI_GATE)
-                if (e2 == hipSuccess) e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_pp_kernel<EPI, 2>),
+                if (e2 == hipSuccess) e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_pp_kernel<EPI, 2, INIT>),
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)PP_SMEM_N128);
             return e0 != hipSuccess ? e0 : (e1 != hipSuccess ? e1 : e2);
         });
@@ -510,7 +542,7 @@ int launch_tiled(const GemmParams& p, hipStream_t stream) {
         if (dvq_knobs().gemm_tn == 128) narrow = true;
         if (dvq_knobs().gemm_tn == 256) narrow = false;
     }
-    static const char* const names[] = {"gemm_bias", "gemm_resid", "gemm_gate"};
+    static const char* const names[] = {"gemm_bias", "gemm_resid", "gemm_gate", "", "", "gemm_state"};
     double ksum = 0;
     int T = 0;
     for (int s = 0; s < p.nsrc; ++s) { ksum += p.src[s].K; T += p.src[s].K / BK; }
@@ -520,11 +552,11 @@ int launch_tiled(const GemmParams& p, hipStream_t stream) {
         if (mode == 2 && narrow) {
             if constexpr (EPI != EPI_GATE) {
                 const long grid2 = ((tiles_m + 7) / 8) * 8 * ((p.N + 127) / 128);
-                DVQ_LAUNCH((gemm_f16x2_pp_kernel<EPI, 2>), dim3((unsigned)grid2), dim3(512), PP_SMEM_N128, stream, p, T);
+                DVQ_LAUNCH((gemm_f16x2_pp_kernel<EPI, 2, INIT>), dim3((unsigned)grid2), dim3(512), PP_SMEM_N128, stream, p, T);
             }
-        } else if (mode == 2) DVQ_LAUNCH((gemm_f16x2_pp_kernel<EPI, 4>), dim3((unsigned)grid), dim3(512), PP_SMEM, stream, p, T);
-        else if (mode == 1) DVQ_LAUNCH((gemm_f16x2_kernel<EPI, true>), dim3((unsigned)grid), dim3(512), SMEM, stream, p);
-        else DVQ_LAUNCH((gemm_f16x2_kernel<EPI, false>), dim3((unsigned)grid), dim3(512), SMEM, stream, p);
+        } else if (mode == 2) DVQ_LAUNCH((gemm_f16x2_pp_kernel<EPI, 4, INIT>), dim3((unsigned)grid), dim3(512), PP_SMEM, stream, p, T);
+        else if (mode == 1) DVQ_LAUNCH((gemm_f16x2_kernel<EPI, true, INIT>), dim3((unsigned)grid), dim3(512), SMEM, stream, p);
+        else DVQ_LAUNCH((gemm_f16x2_kernel<EPI, false, INIT>), dim3((unsigned)grid), dim3(512), SMEM, stream, p);
     }
     DVQ_CHECK_LAUNCH("gemm_f16x2");
     return DVQ_OK;
@@ -619,7 +651,17 @@ __device__ __forceinline__ void skinny_body(const GemmParams& p, int T, int grou
     }
     f32x4 hi[NB], lo[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) { hi[b] = f32x4{0.f, 0.f, 0.f, 0.f}; lo[b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int b = 0; b < NB; ++b) {                          // zero, or the stored state of this lane's four columns of row mb0 + lr
+        hi[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        lo[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nc0 = skinny_col<EPI, R>(g[b], 4 * lc);
+        const bool col_live = EPI == EPI_GATE ? 4 * lc < 2 * R : (4 * lc < R && nc0 < p.N);
+        if (p.acc_hi && col_live && mb0 + lr < p.M) {
+            const long r = p.acc_row ? p.acc_row[mb0 + lr] : mb0 + lr;
+            hi[b] = *reinterpret_cast<const f32x4*>(p.acc_hi + r * p.ldacc + nc0);
+            lo[b] = *reinterpret_cast<const f32x4*>(p.acc_lo + r * p.ldacc + nc0);
+        }
+    }
     SkinnyCursor16<NB> cur;
     cur.open(p, 0, m, n, lc);
     SkinnySlot<NB> slot[PF];
@@ -675,6 +717,10 @@ __device__ __forceinline__ void skinny_body(const GemmParams& p, int T, int grou
                 const int c = 32 * (nc >> 6) + (nc & 31);   // natural channel of gate-packed tanh column nc
                 *reinterpret_cast<f32x4*>(p.out + mo * p.ldo + c) = o;
             }
+        } else if constexpr (EPI == EPI_STATE) {
+            if (4 * lc >= R || mo >= p.M || nc >= p.N) continue;
+            *reinterpret_cast<f32x4*>(p.out + mo * p.ldo + nc) = hi[b];
+            *reinterpret_cast<f32x4*>(p.pre + mo * p.ldpre + nc) = lo[b];
         } else {
             if (4 * lc >= R || mo >= p.M || nc >= p.N) continue;
             const bool vec_ok = (p.N % 4 == 0) && (p.ldo % 4 == 0) && (EPI != EPI_RESID || p.ldr % 4 == 0);
@@ -712,7 +758,7 @@ void launch_skinny_r(const GemmParams& p, int T, int gy, hipStream_t stream) {
 
 template <int EPI>
 int launch_skinny(const GemmParams& p, hipStream_t stream) {
-    static const char* const names[] = {"gemm_bias", "gemm_resid", "gemm_gate"};
+    static const char* const names[] = {"gemm_bias", "gemm_resid", "gemm_gate", "", "", "gemm_state"};
     double ksum = 0;
     int T = 0;
     for (int s = 0; s < p.nsrc; ++s) { ksum += p.src[s].K; T += p.src[s].K / BK; }
@@ -828,6 +874,12 @@ static int check_f16x2(const GemmParams& p, GemmEpilogue epi) {
     DVQ_REQUIRE(a_ok, "gemm_f16x2: activation rows are not 16-byte aligned");
     if (epi == EPI_GATE)
         DVQ_REQUIRE(dvq_aligned16(p.out) && p.ldo % 4 == 0 && (!p.pre || (dvq_aligned16(p.pre) && p.ldpre % 4 == 0)), "gemm_f16x2: gate outputs are not 16-byte aligned");
+    if (epi == EPI_STATE)
+        DVQ_REQUIRE(p.out && p.pre && dvq_aligned16(p.out) && dvq_aligned16(p.pre) && p.ldo % 4 == 0 && p.ldpre % 4 == 0 && p.N % 4 == 0,
+                    "gemm_f16x2: accumulator-state outputs need N %% 4 == 0 and 16-byte aligned rows");
+    if (p.acc_hi)
+        DVQ_REQUIRE(epi == EPI_GATE && p.acc_lo && dvq_aligned16(p.acc_hi) && dvq_aligned16(p.acc_lo) && p.ldacc % 4 == 0 && p.N % 4 == 0,
+                    "gemm_f16x2: an accumulator state needs both sums, N %% 4 == 0 and 16-byte aligned rows");
     return DVQ_OK;
 }
 
@@ -846,12 +898,14 @@ int dvq_launch_gemm_f16x2(const GemmParams& p, GemmEpilogue epi, hipStream_t str
         case EPI_BIAS: return launch_skinny<EPI_BIAS>(p, stream);
         case EPI_RESID: return launch_skinny<EPI_RESID>(p, stream);
         case EPI_GATE: return launch_skinny<EPI_GATE>(p, stream);
+        case EPI_STATE: return launch_skinny<EPI_STATE>(p, stream);
         default: break;
     }
     switch (epi) {
         case EPI_BIAS: return launch_tiled<EPI_BIAS>(p, stream);
         case EPI_RESID: return launch_tiled<EPI_RESID>(p, stream);
-        case EPI_GATE: return launch_tiled<EPI_GATE>(p, stream);
+        case EPI_GATE: return p.acc_hi ? launch_tiled<EPI_GATE, true>(p, stream) : launch_tiled<EPI_GATE, false>(p, stream);
+        case EPI_STATE: return launch_tiled<EPI_STATE>(p, stream);
         default: break;
     }
     dvq_set_error("gemm_f16x2: epilogue %d is not available on the fp16 split path", (int)epi);

@@ -213,11 +213,12 @@ int dvq_launch_gemm_gate_group(const GemmParams* ps, int n, hipStream_t stream) 
 int dvq_launch_gemm(const GemmParams& p, GemmEpilogue epi, hipStream_t stream) {
     DVQ_PROPAGATE(check_gemm(p));
     const bool split = dvq_gemm_mode() == 1 && epi != EPI_ARGMIN;     // the exact VQ argmin stays on the fp32 chain
-    if (split && (epi == EPI_BIAS || epi == EPI_RESID || epi == EPI_GATE)) {
+    if (split && (epi == EPI_BIAS || epi == EPI_RESID || epi == EPI_GATE || epi == EPI_STATE)) {
         int use = 0;
         DVQ_PROPAGATE(check_f16x2_planes(p, epi, &use));
         if (use) return dvq_launch_gemm_f16x2(p, epi, stream);
     }
+    DVQ_REQUIRE(epi != EPI_STATE && !p.acc_hi, "gemm: accumulator states exist on the fp16-plane kernels only");
     for (int s = 0; s < p.nsrc; ++s) DVQ_REQUIRE(!p.src[s].arow, "gemm: row-indexed activations need the fp16-plane kernels (source %d)", s);
     switch (epi) {
         case EPI_BIAS:

@@ -122,6 +122,14 @@ struct Plan {
     int nc;
     float *xvc, *hvc, *xhc, *gc, *hidc, *lgc;
     int64_t* iota;
+    // Accumulator states.  In the vertical stack of row 1 (layers >= 1) the taps on row 0 come FIRST in the K order, in the
+    // horizontal stack of positions (0, 1) and (0, 2) the vertical-to-horizontal source (and (0, 1)'s tap on (0, 0)) does: these
+    // leading sources are class-table rows.  The accumulator pair after them is stored once per class (EPI_STATE) and the batch's
+    // launch continues it with the remaining sources (GemmParams::acc_*, row = label): the same MFMA sequence per output, bit for
+    // bit, at roughly half the K.
+    float *sv, *sh;                                        // [L][GRID][2][nc][2 dim], [L][2][2][nc][2 dim]
+    float* SV(int layer, int c, int which) const { return sv + (((size_t)layer * GRID + c) * 2 + which) * nc * 2 * dim; }
+    float* SH(int layer, int c, int which) const { return sh + (((size_t)layer * 2 + (c - 1)) * 2 + which) * nc * 2 * dim; }
     float* XVC(int level, int c) const { return xvc + ((size_t)(level - 1) * GRID + c) * nc * dim; }      // level 1 .. L, row 0, column c
     float* HVC(int layer, int c) const { return hvc + ((size_t)layer * GRID + c) * nc * 2 * dim; }
     float* XHC(int level) const { return xhc + (size_t)(level - 1) * nc * dim; }                          // level 1 .. L, position (0, 0)
@@ -153,6 +161,7 @@ Plan make_plan(const dvq_pixelcnn_weights* w, int64_t B, void* ws) {
     p.tab = dvq_knobs().pixelcnn_tables && w->planes_kind == DVQ_PLANES_F16X2 && w->w0_p && dvq_gemm_mode() == 1 && B >= 2L * w->n_classes;
     p.xvc = p.hvc = p.xhc = p.gc = p.hidc = p.lgc = nullptr;
     p.iota = nullptr;
+    p.sv = p.sh = nullptr;
     if (p.tab) {
         const size_t nc = (size_t)p.nc;
         p.xvc = (float*)take((size_t)p.L * GRID * nc * p.dim * 4);
@@ -162,6 +171,8 @@ Plan make_plan(const dvq_pixelcnn_weights* w, int64_t B, void* ws) {
         p.hidc = (float*)take(nc * w->n_hidden * 4);
         p.lgc = (float*)take(nc * w->n_in * 4);
         p.iota = (int64_t*)take(nc * 8);
+        p.sv = (float*)take((size_t)p.L * GRID * 2 * nc * 2 * p.dim * 4);
+        p.sh = (float*)take((size_t)p.L * 2 * 2 * nc * 2 * p.dim * 4);
     }
     p.bytes = (size_t)(c - (char*)ws);
     return p;
@@ -199,8 +210,11 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
     struct Act { const float* p; const int64_t* arow; };
     // ---- one layer of the vertical stack at grid row r for the M rows of (label, xv, out, pre): the row's columns do not depend on
     // each other -- one launch where the launch count is what costs (dvq_launch_gemm_gate_group)
+    // ``mode`` 0: the whole product.  1: only the leading sources that are class-table rows, on the table's own rows (M = classes),
+    // accumulator pair -> state_of(col, 0 / 1).  2: the remaining sources, continuing state_of(col, .) through the labels.
     auto vertical_layer = [&](int r, int l, long M, const int64_t* lab, auto xv_of /* (level, pos) -> Act */,
-                              auto out_of /* (col) -> float* (level l + 1) */, auto pre_of /* (col) -> float* */) -> int {
+                              auto out_of /* (col) -> float* (level l + 1) */, auto pre_of /* (col) -> float* */,
+                              int mode, auto state_of /* (col, which) -> float* */) -> int {
         const dvq_pixelcnn_layer& ly = w->layers_host[l];
         const int k = (l == 0) ? 5 : 3, pad = k / 2, KR = k / 2 + 1;
         GemmParams grp[GRID];
@@ -221,6 +235,30 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
                     g.src[ns++] = GemmSrc{a.p, ly.wv + tap * wsz, (long)dim, (long)dim, dim, kind,
                                           ly.wv_p ? ly.wv_p + tap * wsz : nullptr, (long)(KR * k) * (long)wsz, a.arow};
                 }
+            }
+            int lead = 0;                                    // leading sources read through the labels (class-table rows)
+            while (lead < ns && g.src[lead].arow) ++lead;
+            if (mode == 1) {                                 // the state of those sources, on the table's rows
+                if (lead == 0 || lead == ns) continue;
+                for (int i = 0; i < lead; ++i) g.src[i].arow = nullptr;
+                g.nsrc = lead;
+                g.M = M;
+                g.N = 2 * dim;
+                g.wscale = ly.sv;
+                g.out = state_of(c, 0);
+                g.ldo = 2 * dim;
+                g.pre = state_of(c, 1);
+                g.ldpre = 2 * dim;
+                DVQ_PROPAGATE(dvq_launch_gemm(g, EPI_STATE, st));
+                continue;
+            }
+            if (mode == 2 && lead > 0 && lead < ns) {        // continue the class's state with the sources that are per row
+                for (int i = lead; i < ns; ++i) g.src[i - lead] = g.src[i];
+                ns -= lead;
+                g.acc_hi = state_of(c, 0);
+                g.acc_lo = state_of(c, 1);
+                g.ldacc = 2 * dim;
+                g.acc_row = lab;
             }
             float* out = out_of(c);
             float* pre = pre_of(c);
@@ -249,7 +287,7 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
     // ---- the horizontal stack + head of one position for M rows; logits -> lg
     auto horizontal_position = [&](int r, int c, long M, const int64_t* lab, auto hv_of /* (layer, col) -> Act */,
                                    auto xh_of /* (level, pos) -> Act */, auto xh_out /* (level) -> float* at this position */,
-                                   float* gbuf, float* hid, float* lg) -> int {
+                                   float* gbuf, float* hid, float* lg, int mode, auto state_of /* (layer, which) -> float* */) -> int {
         const int pos = r * GRID + c;
         for (int l = 0; l < L; ++l) {
             const dvq_pixelcnn_layer& ly = w->layers_host[l];
@@ -268,6 +306,30 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
                 const Act a = xh_of(l, r * GRID + ic);
                 g.src[ns++] = GemmSrc{a.p, ly.wh + kc * wsz, (long)dim, (long)dim, dim, kind,
                                       ly.wh_p ? ly.wh_p + kc * wsz : nullptr, (long)KC * (long)wsz, a.arow};
+            }
+            int lead = 0;
+            while (lead < ns && g.src[lead].arow) ++lead;
+            if (mode == 1) {
+                if (lead == 0 || lead == ns) continue;
+                for (int i = 0; i < lead; ++i) g.src[i].arow = nullptr;
+                g.nsrc = lead;
+                g.M = M;
+                g.N = 2 * dim;
+                g.wscale = ly.sh;
+                g.out = state_of(l, 0);
+                g.ldo = 2 * dim;
+                g.pre = state_of(l, 1);
+                g.ldpre = 2 * dim;
+                DVQ_PROPAGATE(dvq_launch_gemm(g, EPI_STATE, st));
+                continue;
+            }
+            if (mode == 2 && lead > 0 && lead < ns) {
+                for (int i = lead; i < ns; ++i) g.src[i - lead] = g.src[i];
+                ns -= lead;
+                g.acc_hi = state_of(l, 0);
+                g.acc_lo = state_of(l, 1);
+                g.ldacc = 2 * dim;
+                g.acc_row = lab;
             }
             g.nsrc = ns;
             g.M = M;
@@ -296,6 +358,7 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
                 DVQ_PROPAGATE(dvq_launch_gemm(q, EPI_BIAS, st));
             }
         }
+        if (mode == 1) return DVQ_OK;                        // states only
         GemmParams h0 = {};
         h0.src[0] = GemmSrc{xh_out(L), w->w0, (long)dim, (long)dim, dim, kind, w->w0_p, (long)w->n_hidden * dim, nullptr};
         h0.wscale = w->s0;
@@ -314,12 +377,32 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
         const long nc = pl.nc;
         DVQ_LAUNCH(iota_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, pl.iota, (int)nc);
         DVQ_CHECK_LAUNCH("iota");
+        auto no_state = [](int, int) -> float* { return nullptr; };
         auto xv_c = [&](int level, int pos) { return Act{pl.XVC(level, pos), nullptr}; };     // row 0 only reads row 0 (levels >= 1)
         for (int l = 0; l < L; ++l)
-            DVQ_PROPAGATE(vertical_layer(0, l, nc, pl.iota, xv_c, [&](int c) { return pl.XVC(l + 1, c); }, [&](int c) { return pl.HVC(l, c); }));
+            DVQ_PROPAGATE(vertical_layer(0, l, nc, pl.iota, xv_c, [&](int c) { return pl.XVC(l + 1, c); }, [&](int c) { return pl.HVC(l, c); },
+                                         0, no_state));
         auto hv_c = [&](int layer, int col) { return Act{pl.HVC(layer, col), nullptr}; };
         auto xh_c = [&](int level, int pos) { (void)pos; return Act{pl.XHC(level), nullptr}; }; // position (0, 0) reads itself only, levels >= 1
-        DVQ_PROPAGATE(horizontal_position(0, 0, nc, pl.iota, hv_c, xh_c, [&](int level) { return pl.XHC(level); }, pl.gc, pl.hidc, pl.lgc));
+        DVQ_PROPAGATE(horizontal_position(0, 0, nc, pl.iota, hv_c, xh_c, [&](int level) { return pl.XHC(level); }, pl.gc, pl.hidc, pl.lgc,
+                                          0, no_state));
+        // ---- the accumulator states of the leading class-only sources: vertical stack of row 1, positions (0, 1) and (0, 2).  The
+        // source lists are built exactly as for the batch (table rows marked by a row index); mode 1 keeps the marked prefix.
+        auto xv_m = [&](int level, int pos) {
+            if (level >= 1 && pos < GRID) return Act{pl.XVC(level, pos), pl.iota};
+            return Act{pl.XV(level, pos), nullptr};                                            // never read in mode 1
+        };
+        for (int l = 0; l < L; ++l)
+            DVQ_PROPAGATE(vertical_layer(1, l, nc, pl.iota, xv_m, [&](int) -> float* { return nullptr; }, [&](int) -> float* { return nullptr; },
+                                         1, [&](int c, int which) { return pl.SV(l, c, which); }));
+        auto hv_m = [&](int layer, int col) { return Act{pl.HVC(layer, col), pl.iota}; };
+        auto xh_m = [&](int level, int pos) {
+            if (level >= 1 && pos == 0) return Act{pl.XHC(level), pl.iota};
+            return Act{pl.XH(level, pos), nullptr};
+        };
+        for (int c = 1; c < GRID; ++c)
+            DVQ_PROPAGATE(horizontal_position(0, c, nc, pl.iota, hv_m, xh_m, [&](int) -> float* { return nullptr; }, nullptr, nullptr, nullptr,
+                                              1, [&](int layer, int which) { return pl.SH(layer, c, which); }));
     }
     for (int64_t b0 = 0; b0 < B; b0 += pl.chunk) {
         const long Bc = (long)((B - b0 < pl.chunk) ? (B - b0) : pl.chunk);
@@ -349,14 +432,17 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
             if (!(pl.tab && r == 0))
                 for (int l = 0; l < L; ++l)
                     DVQ_PROPAGATE(vertical_layer(r, l, Bc, pl.lab, xv_b, [&](int c) { return pl.XV(l + 1, r * GRID + c); },
-                                                 [&](int c) { return pl.HV(l, c); }));
+                                                 [&](int c) { return pl.HV(l, c); }, (pl.tab && r == 1) ? 2 : 0,
+                                                 [&](int c, int which) { return pl.SV(l, c, which); }));
             // ---- horizontal stack + head + draw, position by position
             for (int c = 0; c < GRID; ++c) {
                 const int pos = r * GRID + c;
                 const bool from_table = pl.tab && pos == 0;     // its logits are the class table's rows
                 if (!from_table)
                     DVQ_PROPAGATE(horizontal_position(r, c, Bc, pl.lab, [&](int layer, int col) { return hv_b(layer, col, r); }, xh_b,
-                                                      [&](int level) { return pl.XH(level, pos); }, pl.g, pl.hid, pl.lg));
+                                                      [&](int level) { return pl.XH(level, pos); }, pl.g, pl.hid, pl.lg,
+                                                      (pl.tab && r == 0) ? 2 : 0,
+                                                      [&](int layer, int which) { return pl.SH(layer, c, which); }));
                 {
                 DVQ_PROF("pixelcnn_draw", 0, (double)Bc * (2.0 * w->n_in + dim) * 4, st);
                 DVQ_LAUNCH(sample_kernel, dim3((unsigned)((Bc + 3) / 4)), dim3(256), 0, st, from_table ? pl.lgc : pl.lg,
