@@ -487,9 +487,18 @@ def main():
                                "all_mfma_kernels": {"achieved": all_fl / (all_ms * 1e-3) / 1e12, "share_of_step": all_ms / pe_ms}}
             if pn_filtered:
                 pn_ms = sum(kernels[k]["ms"] for k in ("pn_center", "pn_trunk", "pn_exact") if k in kernels)
+                tk = kernels["pn_trunk"]
+                tk_tr, tk_src = pmc_traffic("pn_trunk", B)
                 out["roofline"]["pointnet_trunks"] = {
                     "kernels": "pn_center_kernel + pn_trunk_filter_kernel + pn_exact_kernel",
                     "share_of_step": pn_ms / pe_ms, "algorithmic_tflops": kernels["pn_trunk"]["flops"] / (pn_ms * 1e-3) / 1e12,
+                    # the trunk kernel by itself, priced like the primary object (its share of the step is as large as the gated GEMMs'):
+                    # algorithmic FLOPs of conv1 + conv2 + conv3 per launch over the launch time, against the dense fp16 MFMA peak (conv3,
+                    # 94 % of the FLOPs, runs as ONE fp16 product; conv2's six bf16 products count once)
+                    "trunk_kernel": {"bound": "mfma", "achieved": tk["flops"] / (tk["ms"] * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                                     "frac": tk["flops"] / (tk["ms"] * 1e-3) / 1e12 / 2500.0, "launches": tk["count"],
+                                     "avg_launch_ms": tk["ms"] / tk["count"], "share_of_step": tk["ms"] / pe_ms,
+                                     "traffic": tk_tr, "traffic_source": tk_src},
                     "note": "conv1/conv2 six-product split-bf16, conv3 + max as an fp16 matrix-core filter (1 product) + exact fp32 "
                             "re-evaluation of the candidate points; result bit-identical to the exhaustive exact maximum "
                             "(tests/test_gpu_parity.py::test_pointnet_filter_equals_exhaustive_exact_evaluation); algorithmic "

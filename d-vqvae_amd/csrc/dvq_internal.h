@@ -160,6 +160,7 @@ struct GemmParams {
     const float* acc_lo;
     long ldacc;
     const int64_t* acc_row;
+    int prof_cls;            // 1 = a launch on a class table's rows: "gemm_*_cls" in the per-launch breakdown, small-batch kernels up to 1 024 rows
     int dbg_abl;             // diagnostics only (env DVQ_GEMM_ABL): 2 = no MFMAs
     unsigned long long* dbg_clk;   // diagnostics only (env DVQ_GEMM_CLK=1): block 0 stores {memtime, memrealtime} x {begin, end}
 };

@@ -542,7 +542,9 @@ int launch_tiled(const GemmParams& p, hipStream_t stream) {
         if (dvq_knobs().gemm_tn == 128) narrow = true;
         if (dvq_knobs().gemm_tn == 256) narrow = false;
     }
-    static const char* const names[] = {"gemm_bias", "gemm_resid", "gemm_gate", "", "", "gemm_state"};
+    static const char* const names_row[] = {"gemm_bias", "gemm_resid", "gemm_gate", "", "", "gemm_state"};
+    static const char* const names_cls[] = {"gemm_bias_cls", "gemm_resid_cls", "gemm_gate_cls", "", "", "gemm_state"};
+    const char* const* names = p.prof_cls ? names_cls : names_row;
     double ksum = 0;
     int T = 0;
     for (int s = 0; s < p.nsrc; ++s) { ksum += p.src[s].K; T += p.src[s].K / BK; }
@@ -748,6 +750,9 @@ __global__ __launch_bounds__(64) void gemm_f16x2_skinny_gate_group_kernel(const 
 }
 
 constexpr long SKINNY_MAX_M = 256;     // above this the tiled kernel wins (every row group re-reads the weight panel from L2)
+// launches on a class table's rows (pixelcnn.hip: a chain of ~150 dependent launches per call on n_classes rows) are latency-bound
+// up to more rows: 512 rows measured 7.0 -> 4.6 ms per call
+inline long skinny_max_m(const GemmParams& p) { return p.prof_cls ? 4 * SKINNY_MAX_M : SKINNY_MAX_M; }
 
 template <int EPI, int R>
 void launch_skinny_r(const GemmParams& p, int T, int gy, hipStream_t stream) {
@@ -758,7 +763,9 @@ void launch_skinny_r(const GemmParams& p, int T, int gy, hipStream_t stream) {
 
 template <int EPI>
 int launch_skinny(const GemmParams& p, hipStream_t stream) {
-    static const char* const names[] = {"gemm_bias", "gemm_resid", "gemm_gate", "", "", "gemm_state"};
+    static const char* const names_row[] = {"gemm_bias", "gemm_resid", "gemm_gate", "", "", "gemm_state"};
+    static const char* const names_cls[] = {"gemm_bias_cls", "gemm_resid_cls", "gemm_gate_cls", "", "", "gemm_state"};
+    const char* const* names = p.prof_cls ? names_cls : names_row;
     double ksum = 0;
     int T = 0;
     for (int s = 0; s < p.nsrc; ++s) { ksum += p.src[s].K; T += p.src[s].K / BK; }
@@ -804,7 +811,7 @@ int launch_skinny_gate_group(const GemmParams* ps, int n, hipStream_t stream) {
     const int gy = (int)((ps[0].M + 15) / 16);
     const int want = dvq_knobs().gemm_skinny_cols;          // as launch_skinny: the same width, hence the same kernel body per output
     {
-        DVQ_PROF("gemm_gate", flops, bytes, stream);
+        DVQ_PROF(ps[0].prof_cls ? "gemm_gate_cls" : "gemm_gate", flops, bytes, stream);
         if (want == 4) launch_skinny_gate_group_r<4>(g, n, gy, stream); else launch_skinny_gate_group_r<8>(g, n, gy, stream);
     }
     DVQ_CHECK_LAUNCH("gemm_f16x2_skinny_group");
@@ -887,14 +894,14 @@ static int check_f16x2(const GemmParams& p, GemmEpilogue epi) {
 // fp16 planes.  Returns DVQ_OK after ONE launch, or a negative value when the group has to run as single launches (M beyond the
 // skinny kernel, DVQ_GEMM_SKINNY=0).
 int dvq_launch_gemm_f16x2_gate_group(const GemmParams* ps, int n, hipStream_t stream) {
-    if (!dvq_knobs().gemm_skinny || ps[0].M > SKINNY_MAX_M) return -1;
+    if (!dvq_knobs().gemm_skinny || ps[0].M > skinny_max_m(ps[0])) return -1;
     for (int i = 0; i < n; ++i) DVQ_PROPAGATE(check_f16x2(ps[i], EPI_GATE));
     return launch_skinny_gate_group(ps, n, stream);
 }
 
 int dvq_launch_gemm_f16x2(const GemmParams& p, GemmEpilogue epi, hipStream_t stream) {
     DVQ_PROPAGATE(check_f16x2(p, epi));
-    if (dvq_knobs().gemm_skinny && p.M <= SKINNY_MAX_M) switch (epi) {
+    if (dvq_knobs().gemm_skinny && p.M <= skinny_max_m(p)) switch (epi) {
         case EPI_BIAS: return launch_skinny<EPI_BIAS>(p, stream);
         case EPI_RESID: return launch_skinny<EPI_RESID>(p, stream);
         case EPI_GATE: return launch_skinny<EPI_GATE>(p, stream);

@@ -243,6 +243,7 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
                 for (int i = 0; i < lead; ++i) g.src[i].arow = nullptr;
                 g.nsrc = lead;
                 g.M = M;
+                g.prof_cls = 1;
                 g.N = 2 * dim;
                 g.wscale = ly.sv;
                 g.out = state_of(c, 0);
@@ -270,6 +271,7 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
             }
             g.nsrc = ns;
             g.M = M;
+            g.prof_cls = lab == pl.iota;
             g.N = 2 * dim;
             g.bias = ly.bv;
             g.wscale = ly.sv;
@@ -314,6 +316,7 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
                 for (int i = 0; i < lead; ++i) g.src[i].arow = nullptr;
                 g.nsrc = lead;
                 g.M = M;
+                g.prof_cls = 1;
                 g.N = 2 * dim;
                 g.wscale = ly.sh;
                 g.out = state_of(l, 0);
@@ -333,6 +336,7 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
             }
             g.nsrc = ns;
             g.M = M;
+            g.prof_cls = lab == pl.iota;
             g.N = 2 * dim;
             g.bias = ly.bh;
             g.wscale = ly.sh;
@@ -346,6 +350,7 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
             q.wscale = ly.sr;
             q.nsrc = 1;
             q.M = M;
+            q.prof_cls = lab == pl.iota;
             q.N = dim;
             q.bias = ly.br;
             q.out = xh_out(l + 1);
@@ -362,12 +367,12 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
         GemmParams h0 = {};
         h0.src[0] = GemmSrc{xh_out(L), w->w0, (long)dim, (long)dim, dim, kind, w->w0_p, (long)w->n_hidden * dim, nullptr};
         h0.wscale = w->s0;
-        h0.nsrc = 1; h0.M = M; h0.N = w->n_hidden; h0.bias = w->b0; h0.out = hid; h0.ldo = w->n_hidden; h0.relu = 1;
+        h0.nsrc = 1; h0.M = M; h0.prof_cls = lab == pl.iota; h0.N = w->n_hidden; h0.bias = w->b0; h0.out = hid; h0.ldo = w->n_hidden; h0.relu = 1;
         DVQ_PROPAGATE(dvq_launch_gemm(h0, EPI_BIAS, st));
         GemmParams h2 = {};
         h2.src[0] = GemmSrc{hid, w->w2, (long)w->n_hidden, (long)w->n_hidden, w->n_hidden, kind, w->w2_p, (long)w->n_in * w->n_hidden, nullptr};
         h2.wscale = w->s2;
-        h2.nsrc = 1; h2.M = M; h2.N = w->n_in; h2.bias = w->b2; h2.out = lg; h2.ldo = w->n_in;
+        h2.nsrc = 1; h2.M = M; h2.prof_cls = lab == pl.iota; h2.N = w->n_in; h2.bias = w->b2; h2.out = lg; h2.ldo = w->n_in;
         DVQ_PROPAGATE(dvq_launch_gemm(h2, EPI_BIAS, st));
         return DVQ_OK;
     };
