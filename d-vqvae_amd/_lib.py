@@ -22,7 +22,7 @@ _lock = threading.Lock()
 _lib = None
 
 DVQ_MAX_SRC = 8
-ABI_VERSION = 6            # DVQ_ABI_VERSION of include/dvq.h, which the struct mirrors below follow (tests/test_abi.py compares both with the library's)
+ABI_VERSION = 7            # DVQ_ABI_VERSION of include/dvq.h, which the struct mirrors below follow (tests/test_abi.py compares both with the library's)
 PLANES_BF16X3, PLANES_F16X2 = 0, 1
 
 c_f32p = C.c_void_p      # device pointers travel as integers
@@ -59,7 +59,7 @@ class PixelcnnWeights(C.Structure):
                 ("n_hidden", C.c_int32), ("planes_kind", C.c_int32), ("tok_emb", C.c_void_p),
                 ("layers_host", C.POINTER(PixelcnnLayer)), ("w0", C.c_void_p), ("b0", C.c_void_p),
                 ("w2", C.c_void_p), ("b2", C.c_void_p), ("w0_p", C.c_void_p), ("w2_p", C.c_void_p),
-                ("s0", C.c_void_p), ("s2", C.c_void_p)]
+                ("s0", C.c_void_p), ("s2", C.c_void_p), ("class_tables", C.c_void_p)]
 
 
 class ManoModel(C.Structure):
@@ -100,6 +100,8 @@ SIGNATURES = {
     "dvq_pointnet_pack_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dvq_pointnet_encode": (C.c_int, [C.POINTER(PointnetWeights), c_f32p, C.c_int64, C.c_int, c_f32p, C.c_int64, c_f32p,
                                       C.c_void_p, C.c_size_t, c_stream]),
+    "dvq_pixelcnn_tables_bytes": (C.c_size_t, [C.POINTER(PixelcnnWeights)]),
+    "dvq_pixelcnn_build_tables": (C.c_int, [C.POINTER(PixelcnnWeights), C.c_void_p, C.c_size_t, c_stream]),
     "dvq_pixelcnn_workspace_bytes": (C.c_size_t, [C.POINTER(PixelcnnWeights), C.c_int64]),
     "dvq_pixelcnn_sample": (C.c_int, [C.POINTER(PixelcnnWeights), c_i64p, c_f32p, C.c_int64, c_i64p, c_f32p, c_i32p,
                                       C.c_void_p, C.c_size_t, c_stream]),

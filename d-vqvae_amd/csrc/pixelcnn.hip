@@ -119,6 +119,7 @@ struct Plan {
     // they are evaluated once per class (nc rows instead of one per sample) and read through the label wherever the batch needs
     // them (GemmSrc::arow, the draw kernel's row index) -- the same kernels per row, hence the same bits.
     bool tab;
+    bool prebuilt;                                         // the tables are the weights' own (dvq_pixelcnn_build_tables), not the workspace's
     int nc;
     float *xvc, *hvc, *xhc, *gc, *hidc, *lgc;
     int64_t* iota;
@@ -138,6 +139,28 @@ struct Plan {
     float* HV(int layer, int col) const { return hv + ((size_t)layer * GRID + col) * chunk * 2 * dim; }
 };
 
+bool tables_possible(const dvq_pixelcnn_weights* w) {
+    return dvq_knobs().pixelcnn_tables && w->planes_kind == DVQ_PLANES_F16X2 && w->w0_p && dvq_gemm_mode() == 1;
+}
+
+// the class-table pointers of ``p`` inside ``base`` (null: sizes only); returns the bytes
+size_t carve_tables(Plan& p, const dvq_pixelcnn_weights* w, char* base) {
+    char* c = base;
+    auto take = [&](size_t n) { char* q = c; c += dvq_round_up(n, 256); return q; };
+    const size_t nc = (size_t)w->n_classes, L = (size_t)w->n_layers, dim = (size_t)w->dim;
+    p.nc = w->n_classes;
+    p.xvc = (float*)take(L * GRID * nc * dim * 4);
+    p.hvc = (float*)take(L * GRID * nc * 2 * dim * 4);
+    p.xhc = (float*)take(L * nc * dim * 4);
+    p.gc = (float*)take(nc * dim * 4);
+    p.hidc = (float*)take(nc * w->n_hidden * 4);
+    p.lgc = (float*)take(nc * w->n_in * 4);
+    p.iota = (int64_t*)take(nc * 8);
+    p.sv = (float*)take(L * GRID * 2 * nc * 2 * dim * 4);
+    p.sh = (float*)take(L * 2 * 2 * nc * 2 * dim * 4);
+    return (size_t)(c - base);
+}
+
 Plan make_plan(const dvq_pixelcnn_weights* w, int64_t B, void* ws) {
     Plan p;
     p.L = w->n_layers;
@@ -156,24 +179,17 @@ Plan make_plan(const dvq_pixelcnn_weights* w, int64_t B, void* ws) {
     p.hid = (float*)take((size_t)chunk * w->n_hidden * 4);
     p.lg = (float*)take((size_t)chunk * w->n_in * 4);
     p.lab = (int64_t*)take((size_t)chunk * 8);
-    // class tables: fp16-plane kernels only (they read activation rows through an index), batches that are larger than the table
+    // class tables: fp16-plane kernels only (they read activation rows through an index).  The weights' own when they carry them
+    // (any batch size); else built per call in the workspace by batches that are at least twice the table
     p.nc = w->n_classes;
-    p.tab = dvq_knobs().pixelcnn_tables && w->planes_kind == DVQ_PLANES_F16X2 && w->w0_p && dvq_gemm_mode() == 1 && B >= 2L * w->n_classes;
+    const bool can = tables_possible(w);
+    p.prebuilt = can && w->class_tables != nullptr;
+    p.tab = can && (p.prebuilt || B >= 2L * w->n_classes);
     p.xvc = p.hvc = p.xhc = p.gc = p.hidc = p.lgc = nullptr;
     p.iota = nullptr;
     p.sv = p.sh = nullptr;
-    if (p.tab) {
-        const size_t nc = (size_t)p.nc;
-        p.xvc = (float*)take((size_t)p.L * GRID * nc * p.dim * 4);
-        p.hvc = (float*)take((size_t)p.L * GRID * nc * 2 * p.dim * 4);
-        p.xhc = (float*)take((size_t)p.L * nc * p.dim * 4);
-        p.gc = (float*)take(nc * p.dim * 4);
-        p.hidc = (float*)take(nc * w->n_hidden * 4);
-        p.lgc = (float*)take(nc * w->n_in * 4);
-        p.iota = (int64_t*)take(nc * 8);
-        p.sv = (float*)take((size_t)p.L * GRID * 2 * nc * 2 * p.dim * 4);
-        p.sh = (float*)take((size_t)p.L * 2 * 2 * nc * 2 * p.dim * 4);
-    }
+    if (p.prebuilt) (void)carve_tables(p, w, (char*)w->class_tables);
+    else if (p.tab) c += carve_tables(p, w, c);
     p.bytes = (size_t)(c - (char*)ws);
     return p;
 }
@@ -191,17 +207,27 @@ int check_weights(const dvq_pixelcnn_weights* w) {
     return DVQ_OK;
 }
 
+// ``build`` non-null: only the class tables of ``w``, into that buffer (dvq_pixelcnn_build_tables)
 int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise, const int64_t* forced, int64_t B,
-        int64_t* codes, float* logits_out, int32_t* err_flag, void* ws, size_t ws_bytes, hipStream_t st) {
+        int64_t* codes, float* logits_out, int32_t* err_flag, void* ws, size_t ws_bytes, hipStream_t st, void* build = nullptr) {
     DVQ_PROPAGATE(check_weights(w));
-    DVQ_REQUIRE(B >= 0, "pixelcnn: negative batch");
-    if (B == 0) return DVQ_OK;
-    DVQ_REQUIRE(label && (forced || (noise && codes)), "pixelcnn: null input");
-    DVQ_REQUIRE(ws && dvq_aligned16(ws), "pixelcnn: null/unaligned workspace");
-    const Plan pl = make_plan(w, B, ws);
-    if (ws_bytes < pl.bytes) {
-        dvq_set_error("pixelcnn: workspace %zu < %zu bytes", ws_bytes, pl.bytes);
-        return DVQ_EWORKSPACE;
+    Plan pl;
+    if (build) {
+        pl = Plan{};
+        pl.L = w->n_layers;
+        pl.dim = w->dim;
+        pl.tab = true;
+        (void)carve_tables(pl, w, (char*)build);
+    } else {
+        DVQ_REQUIRE(B >= 0, "pixelcnn: negative batch");
+        if (B == 0) return DVQ_OK;
+        DVQ_REQUIRE(label && (forced || (noise && codes)), "pixelcnn: null input");
+        DVQ_REQUIRE(ws && dvq_aligned16(ws), "pixelcnn: null/unaligned workspace");
+        pl = make_plan(w, B, ws);
+        if (ws_bytes < pl.bytes) {
+            dvq_set_error("pixelcnn: workspace %zu < %zu bytes", ws_bytes, pl.bytes);
+            return DVQ_EWORKSPACE;
+        }
     }
     const int dim = w->dim, L = w->n_layers;
     const int kind = w->planes_kind;                      // DVQ_PLANES_*: what every *_p image of this network holds
@@ -377,8 +403,9 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
         return DVQ_OK;
     };
 
-    if (pl.tab) {
-        // ---- once per call: row 0's vertical stack and position (0, 0)'s horizontal stack + head for every class (label = row)
+    if (pl.tab && !pl.prebuilt) {
+        // ---- once per call (once per model with dvq_pixelcnn_build_tables): row 0's vertical stack and position (0, 0)'s
+        // horizontal stack + head for every class (label = row)
         const long nc = pl.nc;
         DVQ_LAUNCH(iota_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, st, pl.iota, (int)nc);
         DVQ_CHECK_LAUNCH("iota");
@@ -409,6 +436,7 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
             DVQ_PROPAGATE(horizontal_position(0, c, nc, pl.iota, hv_m, xh_m, [&](int) -> float* { return nullptr; }, nullptr, nullptr, nullptr,
                                               1, [&](int layer, int which) { return pl.SH(layer, c, which); }));
     }
+    if (build) return DVQ_OK;
     for (int64_t b0 = 0; b0 < B; b0 += pl.chunk) {
         const long Bc = (long)((B - b0 < pl.chunk) ? (B - b0) : pl.chunk);
         DVQ_LAUNCH(sanitize_labels_kernel, dim3((unsigned)((Bc + 255) / 256)), dim3(256), 0, st, label + b0, Bc,
@@ -464,6 +492,21 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
 }
 
 }  // namespace
+
+extern "C" size_t dvq_pixelcnn_tables_bytes(const dvq_pixelcnn_weights* w) {
+    if (!w || w->planes_kind != DVQ_PLANES_F16X2 || !w->w0_p) return 0;
+    Plan p = {};
+    return carve_tables(p, w, nullptr);
+}
+
+extern "C" int dvq_pixelcnn_build_tables(const dvq_pixelcnn_weights* w, void* tables, size_t tables_bytes, dvq_stream_t stream) {
+    DVQ_REQUIRE(w && tables && dvq_aligned16(tables), "pixelcnn_build_tables: null / unaligned buffer");
+    DVQ_REQUIRE(w->planes_kind == DVQ_PLANES_F16X2 && w->w0_p && dvq_gemm_mode() == 1,
+                "pixelcnn_build_tables: class tables exist for fp16 weight images only (DVQ_PLANES_F16X2)");
+    DVQ_REQUIRE(tables_bytes >= dvq_pixelcnn_tables_bytes(w), "pixelcnn_build_tables: buffer %zu < %zu bytes", tables_bytes,
+                dvq_pixelcnn_tables_bytes(w));
+    return run(w, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, (hipStream_t)stream, tables);
+}
 
 extern "C" size_t dvq_pixelcnn_workspace_bytes(const dvq_pixelcnn_weights* w, int64_t B) {
     if (!w || B <= 0) return 256;

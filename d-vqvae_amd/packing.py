@@ -153,7 +153,7 @@ class _Packed:
         if self.device == device and getattr(self, "kind", None) == self._kind():
             return self
         self.tensors = {k: (v.to(device) if v.dtype == torch.int16 else _dev(v, device)) for k, v in self.tensors.items()
-                        if not k.endswith(("__planes", "__filter", "__scale"))}
+                        if not k.endswith(("__planes", "__filter", "__scale", "__tables"))}
         self.device = device
         self.kind = self._kind()
         for scale_key, keys in self._plane_groups():    # weight images of the GEMM weights, built on the device
@@ -305,7 +305,19 @@ class PackedPixelCNN(_Packed):
         s.w0_p, s.w2_p = self.planes_ptr("w0"), self.planes_ptr("w2")
         s.s0, s.s2 = self.scale_ptr("s0"), self.scale_ptr("s2")
         s.planes_kind = self.kind
+        s.class_tables = None
         self.cstruct = s
+        # What depends on the class label only (grid row 0's vertical stack, position (0, 0), the accumulator states that follow from
+        # them) is a function of the weights: built once here (include/dvq.h: dvq_pixelcnn_build_tables), read by every call.
+        lib = _lib.load()
+        nbytes = lib.dvq_pixelcnn_tables_bytes(C.byref(s)) if self.device is not None and self.device.type == "cuda" else 0
+        if nbytes:
+            with torch.cuda.device(self.device):
+                buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+                _lib.check(lib.dvq_pixelcnn_build_tables(C.byref(s), buf.data_ptr(), nbytes, torch.cuda.current_stream(self.device).cuda_stream),
+                           "dvq_pixelcnn_build_tables")
+            self.tensors["class__tables"] = buf
+            s.class_tables = buf.data_ptr()
 
     def _plane_groups(self):
         g = []

@@ -39,7 +39,7 @@ typedef enum {
 
 /* The version of this header.  dvq_abi_version() returns the library's: a binding checks the two for equality at load time
  * (struct layouts change between versions). */
-#define DVQ_ABI_VERSION 6
+#define DVQ_ABI_VERSION 7
 int dvq_abi_version(void);
 const char* dvq_last_error(void);
 /* number of visible HIP devices, or -1; does not create a context */
@@ -210,7 +210,17 @@ typedef struct {
     const float *w2, *b2;       /* output_conv.2 [n_in][n_hidden] */
     const uint16_t *w0_p, *w2_p; /* optional weight images */
     const float *s0, *s2;        /* DVQ_PLANES_F16X2: their row scales [n_hidden], [n_in] */
+    /* optional (DVQ_PLANES_F16X2 images only): the class tables of dvq_pixelcnn_build_tables for EXACTLY these weights.  With them
+     * every call -- B = 1 included -- reads what depends on the class label only (grid row 0's vertical stack, position (0, 0),
+     * the accumulator states of the sources that follow from them) instead of computing it; without them calls of at least two
+     * rows per class build them per call in the workspace.  The results are the same bits either way. */
+    const void* class_tables;
 } dvq_pixelcnn_weights;
+
+/* Class tables of a packed prior (weights only: build once per model).  dvq_pixelcnn_tables_bytes() = 0 when the weight images
+ * are not DVQ_PLANES_F16X2 (the tables are read by the fp16-plane kernels). */
+size_t dvq_pixelcnn_tables_bytes(const dvq_pixelcnn_weights* w_host);
+int dvq_pixelcnn_build_tables(const dvq_pixelcnn_weights* w_host, void* tables, size_t tables_bytes, dvq_stream_t stream);
 
 size_t dvq_pixelcnn_workspace_bytes(const dvq_pixelcnn_weights* w_host, int64_t B);
 /* label [B] int64 in [0,n_classes), noise q [B,9,n_in] -> codes [B,9] int64 (raster order).

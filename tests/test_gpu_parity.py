@@ -444,13 +444,39 @@ def test_pixelcnn_class_tables_equal_per_row_evaluation(cfg, B):
     b = _with_env("DVQ_PIXELCNN_TABLES", "0", run)
     for name, u, v in zip(("teacher-forced logits", "sampled codes", "sampling logits"), a, b):
         assert torch.equal(u, v), f"{name}: class tables != per-row evaluation"
-    # and the class tables must be in use at this size (the workspace is larger with them)
+    # the packer built the tables once for the weights (include/dvq.h: dvq_pixelcnn_build_tables); without them in the struct a
+    # batch of at least two rows per class builds them per call in its workspace: the same bits again
     import ctypes
     from dvqvae_amd import _lib
     pk = net.packed()
-    with_tab = _lib.load().dvq_pixelcnn_workspace_bytes(ctypes.byref(pk.cstruct), B)
-    without = _with_env("DVQ_PIXELCNN_TABLES", "0", lambda: _lib.load().dvq_pixelcnn_workspace_bytes(ctypes.byref(pk.cstruct), B))
-    assert with_tab > without
+    assert pk.cstruct.class_tables, "the packed prior carries no class tables"
+    lib = _lib.load()
+    ws_pre = lib.dvq_pixelcnn_workspace_bytes(ctypes.byref(pk.cstruct), B)
+    keep = pk.cstruct.class_tables
+    pk.cstruct.class_tables = None
+    try:
+        c = run()
+        ws_call = lib.dvq_pixelcnn_workspace_bytes(ctypes.byref(pk.cstruct), B)
+    finally:
+        pk.cstruct.class_tables = keep
+    for name, u, v in zip(("teacher-forced logits", "sampled codes", "sampling logits"), a, c):
+        assert torch.equal(u, v), f"{name}: tables of the packer != tables built per call"
+    assert ws_call > ws_pre, "per-call tables live in the workspace"
+
+
+def test_pixelcnn_class_tables_serve_single_calls():
+    """With the packer's tables a B = 1 call reads row 0's vertical stack and position (0, 0) instead of computing them: it
+    must still equal the per-row evaluation, and a batch must equal its rows one by one."""
+    net, _ = _prior((512, 512, 15, 128), SEED + 22)
+    g = torch.Generator().manual_seed(3)
+    lab = gpu(torch.randint(0, 128, (6,), generator=g))
+    q = gpu(synth.exp1_noise(6, 9, 512, seed=33))
+    codes, logits = net.generate(None, lab, batch_size=6, noise=q, return_logits=True)
+    for i in range(6):
+        ci, li = net.generate(None, lab[i:i + 1], batch_size=1, noise=q[i:i + 1].contiguous(), return_logits=True)
+        assert torch.equal(ci, codes[i:i + 1]) and torch.equal(li, logits[i:i + 1]), f"row {i}: B = 1 call != its row of the batch"
+    c0, l0 = _with_env("DVQ_PIXELCNN_TABLES", "0", lambda: net.generate(None, lab, batch_size=6, noise=q, return_logits=True))
+    assert torch.equal(c0, codes) and torch.equal(l0, logits), "class tables != per-row evaluation at small batches"
 
 
 def test_pixelcnn_label_out_of_range():
