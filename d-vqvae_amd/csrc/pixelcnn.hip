@@ -494,7 +494,7 @@ int run(const dvq_pixelcnn_weights* w, const int64_t* label, const float* noise,
 }  // namespace
 
 extern "C" size_t dvq_pixelcnn_tables_bytes(const dvq_pixelcnn_weights* w) {
-    if (!w || w->planes_kind != DVQ_PLANES_F16X2 || !w->w0_p) return 0;
+    if (!w || w->planes_kind != DVQ_PLANES_F16X2 || !w->w0_p || dvq_gemm_mode() != 1) return 0;
     Plan p = {};
     return carve_tables(p, w, nullptr);
 }

@@ -218,7 +218,7 @@ typedef struct {
 } dvq_pixelcnn_weights;
 
 /* Class tables of a packed prior (weights only: build once per model).  dvq_pixelcnn_tables_bytes() = 0 when the weight images
- * are not DVQ_PLANES_F16X2 (the tables are read by the fp16-plane kernels). */
+ * are not DVQ_PLANES_F16X2 or the process runs DVQ_GEMM=fp32 (the tables are read by the fp16-plane kernels). */
 size_t dvq_pixelcnn_tables_bytes(const dvq_pixelcnn_weights* w_host);
 int dvq_pixelcnn_build_tables(const dvq_pixelcnn_weights* w_host, void* tables, size_t tables_bytes, dvq_stream_t stream);
 
