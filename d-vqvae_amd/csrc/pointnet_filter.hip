@@ -42,7 +42,8 @@ constexpr int MAX_TILES = 64;                             // filtered trunk: N <
 
 constexpr int F_STAGE2 = 3 * 64 * 128;                    // conv2: one half of W2's planes (3 x 64 rows x 128 B)
 constexpr int F_STAGE3 = 64 * 256;                        // conv3: 64 channels x 128 k fp16
-constexpr int F_OFF_TB = 2 * F_STAGE3;                    // conv3 phase: [8 chunks][4 waves][4][64] fp32 behind the two W3 stages
+constexpr int F_OFF_TB = 2 * F_STAGE3;                    // conv3 phase: record ring [4 chunks][4 waves][2 halves][3][64] fp32 (24 KiB of the 32 reserved) behind the two W3 stages
+constexpr int F_SLOT = 4 * 2 * 3 * 64;                    // floats per chunk slot of the ring
 constexpr int F_OFF_W1 = F_OFF_TB + 8 * 4 * 4 * 64 * 4;   // [64][4] fp32
 constexpr int F_OFF_B1 = F_OFF_W1 + 64 * 4 * 4;           // [64]
 constexpr int F_OFF_B2 = F_OFF_B1 + 64 * 4;               // [128]
@@ -364,13 +365,13 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     w3_store(fl, wave, lane, wreg);
     const float* wnorm_g = reinterpret_cast<const float*>(w3f + 1024 * 256 + 4096);
     const float* rnorm_g = reinterpret_cast<const float*>(w3f + 1024 * 256 + 8192);
-    // per channel of chunk c the FIVE largest id-carrying scores of the tile (real units: three + the flags in a 16-byte record, the
-    // fourth and fifth in an 8-byte one that pn_exact_kernel reads only where the third is in range; with three, a tile holding a
-    // fourth point in range had its 32-point half evaluated in full -- 60 % of those evaluations) and, per lane half of every wave
-    // (32 points), a flag "holds a point within 2 E of the tile's largest score that is not among the three".  Every wave publishes two chunks after
-    // chunk 7 and after chunk 15 (all four busy at the same time: no wave waits for a publisher at the chunk barriers).
+    // Per channel of chunk c the publishing wave merges the sorted triples of the eight lane halves (4 waves x 2) into the tile's
+    // FIVE largest id-carrying scores (real units: three + the flags in a 16-byte record, the fourth and fifth in an 8-byte one that
+    // pn_exact_kernel reads only where the third is in range) and one flag per lane half (32 points) "may hold a point within 2 E of
+    // the tile's largest score that is not among the five".  The ring holds four chunks: after chunks 3, 7, 11 and 15 every wave
+    // publishes one (all four busy at the same time: no wave waits for a publisher at the chunk barriers).
     auto publish = [&](int c) {
-        const float* src = tb + (c & 7) * 1024;
+        const float* src = tb + (c & 3) * F_SLOT;          // [wave][half][k][channel]: every lane's own sorted triple, as finish() left it
         const float ti = tis[64 * c + lane];
         const float pub_wn = wnorm_g[64 * c + lane], pub_rn = rnorm_g[64 * c + lane];
         // the tile's maxima: over its four waves -- over the publishing wave alone where every wave is a tile of its own (TAIL)
@@ -378,40 +379,36 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         const float dmx = (TAIL ? wst[4 + wave] : fmaxf(fmaxf(wst[4], wst[5]), fmaxf(wst[6], wst[7]))) * 1.00001f;
         const float rdm = (TAIL ? wst[8 + wave] : fmaxf(fmaxf(wst[8], wst[9]), fmaxf(wst[10], wst[11]))) * 1.00001f;
         const float e2 = 2.0f * fmaf(pub_rn, dmx, fmaf(pub_wn, rdm, fmaf(C_ID * pub_wn, dmx, 2.0f * DELTA * pub_wn * hm)));
-        float v1[4], v2[4], u0[4], u1[4];
+        // a stored value in real units with the rest of its id: bits [4:0] point block + register (the chain's), 5 lane half, [7:6] wave
+        auto value = [&](int w, int hh, int k) {
+            const int ws = TAIL ? wave : w;                // whose triples (TAIL: one wave = the whole tile, "wave 0" of its record)
+            const float x = src[((ws * 2 + hh) * 3 + k) * 64 + lane] * (scs[ws] * ti);
+            return __uint_as_float((__float_as_uint(x) & ~0xE0u) | (unsigned)(w << 6) | (unsigned)(hh << 5));
+        };
         float c1 = NEG_BIG, c2 = NEG_BIG, c3 = NEG_BIG, c4 = NEG_BIG, c5 = NEG_BIG;   // the tile's FIVE largest id-carrying scores
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            if (TAIL && w > 0) {                           // one wave = the whole tile: it is "wave 0" of its record
-                u0[w] = NEG_BIG; u1[w] = NEG_BIG; v1[w] = NEG_BIG; v2[w] = NEG_BIG;
-                continue;
-            }
-            const int ws = TAIL ? wave : w;                // whose triples
-            const float q0 = src[ws * 256 + lane], q1 = src[ws * 256 + 64 + lane];
-            const float f = scs[ws] * ti;
-            u0[w] = src[ws * 256 + 128 + lane] * f;
-            u1[w] = src[ws * 256 + 192 + lane] * f;
-            v1[w] = __uint_as_float((__float_as_uint(q0 * f) & ~0xC0u) | (unsigned)(w << 6));
-            v2[w] = __uint_as_float((__float_as_uint(q1 * f) & ~0xC0u) | (unsigned)(w << 6));
-            c5 = __builtin_amdgcn_fmed3f(c4, c5, v1[w]); c4 = __builtin_amdgcn_fmed3f(c3, c4, v1[w]);
-            c3 = __builtin_amdgcn_fmed3f(c2, c3, v1[w]); c2 = __builtin_amdgcn_fmed3f(c1, c2, v1[w]); c1 = max_nc(c1, v1[w]);
-            c5 = __builtin_amdgcn_fmed3f(c4, c5, v2[w]); c4 = __builtin_amdgcn_fmed3f(c3, c4, v2[w]);
-            c3 = __builtin_amdgcn_fmed3f(c2, c3, v2[w]); c2 = __builtin_amdgcn_fmed3f(c1, c2, v2[w]); c1 = max_nc(c1, v2[w]);
-        }
-        const float thr = c1 - e2;                         // NaN -> no flag here; pn_exact_kernel sees the non-finite bound
-        unsigned flags = 0;                                // bit 2 w + h: lane half h of wave w holds a point in range that is not kept
+        for (int w = 0; w < (TAIL ? 1 : 4); ++w)
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            flags |= (u0[w] >= thr) ? (1u << (2 * w)) : 0u;
-            flags |= (u1[w] >= thr) ? (2u << (2 * w)) : 0u;
-        }
-        if (__builtin_amdgcn_ballot_w64(c5 >= thr) != 0) {  // five kept scores in range somewhere in the wave: a sixth id-carrying
-#pragma unroll                                               // one may be in range and not kept -- its half is flagged too
-            for (int w = 0; w < 4; ++w) {
-                if (v1[w] >= thr && v1[w] < c5) flags |= 1u << (2 * w + ((__float_as_uint(v1[w]) >> 5) & 1u));
-                if (v2[w] >= thr && v2[w] < c5) flags |= 1u << (2 * w + ((__float_as_uint(v2[w]) >> 5) & 1u));
+            for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float x = value(w, hh, k);
+                    c5 = __builtin_amdgcn_fmed3f(c4, c5, x); c4 = __builtin_amdgcn_fmed3f(c3, c4, x);
+                    c3 = __builtin_amdgcn_fmed3f(c2, c3, x); c2 = __builtin_amdgcn_fmed3f(c1, c2, x); c1 = max_nc(c1, x);
+                }
+        const float thr = c1 - e2;                         // NaN -> no flag here; pn_exact_kernel sees the non-finite bound
+        // bit 2 w + h: lane half h of wave w may hold a point in range that is not among the five: its THIRD is in range (a fourth
+        // could be: the lanes keep three), or one of its first two is in range and was not kept (six in range in the tile).  The
+        // values are read again rather than kept in registers (the loop around this runs at 248).
+        unsigned flags = 0;
+#pragma unroll
+        for (int w = 0; w < (TAIL ? 1 : 4); ++w)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const float t1 = value(w, hh, 0), t2 = value(w, hh, 1), t3 = value(w, hh, 2);
+                const bool f = (t3 >= thr) || (t2 >= thr && t2 < c5) || (t1 >= thr && t1 < c5);
+                flags |= f ? (1u << (2 * w + hh)) : 0u;
             }
-        }
         if (live) {
             part[rec * 1024 + 64 * c + lane] = f32x4{c1, c2, c3, __uint_as_float(flags)};
             part2[rec * 1024 + 64 * c + lane] = qf32x2{c4, c5};
@@ -441,25 +438,11 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
             __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                                                 \
         }                                                                                                      \
     } while (0)
-    // the other lane half holds the same channel for the other 32 points: merge, lanes 0..31 hand the triple over
+    // every lane hands its own sorted triple over (its lane half holds the channel's other 32 points: the publishing wave merges
+    // the two halves of the four waves -- one lane per channel there, where a merge here ran on two lanes per channel in every wave)
     auto finish = [&](int c, int jn, float m1, float m2, float m3) {
-        m1 = __uint_as_float((__float_as_uint(m1) & ~32u) | (unsigned)(h << 5));
-        m2 = __uint_as_float((__float_as_uint(m2) & ~32u) | (unsigned)(h << 5));
-        // v_permlane32_swap: element 1 of the result holds the upper half's values in both halves -- what lanes 0..31 need
-        const float o1 = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(m1), __float_as_uint(m1), false, false)[1]);
-        const float o2 = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(m2), __float_as_uint(m2), false, false)[1]);
-        const float o3 = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(m3), __float_as_uint(m3), false, false)[1]);
-        // lanes 0..31: (m1, m2, m3) = half 0, (o1, o2, o3) = half 1.  The wave's two largest keep their ids; u0 / u1 = the
-        // largest score of half 0 / half 1 that is NOT one of the two (pn_exact_kernel evaluates a half whose u is in range)
-        const float c1 = max_nc(m1, o1);
-        const float c2 = max_nc(min_nc(m1, o1), max_nc(m2, o2));
-        const bool a2top = m2 > o1, b2top = o2 > m1;       // both of the two come from half 0 / from half 1
-        const float u0 = a2top ? m3 : (b2top ? m1 : m2);
-        const float u1 = b2top ? o3 : (a2top ? o1 : o2);
-        if (h == 0) {
-            float* dst = tb + (c & 7) * 1024 + wave * 256 + 32 * jn + r;
-            dst[0] = c1; dst[64] = c2; dst[128] = u0; dst[192] = u1;
-        }
+        float* dst = tb + (c & 3) * F_SLOT + (wave * 2 + h) * 192 + 32 * jn + r;
+        dst[0] = m1; dst[64] = m2; dst[128] = m3;
     };
     int stage = 0;
     if constexpr (TAIL) {
@@ -469,10 +452,10 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         for (int c = 0; c < 16; ++c) {
             __syncthreads();                              // chunk c is in its stage; the other stage and tb parity are free
             if (c + 1 < 16) wreg = w3_load(w3h, 64 * (c + 1), wave, lane);
-            if (c == 8) {
+            if ((c & 3) == 0 && c > 0) {                  // the ring's four chunks are complete (barrier above)
 #pragma unroll 1
-                for (int q = 0; q < 8; ++q) publish(q);
-                __syncthreads();                          // before chunk 8's triples overwrite slot 0
+                for (int q = c - 4; q < c; ++q) publish(q);
+                __syncthreads();                          // before this chunk's triples overwrite slot 0
             }
             const char* st = fl + stage * F_STAGE3;
             qf16x8 wf0[8], wf1[8];
@@ -500,10 +483,9 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     for (int c = 0; c < ((abl & 2) ? 0 : 16); ++c) {
         __syncthreads();                                  // chunk c is in its stage; the other stage and tb parity are free
         if (c + 1 < 16 && !(abl & 1024)) wreg = w3_load(w3h, 64 * (c + 1), wave, lane);
-        if (c == 8 && !(abl & 256)) {                      // chunks 0..7 are complete (barrier above): two per wave
-            publish(2 * wave);
-            publish(2 * wave + 1);
-            __syncthreads();                              // before chunk 8's triples overwrite slot 0
+        if ((c & 3) == 0 && c > 0 && !(abl & 256)) {        // the ring's four chunks are complete (barrier above): one per wave
+            publish(c - 4 + wave);
+            __syncthreads();                              // before this chunk's triples overwrite slot 0
         }
         const char* st = fl + stage * F_STAGE3;
         qf16x8 wf0[8], wf1[8];
@@ -513,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         for (int s = 0; s < 8; ++s) wf1[s] = w3_frag(st, 32 + r, 2 * s + h);
         // Four MFMA blocks and four chain blocks per chunk, each chain under the MFMAs of the block that follows its own.  The last
         // chain of a chunk (second point block x channels 32..63: accP) has no successor inside the chunk: it runs under the FIRST
-        // MFMA block of the next chunk (8 dependent MFMAs that had nothing to cover them), except before a publish (c = 7, 15).
+        // MFMA block of the next chunk (8 dependent MFMAs that had nothing to cover them), except before a publish (c = 3, 7, 11, 15).
         f32x16 accA, accB;
         float a1 = NEG_BIG, a2 = NEG_BIG, a3m = NEG_BIG;
         F_MFMA_BLOCK(accA, 0, wf0);
@@ -535,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         F_INTERLEAVE();
         if (!(abl & 512)) finish(c, 0, a1, a2, a3m);
         else if (a1 + a2 + a3m == 12345.f) tb[lane] = a1;
-        pending = (c & 7) != 7;
+        pending = (c & 3) != 3;
         if (!pending) {
             F_CHAIN_BLOCK(accP, 1, pb1, pb2, pb3);
             if (!(abl & 512)) finish(c, 1, pb1, pb2, pb3);
@@ -551,10 +533,9 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     __syncthreads();
     if constexpr (TAIL) {
 #pragma unroll 1
-        for (int q = 8; q < 16; ++q) publish(q);
+        for (int q = 12; q < 16; ++q) publish(q);
     } else if (!(abl & 256)) {
-        publish(8 + 2 * wave);
-        publish(8 + 2 * wave + 1);
+        publish(12 + wave);
     }
     if ((abl & 4096) && tid == 0) {                        // diagnostics: phase durations in units of 64 ticks, 8 bits each
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
