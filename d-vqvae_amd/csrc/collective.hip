@@ -61,6 +61,8 @@ int fail(const char* what, ncclResult_t e) {
 
 }  // namespace
 
+extern "C" int dvq_comm_available(void) { return rccl().ok ? 1 : 0; }
+
 extern "C" int dvq_comm_unique_id(void* id_out, size_t id_bytes) {
     DVQ_REQUIRE(id_out && id_bytes >= sizeof(ncclUniqueId), "comm_unique_id: need a %zu-byte buffer", sizeof(ncclUniqueId));
     if (!rccl().ok) { dvq_set_error("comm_unique_id: librccl not found"); return DVQ_ENODEVICE; }

@@ -219,6 +219,12 @@ int dvq_launch_gemm(const GemmParams& p, GemmEpilogue epi, hipStream_t stream) {
         if (use) return dvq_launch_gemm_f16x2(p, epi, stream);
     }
     DVQ_REQUIRE(epi != EPI_STATE && !p.acc_hi, "gemm: accumulator states exist on the fp16-plane kernels only");
+    // what is left runs the three-plane bf16 kernels (or, with DVQ_GEMM=fp32, ignores the images): an image of another kind -- fp16
+    // planes on an epilogue the fp16 kernels do not have, an unknown kind -- would be read as three bf16 planes (wrong products,
+    // the third plane past the end of a two-plane buffer)
+    for (int s = 0; s < p.nsrc; ++s)
+        DVQ_REQUIRE(!p.src[s].Wp || p.src[s].wp_kind == DVQ_PLANES_BF16X3,
+                    "gemm: source %d carries a weight image of kind %d, which epilogue %d cannot run on (bf16x3 images only)", s, p.src[s].wp_kind, (int)epi);
     for (int s = 0; s < p.nsrc; ++s) DVQ_REQUIRE(!p.src[s].arow, "gemm: row-indexed activations need the fp16-plane kernels (source %d)", s);
     switch (epi) {
         case EPI_BIAS:
@@ -258,6 +264,9 @@ extern "C" int dvq_linear(const dvq_gemm_src* src, int nsrc, int64_t M, int N, c
     if (M == 0) return DVQ_OK;
     GemmParams p = {};
     for (int s = 0; s < nsrc; ++s)
+        DVQ_REQUIRE(!src[s].wp || src[s].wp_kind == DVQ_PLANES_BF16X3 || src[s].wp_kind == DVQ_PLANES_F16X2,
+                    "dvq_linear: source %d: unknown weight-image kind %d", s, src[s].wp_kind);
+    for (int s = 0; s < nsrc; ++s)
         p.src[s] = GemmSrc{src[s].x, src[s].w, (long)src[s].ldx, (long)src[s].ldw, src[s].K, src[s].wp_kind, src[s].wp, (long)src[s].wp_plane};
     for (int s = 1; s < nsrc; ++s)
         DVQ_REQUIRE(src[s].wp_kind != DVQ_PLANES_F16X2 || !src[s].wp || src[s].w_scale == src[0].w_scale,
@@ -284,6 +293,9 @@ extern "C" int dvq_mlp3(const float* x, int64_t ldx, int64_t M, const dvq_mlp_la
     DVQ_REQUIRE(L && M >= 0, "dvq_mlp3: bad arguments");
     if (M == 0) return DVQ_OK;
     DVQ_REQUIRE(x && y && workspace && dvq_aligned16(workspace), "dvq_mlp3: null/unaligned pointer");
+    for (int i = 0; i < 3; ++i)
+        DVQ_REQUIRE(!L[i].wp || L[i].wp_kind == DVQ_PLANES_BF16X3 || L[i].wp_kind == DVQ_PLANES_F16X2,
+                    "dvq_mlp3: layer %d: unknown weight-image kind %d", i, L[i].wp_kind);
     DVQ_REQUIRE(L[1].k_in == L[0].n_out && L[2].k_in == L[1].n_out, "dvq_mlp3: layer sizes %d->%d, %d->%d, %d->%d do not chain", L[0].k_in,
                 L[0].n_out, L[1].k_in, L[1].n_out, L[2].k_in, L[2].n_out);
     if (workspace_bytes < dvq_mlp3_workspace_bytes(M, L[0].n_out, L[1].n_out)) {

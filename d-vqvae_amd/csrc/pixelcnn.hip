@@ -92,12 +92,14 @@ __global__ void sample_kernel(const float* __restrict__ logits, const float* __r
             const int oi = __shfl_xor(bi, o);
             if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
         }
-        if (bi == 0x7fffffff) {            // all scores NaN: torch.argmax would return the first NaN; keep 0 -- and say so (bit 2 of the
+        const bool nan_draw = bi == 0x7fffffff;
+        if (nan_draw) {                    // all scores NaN: torch.argmax would return the first NaN; keep 0 -- and say so (bit 2 of the
             bi = 0;                        // flag: non-finite logits, e.g. an activation beyond the fp16 range of the default GEMM
             if (lane == 0 && err_flag) atomicOr(err_flag, 4);       // arithmetic; the host mirror generates the batch again on the bf16 split)
         }
         code = bi;
-        if (lane == 0) codes[b * NPOS + pos] = code;
+        // the caller's copy of a draw from all-NaN logits is -1 (include/dvq.h): the host mirror regenerates exactly those rows
+        if (lane == 0) codes[b * NPOS + pos] = nan_draw ? -1 : code;
     }
     const float* e = tok_emb + code * dim;
     for (int c = lane * 4; c < dim; c += 256) *reinterpret_cast<f32x4*>(x0 + b * dim + c) = *reinterpret_cast<const f32x4*>(e + c);

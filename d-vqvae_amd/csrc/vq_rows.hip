@@ -413,9 +413,19 @@ __global__ __launch_bounds__(NT, 2) void vq_rows_kernel(const float* __restrict_
 // called by dvq_vq_argmin_fast (vq_stream.hip) after argument validation
 int dvq_launch_vq_rows(const float* z, const float* E, const void* packed, long M, int64_t* idx, unsigned long long* slow_rows,
                        hipStream_t st) {
-    static unsigned long long* dbg_buf = nullptr;           // DVQ_VQ_ROWS_DBG=1: per-workgroup phase stamps, printed after the launch (syncs)
+    // DVQ_VQ_ROWS_DBG=1, diagnostics builds (-DDVQ_DIAG, tools/diag/) only: per-workgroup phase stamps, printed after the launch
+    // (synchronises; one buffer, first device only).  The product library compiles none of it: dbg_on is a constant false there.
+#ifdef DVQ_DIAG
+    static unsigned long long* dbg_buf = nullptr;
     static const bool dbg_on = getenv("DVQ_VQ_ROWS_DBG") != nullptr;
-    if (dbg_on && !dbg_buf) (void)hipMalloc(&dbg_buf, 8 * 8 * 4096);
+    if (dbg_on && !dbg_buf && hipMalloc(&dbg_buf, 8 * 8 * 4096) != hipSuccess) {
+        dvq_set_error("vq_rows: debug buffer allocation failed");
+        return DVQ_ELAUNCH;
+    }
+#else
+    constexpr unsigned long long* dbg_buf = nullptr;
+    constexpr bool dbg_on = false;
+#endif
     static DvqOncePerDevice attr_once;
     {
         const hipError_t e = attr_once.run([] {

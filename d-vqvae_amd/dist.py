@@ -70,12 +70,14 @@ def _abi_comm(device: torch.device):
     lib = _lib.load()
     world, rank = dist.get_world_size(), dist.get_rank()
     # Every rank must end up with the same answer: a rank whose librccl cannot be resolved (or whose init fails) must not raise while
-    # the others sit in ncclCommInitRank or in the first collective.  So: every rank probes RCCL (making a unique id resolves it;
-    # rank 0's is THE id), the communicator is only initialised if EVERY rank could (all-reduce over the process group) and only
+    # the others sit in ncclCommInitRank or in the first collective.  So: every rank probes RCCL (dvq_comm_available resolves the
+    # symbols; rank 0 alone makes THE id), the communicator is only initialised if EVERY rank could (all-reduce over the process group) and only
     # used if EVERY rank's init succeeded (a second one); otherwise all ranks fall back to torch.distributed's all-gather together
     # (the None is cached: asked once per device).
     uid = C.create_string_buffer(128)
-    have = lib.dvq_comm_unique_id(uid, 128) == 0
+    have = lib.dvq_comm_available() == 1                   # resolves the symbols, creates nothing
+    if have and rank == 0:                                 # only rank 0 makes an id (RCCL starts its bootstrap root for it)
+        have = lib.dvq_comm_unique_id(uid, 128) == 0
     box = [bytes(uid.raw) if rank == 0 else None]
     dist.broadcast_object_list(box, src=0)
 

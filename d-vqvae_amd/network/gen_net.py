@@ -33,7 +33,8 @@ class GenNet(nn.Module):
         #                              None: torch.initial_seed(), i.e. torch.manual_seed governs the draws as it does the reference's
         self._noise_stream = 0       # one Philox stream per gen() call unless the caller names it
         self.sort_by_label = os.environ.get("DVQ_SORT_LABELS", "1") != "0"   # prior evaluated in label order (gather locality)
-        self.range_fallbacks = 0     # gen() calls re-run on the bf16 split because an activation left fp16's range
+        self.range_fallbacks = 0     # gen() calls in which rows were generated again on the bf16 split (an activation left fp16's range)
+        self.range_fallback_rows = 0 # ... and how many rows that was
 
     def set_noise_seed(self, seed, first_stream=0):
         """Seed of the prior's sampling noise; every gen() call without explicit ``noise`` / ``stream_id`` uses the next stream."""
@@ -78,15 +79,16 @@ class GenNet(nn.Module):
         return seed, (drow if row0 is None else row0), stream_id
 
     def _draw_noise(self, B, dev, key, perm=None):
-        """[B, 9, prior_tokens] Exp(1) variates; with ``perm``, row r holds the draws of batch row perm[r]."""
+        """[B, 9, prior_tokens] Exp(1) variates; with ``perm``, row r holds the draws of row perm[r] of the keyed batch."""
         n_in = self.GatedPixelCNN.packed().n_in
         seed, row0, stream_id = key
         return ops.exp1_noise(B, 9 * n_in, seed, row0, stream_id, device=dev, perm=perm).view(B, 9, n_in)
 
-    def _gen_impl(self, obj, noise, key=None):
+    def _gen_impl(self, obj, noise, key=None, rows=None):
         """The device work of gen(): no host synchronisation inside (gen() checks the error flag once at the end).
         ``noise`` None: the prior's draws come from the device generator under ``key``, drawn directly in the order the prior
-        is evaluated in (no gather of the [B, 9, tokens] tensor)."""
+        is evaluated in (no gather of the [B, 9, tokens] tensor).  ``rows`` (int64 [B] on the device): ``obj`` holds rows
+        ``rows`` of the keyed batch -- sample b draws the noise of row ``rows[b]`` (the per-row range fallback of gen())."""
         if obj.dim() != 3:
             raise RuntimeError(f"gen: expected obj [B,4,N], got {tuple(obj.shape)}")
         B, dev = obj.shape[0], obj.device
@@ -106,15 +108,17 @@ class GenNet(nn.Module):
         # Rows are independent, so the order changes no result; the codes are scattered back.
         if B >= 512 and self.sort_by_label:
             order = torch.argsort(label, stable=True)
-            noise_s = self._draw_noise(B, dev, key, perm=order) if noise is None else noise.index_select(0, order)
+            noise_s = (self._draw_noise(B, dev, key, perm=order if rows is None else rows[order].contiguous()) if noise is None
+                       else noise.index_select(0, order))
             codes_s = ops.pixelcnn_sample(pk, label[order].contiguous(), noise_s, err=err)   # :92
             codes = torch.empty_like(codes_s)
             codes[order] = codes_s
         else:
             if noise is None:
-                noise = self._draw_noise(B, dev, key)
+                noise = self._draw_noise(B, dev, key, perm=rows)
             codes = ops.pixelcnn_sample(pk, label, noise.contiguous(), err=err)   # :92
-        recon = self._decode(codes, {"z_out": z_out}, None, err)           # :95-113
+        # a position drawn from all-NaN logits carries -1 (bit 2 of err is set; gen() regenerates those rows): decode token 0 there
+        recon = self._decode(codes.clamp_min(0), {"z_out": z_out}, None, err)   # :95-113
         verts = self._hand_vertices(recon)                                 # :116-118
         self.recon_encoder(verts, out=z_pos[:, :1024])                     # :120
         recon_pos = self.pos_decoder(z_pos).view(B, 6)                     # :122-123
@@ -138,7 +142,8 @@ class GenNet(nn.Module):
         if obj.dim() != 3:
             raise RuntimeError(f"gen: expected obj [B,4,N], got {tuple(obj.shape)}")
         key = self._noise_key(seed, row0, stream_id) if noise is None else None
-        recon, recon_pos, aux, err = self._gen_impl(obj, noise, key)
+        with ops.no_range_check():                                         # ONE check for the whole path, below
+            recon, recon_pos, aux, err = self._gen_impl(obj, noise, key)
         aux["err"] = err
         if not check:
             return (recon, recon_pos, aux) if return_aux else (recon, recon_pos)
@@ -148,13 +153,23 @@ class GenNet(nn.Module):
             raise RuntimeError(self._RANGE_ERROR)
         if (status & 6) and packing.gemm_kind() == _lib.PLANES_F16X2:     # non-finite parameters, or a draw from all-NaN logits (bit 2)
             # The default GEMM arithmetic splits activations into fp16 pieces: a value beyond fp16's range (|x| >= 65 520) turns its
-            # row into NaN -- never a silently wrong number.  Such a batch is generated again on the six-product bf16 split, which
-            # has fp32's range (csrc/gemm_f16x2.hip); NaN / Inf INPUTS come out non-finite there too, as in the reference.
+            # ROW into NaN -- never a silently wrong number (rows do not interact anywhere on the path).  Exactly those rows -- a
+            # non-finite parameter, or a -1 where the sampler drew from all-NaN logits -- are generated again on the six-product bf16
+            # split, which has fp32's range (csrc/gemm_f16x2.hip), under the same noise keys, and scattered back; every other row keeps
+            # its bits.  NaN / Inf INPUTS come out non-finite there too, as in the reference.
+            bad = ~(torch.isfinite(recon).all(dim=1) & torch.isfinite(recon_pos).all(dim=1)) | (aux["codes"].reshape(obj.shape[0], -1) < 0).any(dim=1)
+            rows = bad.nonzero().reshape(-1)
             self.range_fallbacks += 1
-            with packing.gemm_kind_as(_lib.PLANES_BF16X3):
-                recon, recon_pos, aux, err = self._gen_impl(obj, noise, key)
-                if int(err.item()) & 1:
+            self.range_fallback_rows += int(rows.numel())
+            with ops.no_range_check(), packing.gemm_kind_as(_lib.PLANES_BF16X3):
+                r2, p2, aux2, err2 = self._gen_impl(obj.index_select(0, rows), None if noise is None else noise.index_select(0, rows), key, rows=rows)
+                if int(err2.item()) & 1:
                     raise RuntimeError(self._RANGE_ERROR)
+            recon[rows], recon_pos[rows] = r2, p2
+            for k in ("idx6", "codes", "feat_type", "feat_pos", "verts", "hand_feat"):
+                aux[k][rows] = aux2[k]
+            aux["err"] = err2
+            aux["fallback_rows"] = rows
         return (recon, recon_pos, aux) if return_aux else (recon, recon_pos)
 
     @torch.no_grad()

@@ -82,6 +82,36 @@ def new_err_flag(dev: torch.device) -> Tensor:
     return torch.zeros(1, dtype=torch.int32, device=dev)
 
 
+# ------------------------------------------------------------------------------------------ fp16 range
+# The default GEMM arithmetic carries activations as two fp16 pieces: a value beyond fp16's range (|x| >= 65 520) turns its output
+# ROW into NaN -- never a silently wrong number (csrc/gemm_f16x2.hip).  Every entry point that multiplies on those images looks at
+# its result once (one host synchronisation) and runs the call again on the six-product bf16 images, which have fp32's range, when
+# it holds a non-finite value; inputs that are themselves NaN / Inf come out non-finite there too, as in the reference.
+# GenNet.gen makes ONE such check for the whole path and switches the per-op checks off around its inner calls.
+_range_check_off = 0
+
+
+class no_range_check:
+    """``with ops.no_range_check(): ...`` -- the caller checks the final result itself (GenNet.gen: one synchronisation per call)."""
+
+    def __enter__(self):
+        global _range_check_off
+        _range_check_off += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _range_check_off
+        _range_check_off -= 1
+        return False
+
+
+def _out_of_range(kind, *outs: Tensor) -> bool:
+    """True when a result of the fp16-image arithmetic holds a non-finite value and the per-op check is on (synchronises)."""
+    if _range_check_off or kind != _lib.PLANES_F16X2:
+        return False
+    return not all(bool(torch.isfinite(o).all()) for o in outs if o is not None)
+
+
 # ------------------------------------------------------------------------------------------ dense
 def _planes_args(pl, w: Tensor, what: str):
     """(kind, planes pointer, plane stride, scale pointer, scale tensor) of a weight image handed to an op: a packing.Planes
@@ -144,6 +174,9 @@ def linear_multi(pairs: Sequence[Tuple[Tensor, Tensor]], bias: Optional[Tensor] 
     with torch.cuda.device(dev):
         check(lib.dvq_linear(srcs, len(pairs), M, N, bias.data_ptr() if bias is not None else None,
                              1 if relu else 0, po, ldo, _stream(dev)), "dvq_linear")
+    if planes is not None and _out_of_range(srcs[0].wp_kind, out):
+        with no_range_check():                               # once more on the six-product images (fp32's range)
+            return linear_multi(pairs, bias, relu, out, planes=[packing.split_planes(w.contiguous(), _lib.PLANES_BF16X3) for _, w in pairs])
     return out
 
 
@@ -176,6 +209,10 @@ def mlp3(x: Tensor, layers, out: Optional[Tensor] = None) -> Tensor:
     ws = workspace(nws, dev, tag="mlp3")
     with torch.cuda.device(dev):
         check(lib.dvq_mlp3(px, ldx, M, arr, po, ldo, ws.data_ptr(), ws.numel(), _stream(dev)), "dvq_mlp3")
+    if any(l[2] is not None and not isinstance(l[2], Tensor) and l[2].kind == _lib.PLANES_F16X2 for l in layers) and _out_of_range(_lib.PLANES_F16X2, out):
+        from . import packing
+        with no_range_check():                               # once more on the six-product images (fp32's range)
+            return mlp3(x, [(w, b, packing.split_planes(w, _lib.PLANES_BF16X3)) for w, b, _ in layers], out=out)
     return out
 
 
@@ -344,7 +381,9 @@ def pointnet_encode(packed, pc: Tensor, out: Optional[Tensor] = None, want_trans
 
 # ------------------------------------------------------------------------------------------ PixelCNN
 def pixelcnn_sample(packed, label: Tensor, noise: Tensor, return_logits: bool = False, err: Optional[Tensor] = None, _retry: bool = False):
-    """label [B] int64, noise [B,9,n_in] Exp(1) -> codes [B,3,3] int64 (+ logits [B,9,n_in])."""
+    """label [B] int64, noise [B,9,n_in] Exp(1) -> codes [B,3,3] int64 (+ logits [B,9,n_in]).
+    With a caller-supplied ``err`` flag nothing synchronises here: a draw from all-NaN logits (fp16 range, bit 2 of the flag) leaves
+    -1 at its position of ``codes`` and the caller deals with those rows (GenNet.gen regenerates them on the bf16x3 images)."""
     lib = _lib.load()
     dev = _require_gpu(label, noise, err)
     _i64(label, "label"), _f32(noise, "noise")
@@ -398,6 +437,10 @@ def pixelcnn_forward(packed, x: Tensor, label: Tensor) -> Tensor:
                                        err.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)), "dvq_pixelcnn_forward")
     if int(err.item()) & 1:
         raise RuntimeError("index out of range in self (token or class label)")
+    if _out_of_range(packed.kind, logits):
+        from . import packing
+        with no_range_check(), packing.gemm_kind_as(_lib.PLANES_BF16X3):     # once more on the six-product images (fp32's range)
+            return pixelcnn_forward(packed, x, label)
     return logits.view(B, 3, 3, packed.n_in).permute(0, 3, 1, 2)
 
 
@@ -427,6 +470,10 @@ def mano_forward(packed, betas: Tensor, hand_pose: Tensor, global_orient: Option
                                    verts.data_ptr(), 1 if channel_major else 0,
                                    joints.data_ptr() if want_joints else None, ws.data_ptr(), ws.numel(), _stream(dev)),
               "dvq_mano_forward")
+    if _out_of_range(getattr(packed, "kind", None), verts, joints):
+        from . import packing
+        with no_range_check(), packing.gemm_kind_as(_lib.PLANES_BF16X3):     # the blendshape GEMM once more on the six-product images
+            return mano_forward(packed, betas, hand_pose, global_orient, transl, channel_major, want_joints)
     return (verts, joints) if want_joints else verts
 
 

@@ -152,8 +152,25 @@ class _Packed:
             device = torch.device("cuda", torch.cuda.current_device())
         if self.device == device and getattr(self, "kind", None) == self._kind():
             return self
+        derived = ("__planes", "__filter", "__scale", "__tables")
+        stash = self.__dict__.setdefault("_stash", {})
+        if self.device == device and getattr(self, "kind", None) is not None:
+            # the weight-image kind flips on the same device (a range fallback and the return from it): park this kind's images and
+            # bound struct instead of dropping them -- the way back (class tables of the prior included) costs nothing
+            stash[self.kind] = ({k: v for k, v in self.tensors.items() if k.endswith(derived)}, self.cstruct,
+                                {a: self.__dict__[a] for a in ("_layers",) if a in self.__dict__})
+            hit = stash.get(self._kind())
+            if hit is not None:
+                self.tensors = {k: v for k, v in self.tensors.items() if not k.endswith(derived)}
+                self.tensors.update(hit[0])
+                self.cstruct = hit[1]
+                self.__dict__.update(hit[2])
+                self.kind = self._kind()
+                return self
+        else:
+            stash.clear()
         self.tensors = {k: (v.to(device) if v.dtype == torch.int16 else _dev(v, device)) for k, v in self.tensors.items()
-                        if not k.endswith(("__planes", "__filter", "__scale", "__tables"))}
+                        if not k.endswith(derived)}
         self.device = device
         self.kind = self._kind()
         for scale_key, keys in self._plane_groups():    # weight images of the GEMM weights, built on the device

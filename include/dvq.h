@@ -39,7 +39,7 @@ typedef enum {
 
 /* The version of this header.  dvq_abi_version() returns the library's: a binding checks the two for equality at load time
  * (struct layouts change between versions). */
-#define DVQ_ABI_VERSION 7
+#define DVQ_ABI_VERSION 8
 int dvq_abi_version(void);
 const char* dvq_last_error(void);
 /* number of visible HIP devices, or -1; does not create a context */
@@ -226,7 +226,8 @@ size_t dvq_pixelcnn_workspace_bytes(const dvq_pixelcnn_weights* w_host, int64_t 
 /* label [B] int64 in [0,n_classes), noise q [B,9,n_in] -> codes [B,9] int64 (raster order).
  * logits_out (optional) [B,9,n_in] receives the logits each draw was made from.
  * *err_flag (device int32, caller zeroes it): bit 0 = a label / token out of range; bit 2 = a draw from logits that were all NaN
- * (the code is 0 then): with fp16 weight images, an activation beyond +-65 504 -- run the call again with bf16x3 images. */
+ * (that position's entry of `codes` is -1 then (v8; 0 before), the sampler itself continues from token 0): with fp16 weight
+ * images, an activation beyond +-65 504 made the row NaN -- run the rows that hold a -1 again with bf16x3 images. */
 int dvq_pixelcnn_sample(const dvq_pixelcnn_weights* w_host, const int64_t* label, const float* noise,
                         int64_t B, int64_t* codes, float* logits_out, int32_t* err_flag,
                         void* workspace, size_t workspace_bytes, dvq_stream_t stream);
@@ -320,6 +321,9 @@ int dvq_interior(const float* normals /* [B,V,3] */, const float* hand /* [B,V,3
  *   dvq_allgather_params: out[r * rows_per_rank + i, :] = rank r's local[i, :]; enqueued on `stream`; equal shards only
  *                        (ragged batches: pad the shard, the host mirror does)
  * RCCL is resolved at the first call (dlopen); without it these return DVQ_ENODEVICE and the rest of the library is unaffected. */
+/* 1 when librccl and the five entry points used here resolve in this process, else 0: a probe that creates nothing (v8; making a
+ * unique id starts RCCL's bootstrap thread and socket, which only rank 0 should do) */
+int dvq_comm_available(void);
 int dvq_comm_unique_id(void* id_out, size_t id_bytes /* >= 128 */);
 int dvq_comm_init(const void* id, size_t id_bytes, int world, int rank, void** comm_out);
 int dvq_allgather_params(void* comm, const float* local /* [rows_per_rank, cols] */, int64_t rows_per_rank, int cols /* 61 */,

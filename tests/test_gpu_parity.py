@@ -2,6 +2,7 @@
 (produced by the real reference) and size-independent properties.  Indices bit-exact; floats within the
 tolerance BASELINE.json states for the path (1e-5 abs on MANO pose/shape)."""
 import os
+import time
 
 import numpy as np
 import pytest
@@ -1014,6 +1015,142 @@ def test_gen_falls_back_to_bf16x3_beyond_fp16_range():
             net.GatedPixelCNN.layers[2].horiz_resid.weight.mul_(1.0e-7)
     assert torch.equal(c_def, c_b)
     assert int((c_b != 0).sum()) > 0, "the bf16 split must draw real codes where the fp16 images had NaN logits"
+
+
+def test_gen_range_fallback_regenerates_only_the_rows_that_need_it():
+    """One grasp of a batch leaves fp16's range (its cloud is scaled until the PointNet feature, an input of the decoder, passes
+    65 504): gen() regenerates THAT row on the six-product images under the same noise key -- the row equals the DVQ_GEMM=bf16x3
+    result bit for bit, every other row keeps the bits of a clean call, and at the benchmark's batch a step with one such row costs
+    what a clean step costs (the whole-batch re-run of round 4 cost 1.6 x)."""
+    net, _ = _gennet()
+    B, bad = 40, 17
+    obj = gpu(synth.synthetic_clouds(B, 300, seed=91))
+    clean = obj.clone()
+    scale = None
+    for s_try in (1.0e3, 1.0e4, 1.0e5, 1.0e6):                                   # the smallest scale that leaves fp16's range
+        with torch.no_grad():
+            f_bad, _, _ = net.obj_encoder_type(clean[bad:bad + 1] * s_try)
+        if float(f_bad.abs().max()) > 7.0e4:
+            scale = s_try
+            break
+    assert scale is not None, "no scale pushed the PointNet feature (a decoder input) beyond fp16's range"
+    obj[bad] *= scale
+    n0, r0 = net.range_fallbacks, net.range_fallback_rows
+    r, p, aux = net.gen(obj, seed=5, row0=300, stream_id=2, return_aux=True)
+    assert net.range_fallbacks == n0 + 1 and net.range_fallback_rows == r0 + 1 and aux["fallback_rows"].tolist() == [bad]
+    assert bool(torch.isfinite(r).all()) and bool(torch.isfinite(p).all())
+    rc, pc = net.gen(clean, seed=5, row0=300, stream_id=2)                       # no row out of range: no fallback
+    assert net.range_fallbacks == n0 + 1
+    keep = [i for i in range(B) if i != bad]
+    assert torch.equal(r[keep], rc[keep]) and torch.equal(p[keep], pc[keep]), "rows inside the range must keep their bits"
+    rb, pb = _with_env("DVQ_GEMM", "bf16x3", lambda: net.gen(obj, seed=5, row0=300, stream_id=2))
+    assert torch.equal(r[bad], rb[bad]) and torch.equal(p[bad], pb[bad]), "the regenerated row must be the six-product result"
+    # the cost at the benchmark's batch: one bad row in 65 536
+    big = clean[torch.arange(65536, device=DEV) % B].contiguous()
+    net.gen(big[:512], seed=6)                                                   # images of both kinds exist from here on
+    def timed(x):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        net.gen(x, seed=6, row0=0, stream_id=1)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    timed(big)
+    t_clean = min(timed(big), timed(big))
+    big[40000] *= scale
+    timed(big)
+    n1 = net.range_fallback_rows
+    t_bad = min(timed(big), timed(big))
+    assert net.range_fallback_rows == n1 + 2
+    assert t_bad <= 1.05 * t_clean + 0.005, f"one out-of-range row: {t_bad * 1e3:.1f} ms against {t_clean * 1e3:.1f} ms for a clean step"
+
+
+def test_every_entry_point_survives_the_fp16_range():
+    """ops.linear / ops.mlp3 / Decoder / GatedPixelCNN.forward / the MANO layer on the default fp16 images: an activation beyond
+    +-65 504 must not come back as NaN where the fp32 reference is finite -- each entry point looks at its result and runs again on
+    the six-product images (same result as DVQ_GEMM=bf16x3)."""
+    from dvqvae_amd import packing
+    torch.manual_seed(3)
+    x = torch.randn(24, 256, device=DEV)
+    x[5] *= 1.0e6
+    w, b = torch.randn(64, 256, device=DEV) * 0.05, torch.randn(64, device=DEV)
+    y = ops.linear(x, w, b, planes=packing.split_planes(w))
+    y_ref = _with_env("DVQ_GEMM", "bf16x3", lambda: ops.linear(x, w, b))
+    assert bool(torch.isfinite(y).all()) and torch.equal(y, y_ref)
+    with ops.no_range_check():                                                  # what the check is for: the raw result has a NaN row
+        y_raw = ops.linear(x, w, b, planes=packing.split_planes(w))
+    assert bool(torch.isnan(y_raw[5]).all()) and bool(torch.isfinite(y_raw[:5]).all())
+    net, _ = _gennet()
+    z = torch.randn(24, 2560, device=DEV)
+    z[7] *= 1.0e6
+    d = net.decoder(z)
+    d_ref = _with_env("DVQ_GEMM", "bf16x3", lambda: net.decoder(z))
+    assert bool(torch.isfinite(d).all()) and torch.equal(d, d_ref)
+    tok = gpu(torch.arange(54).reshape(6, 3, 3) % 128)
+    lab = gpu(torch.arange(6) % 4)
+    with torch.no_grad():
+        net.GatedPixelCNN.layers[2].horiz_resid.weight.mul_(1.0e7)
+    try:
+        lg = net.GatedPixelCNN(tok, lab)
+        lg_ref = _with_env("DVQ_GEMM", "bf16x3", lambda: net.GatedPixelCNN(tok, lab))
+    finally:
+        with torch.no_grad():
+            net.GatedPixelCNN.layers[2].horiz_resid.weight.mul_(1.0e-7)
+    assert bool(torch.isfinite(lg_ref).all()) and torch.equal(lg, lg_ref)
+    betas, pose = torch.randn(8, 10, device=DEV), torch.randn(8, 45, device=DEV) * 0.3
+    betas[2] *= 1.0e6
+    v = net.rh_mano(betas=betas, global_orient=torch.zeros(8, 3, device=DEV), hand_pose=pose, transl=torch.zeros(8, 3, device=DEV)).vertices
+    v_ref = _with_env("DVQ_GEMM", "bf16x3", lambda: net.rh_mano(betas=betas, global_orient=torch.zeros(8, 3, device=DEV), hand_pose=pose,
+                                                                 transl=torch.zeros(8, 3, device=DEV)).vertices)
+    assert bool(torch.isfinite(v).all()) and torch.equal(v, v_ref)
+
+
+def test_checkpoint_files_load_like_the_reference(tmp_path):
+    """The loading branch of the entry points with the files a user of the reference has (gen_diverse_grasp_obman.py:333-346):
+    ``model_best.pth`` = {'network': state_dict} with keys GenNet does not have (the trainer's hand encoders) and without some it has
+    (those keep the module's own initial values), filtered into GenNet.state_dict(); the prior's state_dict as a file of its own,
+    loaded whole.  The JSON an entry point writes from the files equals, byte for byte, what an in-memory net loaded with the same
+    tensors generates.  And: the reference's 128-row codebooks under an unrestricted 512-class prior raise, as there."""
+    import json
+    from dvqvae_amd import generate
+    from dvqvae_amd.network.gen_net import GenNet
+    seed = 11
+    torch.manual_seed(seed)
+    tmpl = GenNet(n_embeddings=128)
+    full = synth.synthetic_state_dict(tmpl.state_dict(), 4321)
+    full["GatedPixelCNN.output_conv.2.bias"][128:] = -1e4                        # codes stay inside the 128-row codebooks
+    missing = [k for k in full if k.endswith("num_batches_tracked")] + ["pos_decoder.MLP.L2.bias"]
+    network = {k: v for k, v in full.items() if not k.startswith("GatedPixelCNN.") and k not in missing}
+    network["emb_0.MLP.L0.weight"] = torch.randn(512, 1024)                      # keys of the training net GenNet has no use for
+    network["fing_3.stn.fc3.bias"] = torch.randn(9)
+    prior = {k[len("GatedPixelCNN."):]: v for k, v in full.items() if k.startswith("GatedPixelCNN.")}
+    ck, pck = str(tmp_path / "model_best.pth"), str(tmp_path / "LATENT_BLOCK_pixelcnn.pt")
+    torch.save({"network": network, "epoch": 3}, ck)
+    torch.save(prior, pck)
+    out_dir = str(tmp_path / "out")
+    argv = ["--num_grasp", "6", "--num_objects", "2", "--points", "700", "--seed", str(seed), "--out_dir", out_dir,
+            "--checkpoint", ck, "--prior_checkpoint", pck, "--mano_model", "/nonexistent"]
+    paths = generate.main("ho3d", argv)
+    assert len(paths) == 2
+    # the same tensors, loaded in memory the way the reference's script does
+    torch.manual_seed(seed)                                                      # main() seeds before it builds the net: same initial values
+    net = GenNet(n_embeddings=128)
+    sd = net.state_dict()
+    assert float((sd["pos_decoder.MLP.L2.bias"] - full["pos_decoder.MLP.L2.bias"]).abs().max()) > 0, "the missing key must matter"
+    sd.update({k: v for k, v in network.items() if k in sd})
+    net.load_state_dict(sd)
+    net.GatedPixelCNN.load_state_dict(prior)
+    net.eval().to(DEV)
+    net.set_rh_mano(dmano.ManoLayer(dmano.synthetic_mano_arrays()).to(DEV))
+    clouds = synth.synthetic_clouds(2, 700, seed=seed)
+    for gi, path in enumerate(paths):
+        out = generate.generate_for_object(net, clouds[gi], 6, True, np.random.default_rng([seed, gi]), seed=seed, object_index=gi)
+        assert open(path).read() == json.dumps(out["json"]), f"{path}: the files loaded differently from the in-memory net"
+    # an unrestricted prior draws codes beyond the 128 codebook rows: the reference's embedding lookup raises; so does the entry point
+    prior_u = dict(prior)
+    prior_u["output_conv.2.bias"] = torch.zeros_like(prior["output_conv.2.bias"])
+    torch.save(prior_u, pck)
+    with pytest.raises(RuntimeError, match="out of range"):
+        generate.main("ho3d", argv + ["--n_embeddings", "128"])
 
 
 def test_gen_sharded_equals_unsharded_with_device_noise():

@@ -7,6 +7,7 @@ Every test starts FRESH child processes (a process that has initialised the GPU 
   (b) ``bench.py --gpus 1 --force-pg --backend nccl``: RCCL itself -- process-group init, the C ABI's communicator
       (dvq_comm_unique_id / dvq_comm_init) and dvq_allgather_params, barrier, all_reduce(MAX) on device tensors -- runs at
       world size 1 and gives the same bits again;
+  (a') the same with EIGHT ranks at the real global batch 65 536 (8 192 rows per rank);
   (c) ``gen_diverse_grasp_ho3d.py`` under two ranks writes the same JSON files as one rank (objects sharded over ranks,
       rotations and noise keyed by the global object index)."""
 import json
@@ -29,10 +30,13 @@ def _port():
         return str(s.getsockname()[1])
 
 
-def _bench(extra, env=None):
+def _bench(extra, env=None, batch=None):
     e = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_port())
     e.update(env or {})
-    r = subprocess.run(BENCH + extra, env=e, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    cmd = list(BENCH)
+    if batch is not None:
+        cmd[cmd.index("--batch") + 1] = str(batch)
+    r = subprocess.run(cmd + extra, env=e, capture_output=True, text=True, timeout=2400, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, f"expected ONE JSON line on rank 0, got {len(lines)}:\n{r.stdout[-2000:]}"
@@ -57,6 +61,17 @@ def test_bench_two_ranks_on_one_gpu_equals_one_rank(single):
 def test_bench_ragged_shards_three_ranks(single):
     three = _bench(["--gpus", "3", "--share-gpu", "--backend", "gloo"])      # 2048 = 683 + 683 + 682: the padded all-gather
     assert three["n_gpus"] == 3 and three["gathered_sha256"] == single["gathered_sha256"]
+
+
+def test_bench_eight_ranks_at_the_real_global_batch():
+    """The plumbing of BASELINE config 5 at its real size, on one GPU: global batch 65 536 over EIGHT ranks (8 192 rows per rank -- the
+    share whose GEMMs select the 128 x 128 tiles, two PointNet launches of 4 096 clouds per trunk) must generate the grasps of the
+    one-rank run, bit for bit.  RCCL with more than one rank cannot run on a one-GPU box: the ranks gather over gloo."""
+    one = _bench(["--gpus", "1"], batch=65536)
+    eight = _bench(["--gpus", "8", "--share-gpu", "--backend", "gloo"], batch=65536)
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "strong" and eight["config"]["global_batch"] == 65536
+    assert eight["config"]["allgather_bytes_per_rank"] == 8192 * 61 * 4
+    assert eight["gathered_sha256"] == one["gathered_sha256"], "eight shards generated different grasps than the unsharded batch"
 
 
 def test_bench_rccl_world_size_one(single):
