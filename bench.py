@@ -563,7 +563,7 @@ def config_leg(args, lib, _lib, dev):
                      "algorithmic_tflops": value * flop_per_grasp / 1e12}}
     out.update(extra)
     if kernels:
-        out["roofline"] = step_roofline(kernels, pe_ms, 1, dt * 1e3, 65536)
+        out["roofline"] = step_roofline(kernels, pe_ms, 1, dt * 1e3, B)       # PMC traffic exists for the headline's launches only
         out["kernels"] = {k: {"count": v["count"], "ms": round(v["ms"], 3),
                               "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0}
                           for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"])}

@@ -222,7 +222,7 @@ int dvq_launch_gemm(const GemmParams& p, GemmEpilogue epi, hipStream_t stream) {
     // what is left runs the three-plane bf16 kernels (or, with DVQ_GEMM=fp32, ignores the images): an image of another kind -- fp16
     // planes on an epilogue the fp16 kernels do not have, an unknown kind -- would be read as three bf16 planes (wrong products,
     // the third plane past the end of a two-plane buffer)
-    for (int s = 0; s < p.nsrc; ++s)
+    for (int s = 0; s < p.nsrc && split; ++s)                  // (DVQ_GEMM=fp32 reads no image at all)
         DVQ_REQUIRE(!p.src[s].Wp || p.src[s].wp_kind == DVQ_PLANES_BF16X3,
                     "gemm: source %d carries a weight image of kind %d, which epilogue %d cannot run on (bf16x3 images only)", s, p.src[s].wp_kind, (int)epi);
     for (int s = 0; s < p.nsrc; ++s) DVQ_REQUIRE(!p.src[s].arow, "gemm: row-indexed activations need the fp16-plane kernels (source %d)", s);

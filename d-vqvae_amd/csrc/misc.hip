@@ -42,6 +42,8 @@ DvqKnobs* read_knobs() {
         if (sscanf(e, "%d,%d", &a, &c) == 2) { k->pn_caps[0] = a < 0 ? 0 : a; k->pn_caps[1] = c < 0 ? 0 : c; }
     }
     k->pn_chunk = num("DVQ_PN_CHUNK");
+    k->pn_streams = is("DVQ_PN_STREAMS", '0') ? 0 : 1;
+    k->pn_slots = (int)num("DVQ_PN_SLOTS");
     k->pn_stats = getenv("DVQ_PN_STATS") != nullptr;
     k->pixelcnn_chunk = num("DVQ_PIXELCNN_CHUNK");
     k->pixelcnn_tables = is("DVQ_PIXELCNN_TABLES", '0') ? 0 : 1;

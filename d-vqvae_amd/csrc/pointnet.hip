@@ -7,6 +7,9 @@
 // unfused instead: pn_layer1_kernel (vector ALU) + two fp32-MFMA GEMMs, the second with the column-max epilogue.
 // BatchNorm (eval) is folded into the weights by the packer (packing.py, fp64 fold, rounded once).
 #include "dvq_internal.h"
+#include <map>
+#include <utility>
+#include <vector>
 
 int dvq_launch_pn_trunk(const float* pc, int C, int N, long B, const float* trans, const float* W1, const float* b1,
                         const uint16_t* W2p, const float* b2, const uint16_t* W3p, const float* b3, float* partial,
@@ -18,6 +21,11 @@ int dvq_launch_pn_trunk_filter(const float* pc, int C, int N, int Npad, long B, 
                                const float* W2, const uint16_t* W2p, const float* b2, const void* w3f, const float* w3, const float* b3,
                                int relu, float* h2buf, void* part, unsigned* tstat, float* cbuf, float* feat, long ld_feat,
                                unsigned long long* stats, hipStream_t st);
+int dvq_launch_pn_filter_front(const float* pc, int C, int N, int Npad, long B, const float* trans, const float* W1, const float* b1,
+                               const float* W2, const uint16_t* W2p, const float* b2, const void* w3f, float* h2buf, void* part,
+                               unsigned* tstat, float* cbuf, unsigned long long* stats, hipStream_t st);
+int dvq_launch_pn_filter_back(int N, int Npad, long B, const void* w3f, const float* w3, const float* b3, int relu, const float* h2buf,
+                              const void* part, const unsigned* tstat, float* feat, long ld_feat, unsigned long long* stats, hipStream_t st);
 
 namespace {
 
@@ -56,10 +64,17 @@ __global__ void pn_layer1_kernel(const float* __restrict__ pc, int C, int N, int
     *reinterpret_cast<f32x4*>(out + pt * 64 + q * 4) = y;
 }
 
-struct PnScratch {
-    float *h1, *h2, *part, *f0, *f1, *f2, *tr;
+// Scratch of one encode call.  The filtered trunk works in LAUNCHES of ``chunk`` samples; a launch's trunk kernel ("front": centres,
+// conv1/conv2/conv3 filter, h2 rows + tile records) and its exact stage ("back": pn_exact_kernel, which reads them) use one of
+// ``slots`` scratch sets, so that the back of launch i can run on a second stream beside the front of launch i + 1 (below).
+struct PnSlot {
+    float *h2, *part, *cbuf;
     unsigned* tstat;
-    float* cbuf;
+};
+struct PnScratch {
+    PnSlot slot[4];
+    int slots;
+    float *h1, *f0, *f1, *f2, *tr;
     unsigned long long* stats;
     long chunk;
     int Npad;
@@ -69,32 +84,43 @@ struct PnScratch {
 PnScratch plan(int64_t B, int N, void* ws) {
     PnScratch s;
     s.Npad = (N + 255) / 256 * 256;                       // tiles of 128 (fused / unfused trunk) and of 256 (filtered trunk)
-    const size_t per_sample = (size_t)s.Npad * (64 + 128) * 4 + (size_t)s.Npad * 96 + (size_t)(s.Npad / 256) * 16 + 512 +
-                              (1024 + 512 + 256 + 16 + 1) * 4;
-    const size_t budget = (size_t)13 << 29;               // 6.5 GB: the benchmark batch in nine launches of 7 282 samples
+    const size_t per_sample = (size_t)s.Npad * 128 * 4 + (size_t)s.Npad * 96 + (size_t)(s.Npad / 256) * 16 + 512;
+    const size_t budget = (size_t)9 << 29;                // 4.5 GB per scratch set: 7 282 samples of 1 024 points
     long chunk = (long)(budget / per_sample);
-    {                                                     // samples per launch (default: what 6 GB of scratch hold)
+    {                                                     // samples per launch (DVQ_PN_CHUNK)
         const long v = dvq_knobs().pn_chunk;
         if (v > 0 && v < chunk) chunk = v;
+        // default: launches of at most 4 096 samples and at least four launches per pass once there are 2 048 samples, so that the two
+        // streams have something to overlap (the trunk kernel also likes a small, re-used h2 buffer: DESIGN.md 3.3)
+        if (v <= 0) {
+            if (chunk > 4096) chunk = 4096;
+            if (B >= 2048 && chunk > (B + 3) / 4) chunk = (B + 3) / 4;
+        }
     }
-    if (chunk < 1) chunk = 1;
     if (chunk > B) chunk = B;
     if (chunk < 1) chunk = 1;
-    // equal launches: 8 192 samples (an eighth of the benchmark batch) run as 2 x 4 096, not 7 500 + 692
+    // equal launches: 8 192 samples run as 4 x 2 048, not 3 x 2 731 + 1
     if (B > 0) chunk = (B + ((B + chunk - 1) / chunk) - 1) / ((B + chunk - 1) / chunk);
     s.chunk = chunk;
+    const long launches = B > 0 ? (B + chunk - 1) / chunk : 1;
+    s.slots = launches >= 2 ? (dvq_knobs().pn_slots > 0 ? dvq_knobs().pn_slots : 3) : 1;
+    if (s.slots > 4) s.slots = 4;
+    if (s.slots > 2 * launches) s.slots = (int)(2 * launches);
     char* p = (char*)ws;
     auto take = [&](size_t n) { char* q = p; p += dvq_round_up(n, 256); return (float*)q; };
-    s.h1 = take((size_t)chunk * s.Npad * 64 * 4);
-    s.h2 = take((size_t)chunk * s.Npad * 128 * 4);
-    s.part = take((size_t)chunk * s.Npad * 96);           // [tiles128][1024] floats, or [tiles256][1024] float4 + [tiles256][1024] float2
-    s.tstat = (unsigned*)take((size_t)chunk * (s.Npad / 256) * 16);
-    s.cbuf = take((size_t)chunk * 128 * 4);
+    for (int i = 0; i < 4; ++i) s.slot[i] = PnSlot{nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < s.slots; ++i) {
+        s.slot[i].h2 = take((size_t)chunk * s.Npad * 128 * 4);
+        s.slot[i].part = take((size_t)chunk * s.Npad * 96);   // [tiles128][1024] floats, or [tiles256][1024] float4 + [tiles256][1024] float2
+        s.slot[i].tstat = (unsigned*)take((size_t)chunk * (s.Npad / 256) * 16);
+        s.slot[i].cbuf = take((size_t)chunk * 128 * 4);
+    }
+    s.h1 = dvq_gemm_mode() == 1 ? nullptr : take((size_t)chunk * s.Npad * 64 * 4);   // the unfused trunk (DVQ_GEMM=fp32) only
     s.stats = (unsigned long long*)take(64);
     s.f0 = take((size_t)chunk * 1024 * 4);
     s.f1 = take((size_t)chunk * 512 * 4);
     s.f2 = take((size_t)chunk * 256 * 4);
-    s.tr = take((size_t)chunk * 16 * 4);
+    s.tr = take((size_t)(B > 0 ? B : 1) * 16 * 4);        // the whole batch's transforms: pass 1 writes them, pass 2 reads them
     s.bytes = (size_t)(p - (char*)ws);
     return s;
 }
@@ -116,23 +142,29 @@ int dense(const float* x, long ldx, int K, const float* w, const uint16_t* wp, c
 // DVQ_PN_FILTER: 0 = six-product trunk everywhere, 2 = filtered trunk whatever the fill of its tiles (tests), default 1
 int filter_mode() { return dvq_knobs().pn_filter; }
 
-int trunk(const float* pc, int C, int N, long Bc, const float* trans, const float* w1, const float* b1, const float* w2,
-          const uint16_t* w2p, const float* b2, const float* w3, const uint16_t* w3p, const void* w3f, const float* b3, int relu3,
-          const PnScratch& s, float* feat, long ld_feat, hipStream_t st) {
-    // filtered trunk (pointnet_filter.hip) when its 256-point tiles are at least 3/4 full: padding slots repeat real points, and
-    // many repeats mean many ties for the exact stage (N = 300 in two tiles: 4.6 ms against 3.6 ms for the six-product trunk)
+// does the filtered trunk (pointnet_filter.hip) take this shape?  When its 256-point tiles are at least 3/4 full: padding slots repeat
+// real points, and many repeats mean many ties for the exact stage (N = 300 in two tiles: 4.6 ms against 3.6 ms for the six-product trunk)
+bool use_filter(const dvq_pointnet_weights* w, int N) {
     const int fm = filter_mode();
     const int tiles256 = (N + 255) / 256, over = N - 256 * (tiles256 - 1);
     // slots the filtered trunk evaluates: whole tiles, or whole tiles + a 32-point tail block (pointnet_filter.hip)
     const long slots = (tiles256 >= 2 && over <= 32 && dvq_knobs().pn_tail) ? 256L * (tiles256 - 1) + 32 : 256L * tiles256;
-    if (w2p && w3f && dvq_gemm_mode() == 1 && fm && N <= 16384 && (fm == 2 || 4L * N >= 3L * slots))
-        return dvq_launch_pn_trunk_filter(pc, C, N, s.Npad, Bc, trans, w1, b1, w2, w2p, b2, w3f, w3, b3, relu3, s.h2, s.part, s.tstat,
-                                          s.cbuf, feat, ld_feat, dvq_knobs().pn_stats ? s.stats : nullptr, st);
+    return w->w2p && w->w3f && w->s_w2p && w->s_w3f && dvq_gemm_mode() == 1 && fm && N <= 16384 && (fm == 2 || 4L * N >= 3L * slots);
+}
+
+int trunk(const float* pc, int C, int N, long Bc, const float* trans, const float* w1, const float* b1, const float* w2,
+          const uint16_t* w2p, const float* b2, const float* w3, const uint16_t* w3p, const void* w3f, const float* b3, int relu3,
+          bool filtered, const PnScratch& s, float* feat, long ld_feat, hipStream_t st) {
+    const PnSlot& sl = s.slot[0];
+    if (filtered)
+        return dvq_launch_pn_trunk_filter(pc, C, N, s.Npad, Bc, trans, w1, b1, w2, w2p, b2, w3f, w3, b3, relu3, sl.h2, sl.part, sl.tstat,
+                                          sl.cbuf, feat, ld_feat, dvq_knobs().pn_stats ? s.stats : nullptr, st);
     if (w2p && w3p && dvq_gemm_mode() == 1) {       // fused trunk; w3p is the k-permuted plane image (see pn_trunk_kernel)
-        DVQ_PROPAGATE(dvq_launch_pn_trunk(pc, C, N, Bc, trans, w1, b1, w2p, b2, w3p, b3, s.part, st));
-        return dvq_launch_colmax_reduce(s.part, Bc, (N + 127) / 128, 1024, relu3, feat, ld_feat, st);   // the kernel's own tiling
+        DVQ_PROPAGATE(dvq_launch_pn_trunk(pc, C, N, Bc, trans, w1, b1, w2p, b2, w3p, b3, sl.part, st));
+        return dvq_launch_colmax_reduce(sl.part, Bc, (N + 127) / 128, 1024, relu3, feat, ld_feat, st);   // the kernel's own tiling
     }
     w3p = nullptr;                                  // the unfused GEMM path takes natural-order planes only: split on the fly
+    DVQ_REQUIRE(s.h1, "pointnet: no scratch for the unfused trunk");
     const long rows = Bc * s.Npad;
     const long threads = rows * 16;
     {
@@ -141,9 +173,9 @@ int trunk(const float* pc, int C, int N, long Bc, const float* trans, const floa
                            trans, w1, b1, s.h1);
     }
     DVQ_CHECK_LAUNCH("pn_layer1");
-    DVQ_PROPAGATE(dense(s.h1, 64, 64, w2, w2p, b2, rows, 128, 1, s.h2, 128, st));
+    DVQ_PROPAGATE(dense(s.h1, 64, 64, w2, w2p, b2, rows, 128, 1, sl.h2, 128, st));
     GemmParams p = {};
-    p.src[0] = GemmSrc{s.h2, w3, 128, 128, 128, 0, w3p, 1024L * 128};
+    p.src[0] = GemmSrc{sl.h2, w3, 128, 128, 128, 0, w3p, 1024L * 128};
     p.nsrc = 1;
     p.M = rows;
     p.N = 1024;
@@ -151,9 +183,104 @@ int trunk(const float* pc, int C, int N, long Bc, const float* trans, const floa
     p.relu = 0;                  // max(relu(x)) == relu(max(x)): the ReLU is applied by the reduction
     p.rows_per_group = s.Npad;
     p.valid_rows = N;
-    p.partial = s.part;
+    p.partial = sl.part;
     DVQ_PROPAGATE(dvq_launch_gemm(p, EPI_COLMAX, st));
-    return dvq_launch_colmax_reduce(s.part, Bc, s.Npad / 128, 1024, relu3, feat, ld_feat, st);
+    return dvq_launch_colmax_reduce(sl.part, Bc, s.Npad / 128, 1024, relu3, feat, ld_feat, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Second stream per (device, caller's stream), with a pool of events: the exact stage and the STN's FC layers of launch i run there,
+// beside the trunk kernel of launch i + 1 on the caller's stream.  pn_exact_kernel waits on gathers (71 % of its wave cycles) and
+// the trunk kernel issues matrix / vector work: resident together they fill each other's stalls.
+struct PnSide {
+    hipStream_t s2 = nullptr;
+    std::vector<hipEvent_t> ev;
+    hipEvent_t event(size_t i) {
+        while (ev.size() <= i) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+            ev.push_back(e);
+        }
+        return ev[i];
+    }
+};
+PnSide* side_for(hipStream_t st) {
+    static std::mutex lock;
+    static std::map<std::pair<int, hipStream_t>, PnSide*> sides;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(lock);
+    PnSide*& sd = sides[std::make_pair(dev, st)];
+    if (!sd) {
+        PnSide* n = new PnSide();
+        if (hipStreamCreateWithFlags(&n->s2, hipStreamNonBlocking) != hipSuccess) { delete n; return nullptr; }
+        sd = n;
+    }
+    return sd;
+}
+
+#define PN_HIP(call, what)                                                                  \
+    do {                                                                                    \
+        const hipError_t e__ = (call);                                                      \
+        if (e__ != hipSuccess) {                                                            \
+            dvq_set_error("pointnet_encode: %s failed: %s", what, hipGetErrorString(e__)); \
+            return DVQ_ELAUNCH;                                                             \
+        }                                                                                   \
+    } while (0)
+
+// Both passes (STN, main) of the filtered trunk over the launches of a batch, two streams:
+//   S1 (the caller's): front(i) = centres + trunk kernel into scratch set i % slots
+//   S2:                back(i) = pn_exact_kernel of that set -> features; pass 1: the STN's FCs of the launch -> its transforms
+// front(i) waits for back(i - slots) (its scratch set is free) and, in pass 2, for the transforms of its launch.
+int encode_two_streams(const dvq_pointnet_weights* w, const float* pc, int64_t B, int N, float* feat, int64_t ld_feat, float* trans_out,
+                       const PnScratch& s, hipStream_t st) {
+    PnSide* sd = side_for(st);
+    DVQ_REQUIRE(sd, "pointnet_encode: no second stream");
+    hipStream_t s2 = sd->s2;
+    const long launches = (B + s.chunk - 1) / s.chunk;
+    // events: [0] start / join, [1 .. slots] front done, [1 + slots .. 2 slots] set free, then one per launch: transforms ready
+    const size_t e_front = 1, e_free = 1 + s.slots, e_tr = 1 + 2 * s.slots;
+    DVQ_REQUIRE(sd->event(e_tr + launches), "pointnet_encode: event creation failed");
+    unsigned long long* stats = dvq_knobs().pn_stats ? s.stats : nullptr;
+    PN_HIP(hipEventRecord(sd->event(0), st), "hipEventRecord");
+    PN_HIP(hipStreamWaitEvent(s2, sd->event(0), 0), "hipStreamWaitEvent");        // S2 starts behind everything enqueued on S1 so far
+    float* tr_all = trans_out ? trans_out : s.tr;
+    int rc = DVQ_OK;
+    long idx = 0;
+    for (int pass = 0; pass < 2 && rc == DVQ_OK; ++pass)
+        for (long c = 0; c < launches && rc == DVQ_OK; ++c, ++idx) {
+            const int64_t b0 = c * s.chunk;
+            const long Bc = (long)((B - b0 < s.chunk) ? (B - b0) : s.chunk);
+            const float* pcb = pc + b0 * (long)w->C * N;
+            const PnSlot& sl = s.slot[idx % s.slots];
+            float* tr = tr_all + b0 * 9;
+            if (idx >= s.slots) PN_HIP(hipStreamWaitEvent(st, sd->event(e_free + idx % s.slots), 0), "hipStreamWaitEvent");
+            if (pass == 1) PN_HIP(hipStreamWaitEvent(st, sd->event(e_tr + c), 0), "hipStreamWaitEvent");
+            rc = pass == 0 ? dvq_launch_pn_filter_front(pcb, w->C, N, s.Npad, Bc, nullptr, w->s_w1, w->s_b1, w->s_w2, w->s_w2p, w->s_b2, w->s_w3f,
+                                                        sl.h2, sl.part, sl.tstat, sl.cbuf, stats, st)
+                           : dvq_launch_pn_filter_front(pcb, w->C, N, s.Npad, Bc, tr, w->w1, w->b1, w->w2, w->w2p, w->b2, w->w3f, sl.h2, sl.part,
+                                                        sl.tstat, sl.cbuf, stats, st);
+            if (rc != DVQ_OK) break;
+            PN_HIP(hipEventRecord(sd->event(e_front + idx % s.slots), st), "hipEventRecord");
+            PN_HIP(hipStreamWaitEvent(s2, sd->event(e_front + idx % s.slots), 0), "hipStreamWaitEvent");
+            if (pass == 0) {
+                // STN3d: trunk with ReLU on the last layer, then fc1/fc2 (BN folded, ReLU) and fc3 (+identity)
+                rc = dvq_launch_pn_filter_back(N, s.Npad, Bc, w->s_w3f, w->s_w3, w->s_b3, 1, sl.h2, sl.part, sl.tstat, s.f0, 1024, stats, s2);
+                PN_HIP(hipEventRecord(sd->event(e_free + idx % s.slots), s2), "hipEventRecord");
+                if (rc == DVQ_OK) rc = dense(s.f0, 1024, 1024, w->s_f1, w->s_f1p, w->s_c1, Bc, 512, 1, s.f1, 512, s2);
+                if (rc == DVQ_OK) rc = dense(s.f1, 512, 512, w->s_f2, w->s_f2p, w->s_c2, Bc, 256, 1, s.f2, 256, s2);
+                if (rc == DVQ_OK) rc = dense(s.f2, 256, 256, w->s_f3, w->s_f3p, w->s_c3, Bc, 9, 0, tr, 9, s2);
+                PN_HIP(hipEventRecord(sd->event(e_tr + c), s2), "hipEventRecord");
+            } else {
+                // main trunk on the transformed cloud; no ReLU after the last BN (pointnet_encoder.py:162)
+                rc = dvq_launch_pn_filter_back(N, s.Npad, Bc, w->w3f, w->w3, w->b3, 0, sl.h2, sl.part, sl.tstat, feat + b0 * ld_feat, ld_feat, stats, s2);
+                PN_HIP(hipEventRecord(sd->event(e_free + idx % s.slots), s2), "hipEventRecord");
+            }
+        }
+    // join: whatever happened, the caller's stream continues behind everything enqueued on S2
+    PN_HIP(hipEventRecord(sd->event(0), s2), "hipEventRecord");
+    PN_HIP(hipStreamWaitEvent(st, sd->event(0), 0), "hipStreamWaitEvent");
+    return rc;
 }
 
 }  // namespace
@@ -178,18 +305,20 @@ extern "C" int dvq_pointnet_encode(const dvq_pointnet_weights* w, const float* p
         return DVQ_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
+    const bool filtered = use_filter(w, N);
+    if (filtered && s.slots >= 2 && dvq_knobs().pn_streams) return encode_two_streams(w, pc, B, N, feat, ld_feat, trans_out, s, st);
     for (int64_t b0 = 0; b0 < B; b0 += s.chunk) {
         const long Bc = (long)((B - b0 < s.chunk) ? (B - b0) : s.chunk);
         const float* pcb = pc + b0 * (long)w->C * N;
         // STN3d: trunk with ReLU on the last layer, then fc1/fc2 (BN folded, ReLU) and fc3 (+identity)
         DVQ_PROPAGATE(trunk(pcb, w->C, N, Bc, nullptr, w->s_w1, w->s_b1, w->s_w2, w->s_w2p, w->s_b2, w->s_w3, w->s_w3p, w->s_w3f, w->s_b3,
-                            1, s, s.f0, 1024, st));
+                            1, filtered, s, s.f0, 1024, st));
         DVQ_PROPAGATE(dense(s.f0, 1024, 1024, w->s_f1, w->s_f1p, w->s_c1, Bc, 512, 1, s.f1, 512, st));
         DVQ_PROPAGATE(dense(s.f1, 512, 512, w->s_f2, w->s_f2p, w->s_c2, Bc, 256, 1, s.f2, 256, st));
-        float* tr = trans_out ? trans_out + b0 * 9 : s.tr;
+        float* tr = (trans_out ? trans_out : s.tr) + b0 * 9;
         DVQ_PROPAGATE(dense(s.f2, 256, 256, w->s_f3, w->s_f3p, w->s_c3, Bc, 9, 0, tr, 9, st));
         // main trunk on the transformed cloud; no ReLU after the last BN (pointnet_encoder.py:162)
-        DVQ_PROPAGATE(trunk(pcb, w->C, N, Bc, tr, w->w1, w->b1, w->w2, w->w2p, w->b2, w->w3, w->w3p, w->w3f, w->b3, 0, s,
+        DVQ_PROPAGATE(trunk(pcb, w->C, N, Bc, tr, w->w1, w->b1, w->w2, w->w2p, w->b2, w->w3, w->w3p, w->w3f, w->b3, 0, filtered, s,
                             feat + b0 * ld_feat, ld_feat, st));
     }
     return DVQ_OK;

@@ -5,9 +5,10 @@
 //      pn_trunk_kernel; the fp32 h2 rows [point][128] go to HBM.  conv3 (94 % of the trunk's FLOPs) is then evaluated as ONE
 //      fp16 product per term on CENTRED rows: d_p = h2_p - c (c = pn_center_kernel's mean of four rows of the sample; the
 //      argmax over the points does not depend on it), d scaled by a per-wave power of two, W3 by a per-channel power of
-//      two, both rounded to fp16.  Per (sample, 256-point tile, channel) the kernel emits the FIVE largest approximate
-//      scores that carry the id of their point in the low mantissa bits, and one flag per wave (64 points) that holds
-//      further points in range whose ids were not kept.
+//      two, both rounded to fp16.  Every lane keeps, per 32 x 32 accumulator block (its 16 points of one channel), the TWO largest
+//      approximate scores with the id of their point in the low mantissa bits; per (sample, 256-point tile, channel) the kernel
+//      emits the FIVE largest of those 32 values and one flag per 16-point group that may hold further points in range whose
+//      ids were not kept.
 //   2. pn_exact_kernel: per (sample, channel) the estimate of a point's score is  approx + exact_dot(w_n, c)  with
 //      |estimate - exact_dot(w_n, h2_p)| <= E_t = |r_n| max_p |d_p| + |w_n| max_p |rd_p| + C_ID |w_n| max_p |d_p|
 //      + 2 DELTA |w_n| max_p |h2_p|, maxima over the tile; r_n = w_n - fp16 image (norm measured by the packer), rd_p =
@@ -15,11 +16,12 @@
 //      one exact_dot.  Every tracked
 //      point whose upper bound reaches the best lower bound is re-evaluated in fp32 (exact_dot: a fixed-order fp32 FMA dot
 //      of W3[n,:] and the stored h2 row) and the maximum of THOSE values + bias is the feature -- bit-identical to the
-//      maximum of exact_dot over ALL points (tests: DVQ_PN_EXHAUSTIVE=1 evaluates exactly that).  The 64 points of a flagged
-//      wave are all evaluated.
+//      maximum of exact_dot over ALL points (tests: DVQ_PN_EXHAUSTIVE=1 evaluates exactly that).  The 16 points of a flagged
+//      group are all evaluated.
 //
 // Matrix-core cost per (32 points x 32 channels x K=128): 8 x v_mfma_f32_32x32x16_f16 instead of 48 bf16 MFMAs; the
-// kernel is co-bound by the vector port (4 instructions per score: id, max, two med3) -- see DESIGN.md 3.3.
+// kernel is bound by vector-instruction issue: 3 instructions per score (id, med3, max) since round 5 -- a top-two per 16-point
+// group flags about as many points for re-evaluation as the top-three per 32 points of round 4 did.
 #include "dvq_internal.h"
 #include <vector>
 
@@ -42,8 +44,8 @@ constexpr int MAX_TILES = 64;                             // filtered trunk: N <
 
 constexpr int F_STAGE2 = 3 * 64 * 128;                    // conv2: one half of W2's planes (3 x 64 rows x 128 B)
 constexpr int F_STAGE3 = 64 * 256;                        // conv3: 64 channels x 128 k fp16
-constexpr int F_OFF_TB = 2 * F_STAGE3;                    // conv3 phase: record ring [4 chunks][4 waves][2 halves][3][64] fp32 (24 KiB of the 32 reserved) behind the two W3 stages
-constexpr int F_SLOT = 4 * 2 * 3 * 64;                    // floats per chunk slot of the ring
+constexpr int F_OFF_TB = 2 * F_STAGE3;                    // conv3 phase: record ring [4 chunks][4 waves][2 point blocks][2 halves][2][64] fp32 (32 KiB) behind the two W3 stages
+constexpr int F_SLOT = 4 * 2 * 2 * 2 * 64;                // floats per chunk slot of the ring
 constexpr int F_OFF_W1 = F_OFF_TB + 8 * 4 * 4 * 64 * 4;   // [64][4] fp32
 constexpr int F_OFF_B1 = F_OFF_W1 + 64 * 4 * 4;           // [64]
 constexpr int F_OFF_B2 = F_OFF_B1 + 64 * 4;               // [128]
@@ -51,8 +53,9 @@ constexpr int F_OFF_SC = F_OFF_B2 + 128 * 4;              // [4] 1 / (wave scale
 constexpr int F_OFF_TI = F_OFF_SC + 64;                   // [1024] 1 / (channel scale)
 constexpr int F_OFF_CS = F_OFF_TI + 4096;                 // [128] centre of the sample
 constexpr int F_OFF_WS = F_OFF_CS + 512;                  // [3][4] per-wave |h|max, |d|max, |rd|max
-constexpr int F_LDS = F_OFF_WS + 64;                      // 72 064 B -> 2 workgroups per CU
-constexpr int F_LDS_TAIL = F_LDS + 4 * 512;               // tail kernel: one centre per wave (its own sample) behind the common image
+constexpr int F_OFF_E2 = F_OFF_WS + 64;                   // [1024] 2 E of the tile per channel ([4][1024] in the tail kernel: a tile per wave)
+constexpr int F_LDS = F_OFF_E2 + 4096;                    // 76 160 B -> 2 workgroups per CU
+constexpr int F_LDS_TAIL = F_LDS + 3 * 4096 + 4 * 512;    // tail kernel: three more e2 tables, one centre per wave (its own sample) behind them
 static_assert(F_OFF_W1 >= 2 * F_STAGE2, "the conv3 stages and the triple buffer cover the W2 region");
 
 // h - x with h the low (HI = 0) or high (HI = 1) fp16 half of hp: one v_fma_mix_f32, exact
@@ -196,7 +199,8 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     const long b = live ? b_raw : B - 1;
     const int tile = TAIL ? deal : (int)(blockIdx.x % deal);
     const long rec = b * tiles + tile;                     // (sample, tile) record
-    float* cs = reinterpret_cast<float*>(fl + (TAIL ? F_LDS + 512 * wave : F_OFF_CS));
+    float* cs = reinterpret_cast<float*>(fl + (TAIL ? F_LDS + 3 * 4096 + 512 * wave : F_OFF_CS));
+    float* e2s = reinterpret_cast<float*>(fl + F_OFF_E2) + (TAIL ? 1024 * wave : 0);
 
     const unsigned long long t_start = (abl & 4096) ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long t_a = 0, t_b = 0, t_c = 0;
@@ -230,6 +234,12 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         xin[pb][0] = x0; xin[pb][1] = x1; xin[pb][2] = x2; xin[pb][3] = x3;
     }
     dvq_dma_barrier();                                    // W1/b1/b2 visible, W2 planes landed
+    // The same wait once more in a form the compiler's counter model sees (vmcnt(0), the other counters untouched).  Without it the
+    // FIRST use of the second point block's coordinates -- loaded above, consumed after the first block's sixteen h2 stores -- gets an
+    // "s_waitcnt vmcnt(3)": the stores sit in a branch (padding slots store nothing), the compiler takes the smaller count of the two
+    // paths, and the wave waits for thirteen of its sixteen stores to be ACKNOWLEDGED before it goes on (round 5: -11 % of the kernel
+    // with the stores ablated, all of it this wait).
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     if (abl & 4096) t_a = __builtin_amdgcn_s_memtime();
     float cnorm;                                          // |c| (every wave for itself: no ordering between the waves needed)
     {
@@ -271,6 +281,11 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
                 qbf16x8 wf[3];
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) wf[pl] = w2_frag(st, pl, row, 2 * s + h);
+                if (abl & 8) {                                // timing only: what a three-product conv2 would cost in matrix work
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1], h1f[s][0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], h1f[s][1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], h1f[s][0], acc, 0, 0, 0);
+                } else
                 Q_MFMA6(acc, wf, h1f[s]);
             }
 #pragma unroll
@@ -345,6 +360,10 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         rn2 = fmaxf(rn2, sq);
     }
     rn2 = wave_max(rn2);
+    // conv3's first W3 chunk: requested BEFORE the three atomics below -- the wait for these loads then leaves the atomics (younger,
+    // in the in-order counter) pending instead of sitting out their round trip (600 .. 3 000 cycles each under load)
+    const char* w3h = w3f;
+    W3Regs wreg = w3_load(w3h, 0, wave, lane);
     if (lane == 0) {              // per-tile maxima; non-negative floats (and NaN, above all of them) order as integers
         const float dmx = sqrtf(dn2), rdm = sqrtf(rn2) / s_w;
         const float hm = (dmx + cnorm) * 1.0001f;          // |h_p| <= |h_p - c| + |c|
@@ -359,74 +378,102 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     __syncthreads();                                      // everybody is done with W2 in the stages; scs visible
     if (abl & 4096) t_c = __builtin_amdgcn_s_memtime();
 
-    // ---- conv3, filtered: 16 chunks of 64 channels, one fp16 product, top three scores per channel
-    const char* w3h = w3f;
-    W3Regs wreg = w3_load(w3h, 0, wave, lane);
+    // ---- conv3, filtered: 16 chunks of 64 channels, one fp16 product, top two scores per channel and 16-point group
     w3_store(fl, wave, lane, wreg);
-    const float* wnorm_g = reinterpret_cast<const float*>(w3f + 1024 * 256 + 4096);
-    const float* rnorm_g = reinterpret_cast<const float*>(w3f + 1024 * 256 + 8192);
-    // Per channel of chunk c the publishing wave merges the sorted triples of the eight lane halves (4 waves x 2) into the tile's
-    // FIVE largest id-carrying scores (real units: three + the flags in a 16-byte record, the fourth and fifth in an 8-byte one that
-    // pn_exact_kernel reads only where the third is in range) and one flag per lane half (32 points) "may hold a point within 2 E of
-    // the tile's largest score that is not among the five".  The ring holds four chunks: after chunks 3, 7, 11 and 15 every wave
-    // publishes one (all four busy at the same time: no wave waits for a publisher at the chunk barriers).
-    auto publish = [&](int c) {
-        const float* src = tb + (c & 3) * F_SLOT;          // [wave][half][k][channel]: every lane's own sorted triple, as finish() left it
-        const float ti = tis[64 * c + lane];
-        const float pub_wn = wnorm_g[64 * c + lane], pub_rn = rnorm_g[64 * c + lane];
-        // the tile's maxima: over its four waves -- over the publishing wave alone where every wave is a tile of its own (TAIL)
+    {
+        // 2 E of this tile for every channel, once, into the LDS (the publishing waves used to fetch the two weight norms of their
+        // channels from global memory at the top of every publish: an L2 round trip in front of four idle waves, four times)
+        const float* wnorm_g = reinterpret_cast<const float*>(w3f + 1024 * 256 + 4096);
+        const float* rnorm_g = reinterpret_cast<const float*>(w3f + 1024 * 256 + 8192);
+        // the tile's maxima: over its four waves -- over the wave alone where every wave is a tile of its own (TAIL)
         const float hm = (TAIL ? wst[wave] : fmaxf(fmaxf(wst[0], wst[1]), fmaxf(wst[2], wst[3]))) * 1.00001f;
         const float dmx = (TAIL ? wst[4 + wave] : fmaxf(fmaxf(wst[4], wst[5]), fmaxf(wst[6], wst[7]))) * 1.00001f;
         const float rdm = (TAIL ? wst[8 + wave] : fmaxf(fmaxf(wst[8], wst[9]), fmaxf(wst[10], wst[11]))) * 1.00001f;
-        const float e2 = 2.0f * fmaf(pub_rn, dmx, fmaf(pub_wn, rdm, fmaf(C_ID * pub_wn, dmx, 2.0f * DELTA * pub_wn * hm)));
-        // a stored value in real units with the rest of its id: bits [4:0] point block + register (the chain's), 5 lane half, [7:6] wave
-        auto value = [&](int w, int hh, int k) {
-            const int ws = TAIL ? wave : w;                // whose triples (TAIL: one wave = the whole tile, "wave 0" of its record)
-            const float x = src[((ws * 2 + hh) * 3 + k) * 64 + lane] * (scs[ws] * ti);
-            return __uint_as_float((__float_as_uint(x) & ~0xE0u) | (unsigned)(w << 6) | (unsigned)(hh << 5));
-        };
+        constexpr int PER = TAIL ? 16 : 4;                 // channels per lane: a wave fills its own table (TAIL), the workgroup one
+#pragma unroll
+        for (int i = 0; i < PER; i += 4) {
+            float wn[4], rn[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int n = (TAIL ? lane : tid) + (TAIL ? 64 : 256) * (i + u);
+                wn[u] = wnorm_g[n];
+                rn[u] = rnorm_g[n];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int n = (TAIL ? lane : tid) + (TAIL ? 64 : 256) * (i + u);
+                e2s[n] = 2.0f * fmaf(rn[u], dmx, fmaf(wn[u], rdm, fmaf(C_ID * wn[u], dmx, 2.0f * DELTA * wn[u] * hm)));
+            }
+        }
+    }
+    // Per channel of chunk c the publishing wave merges the sorted PAIRS of the sixteen 16-point groups (4 waves x 2 point blocks x 2
+    // lane halves) into the tile's FIVE largest id-carrying scores (real units: three + the flags in a 16-byte record, the fourth and
+    // fifth in an 8-byte one that pn_exact_kernel reads only where the third is in range) and one flag per group "may hold a point
+    // within 2 E of the tile's largest score that is not among the five".  The ring holds four chunks: after chunks 3, 7, 11 and 15
+    // every wave publishes one (all four busy at the same time: no wave waits for a publisher at the chunk barriers).
+    auto publish = [&](int c) {
+        const float* src = tb + (c & 3) * F_SLOT;          // [wave][point block][half][k][channel]: every lane's own sorted pair, as finish() left it
+        const float ti = tis[64 * c + lane];
+        // all sixteen pairs first (one trip to the LDS), in real units, with the rest of their ids: bits [4:0] point block + register
+        // (the chain's), 5 lane half, [7:6] wave
+        constexpr int NG = TAIL ? 2 : 16;                  // groups: 4 w + 2 pb + hh (TAIL: the publishing wave's two lane halves, "wave 0")
+        float t1[NG], t2[NG];
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const int w = TAIL ? 0 : gi >> 2, pb = TAIL ? 0 : (gi >> 1) & 1, hh = gi & 1;
+            const int ws = TAIL ? wave : w;                // whose pairs (TAIL: one wave = the whole tile)
+            const float* q = src + (((ws * 2 + pb) * 2 + hh) * 2) * 64 + lane;
+            t1[gi] = q[0];
+            t2[gi] = q[64];
+        }
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const int w = TAIL ? 0 : gi >> 2, hh = gi & 1;
+            const float sc = scs[TAIL ? wave : w] * ti;     // a power of two
+            const unsigned tag = (unsigned)(w << 6) | (unsigned)(hh << 5);
+            t1[gi] = __uint_as_float((__float_as_uint(t1[gi] * sc) & ~0xE0u) | tag);
+            t2[gi] = __uint_as_float((__float_as_uint(t2[gi] * sc) & ~0xE0u) | tag);
+        }
+        const float e2 = e2s[64 * c + lane];               // 2 E of the tile for this channel (filled once, before the loop)
         float c1 = NEG_BIG, c2 = NEG_BIG, c3 = NEG_BIG, c4 = NEG_BIG, c5 = NEG_BIG;   // the tile's FIVE largest id-carrying scores
 #pragma unroll
-        for (int w = 0; w < (TAIL ? 1 : 4); ++w)
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float x = value(w, hh, k);
-                    c5 = __builtin_amdgcn_fmed3f(c4, c5, x); c4 = __builtin_amdgcn_fmed3f(c3, c4, x);
-                    c3 = __builtin_amdgcn_fmed3f(c2, c3, x); c2 = __builtin_amdgcn_fmed3f(c1, c2, x); c1 = max_nc(c1, x);
-                }
+        for (int gi = 0; gi < NG; ++gi) {
+            float x = t1[gi];
+            c5 = __builtin_amdgcn_fmed3f(c4, c5, x); c4 = __builtin_amdgcn_fmed3f(c3, c4, x);
+            c3 = __builtin_amdgcn_fmed3f(c2, c3, x); c2 = __builtin_amdgcn_fmed3f(c1, c2, x); c1 = max_nc(c1, x);
+            x = t2[gi];                                    // <= t1[gi] <= c1: never the new largest
+            c5 = __builtin_amdgcn_fmed3f(c4, c5, x); c4 = __builtin_amdgcn_fmed3f(c3, c4, x);
+            c3 = __builtin_amdgcn_fmed3f(c2, c3, x); c2 = __builtin_amdgcn_fmed3f(c1, c2, x);
+        }
         const float thr = c1 - e2;                         // NaN -> no flag here; pn_exact_kernel sees the non-finite bound
-        // bit 2 w + h: lane half h of wave w may hold a point in range that is not among the five: its THIRD is in range (a fourth
-        // could be: the lanes keep three), or one of its first two is in range and was not kept (six in range in the tile).  The
-        // values are read again rather than kept in registers (the loop around this runs at 248).
+        // bit 4 w + 2 pb + h: that 16-point group may hold a point in range that is not among the five: its SECOND is in range (a
+        // third could be: the lanes keep two), or its first is in range and was not kept (six in range in the tile).  With t1 >= t2
+        // that is "u >= thr" for u = t1 if t1 was not kept (t1 < c5), else t2 -- no branches, no second trip to the LDS.
         unsigned flags = 0;
 #pragma unroll
-        for (int w = 0; w < (TAIL ? 1 : 4); ++w)
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const float t1 = value(w, hh, 0), t2 = value(w, hh, 1), t3 = value(w, hh, 2);
-                const bool f = (t3 >= thr) || (t2 >= thr && t2 < c5) || (t1 >= thr && t1 < c5);
-                flags |= f ? (1u << (2 * w + hh)) : 0u;
-            }
+        for (int gi = NG - 1; gi >= 0; --gi) {
+            const float u = t1[gi] < c5 ? t1[gi] : t2[gi];
+            flags = flags + flags + (unsigned)(u >= thr);
+        }
         if (live) {
             part[rec * 1024 + 64 * c + lane] = f32x4{c1, c2, c3, __uint_as_float(flags)};
             part2[rec * 1024 + 64 * c + lane] = qf32x2{c4, c5};
         }
     };
-    // one 32-point x 32-channel block: 8 MFMAs; its 32 scores per lane go through the top-three chain (4 vector
-    // instructions per score) while the NEXT block's MFMAs run: 1 MFMA (32 cycles of the matrix pipe) per 8 chain instructions
+    // one 32-point x 32-channel block: 8 MFMAs; its 16 scores per lane go through the top-two chain (3 vector instructions per
+    // score) while the NEXT block's MFMAs run: 1 MFMA (32 cycles of the matrix pipe) per 6 chain instructions
 #define F_MFMA_BLOCK(ACC, PB, WF)                                                                              \
     do {                                                                                                       \
         _Pragma("unroll") for (int e = 0; e < 16; ++e) ACC[e] = 0.f;                                           \
         _Pragma("unroll") for (int s = 0; s < 8; ++s)                                                          \
             ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3[PB][s], WF[s], ACC, 0, 0, 0);                      \
     } while (0)
-#define F_CHAIN_BLOCK(ACC, PB, M1, M2, M3)                                                                     \
+#define F_CHAIN_BLOCK(ACC, PB, M1, M2)                                                                         \
     do {                                                                                                       \
+        M1 = NEG_BIG; M2 = NEG_BIG;                                                                            \
+        if (abl & 128) { M1 = ACC[0]; M2 = ACC[15]; } else   /* timing only: no chain */                       \
         _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                       \
             const float x = __uint_as_float((__float_as_uint(ACC[e]) & ~31u) | (unsigned)(16 * (PB) + e));     \
-            M3 = __builtin_amdgcn_fmed3f(M2, M3, x);                                                           \
             M2 = __builtin_amdgcn_fmed3f(M1, M2, x);                                                           \
             M1 = max_nc(M1, x);                                                                                \
         }                                                                                                      \
@@ -435,14 +482,14 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     do {                                                                                                       \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                        \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 \
-            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);                                                 \
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                                                 \
         }                                                                                                      \
     } while (0)
-    // every lane hands its own sorted triple over (its lane half holds the channel's other 32 points: the publishing wave merges
-    // the two halves of the four waves -- one lane per channel there, where a merge here ran on two lanes per channel in every wave)
-    auto finish = [&](int c, int jn, float m1, float m2, float m3) {
-        float* dst = tb + (c & 3) * F_SLOT + (wave * 2 + h) * 192 + 32 * jn + r;
-        dst[0] = m1; dst[64] = m2; dst[128] = m3;
+    // every lane hands its own sorted pair of a block over (16 points of one channel); the publishing wave merges the sixteen groups
+    // of a (tile, channel) -- one lane per channel there
+    auto finish = [&](int c, int jn, int pb, float m1, float m2) {
+        float* dst = tb + (c & 3) * F_SLOT + ((wave * 2 + pb) * 2 + h) * 128 + 32 * jn + r;
+        dst[0] = m1; dst[64] = m2;
     };
     int stage = 0;
     if constexpr (TAIL) {
@@ -455,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
             if ((c & 3) == 0 && c > 0) {                  // the ring's four chunks are complete (barrier above)
 #pragma unroll 1
                 for (int q = c - 4; q < c; ++q) publish(q);
-                __syncthreads();                          // before this chunk's triples overwrite slot 0
+                __syncthreads();                          // before this chunk's pairs overwrite slot 0
             }
             const char* st = fl + stage * F_STAGE3;
             qf16x8 wf0[8], wf1[8];
@@ -464,28 +511,27 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
 #pragma unroll
             for (int s = 0; s < 8; ++s) wf1[s] = w3_frag(st, 32 + r, 2 * s + h);
             f32x16 accA, accB;
-            float a1 = NEG_BIG, a2 = NEG_BIG, a3m = NEG_BIG, q1 = NEG_BIG, q2 = NEG_BIG, q3 = NEG_BIG;
+            float a1, a2, q1, q2;
             F_MFMA_BLOCK(accA, 0, wf0);
             F_MFMA_BLOCK(accB, 0, wf1);
-            F_CHAIN_BLOCK(accA, 0, a1, a2, a3m);
+            F_CHAIN_BLOCK(accA, 0, a1, a2);
             F_INTERLEAVE();
-            F_CHAIN_BLOCK(accB, 0, q1, q2, q3);
-            finish(c, 0, a1, a2, a3m);
-            finish(c, 1, q1, q2, q3);
+            F_CHAIN_BLOCK(accB, 0, q1, q2);
+            finish(c, 0, 0, a1, a2);
+            finish(c, 1, 0, q1, q2);
             if (c + 1 < 16) w3_store(fl + (stage ^ 1) * F_STAGE3, wave, lane, wreg);
             stage ^= 1;
         }
     } else {
     f32x16 accP;                                          // the chunk's last accumulator block, scored under the next chunk's first MFMAs
-    float pb1 = NEG_BIG, pb2 = NEG_BIG, pb3 = NEG_BIG;
     bool pending = false;
 #pragma unroll 1
     for (int c = 0; c < ((abl & 2) ? 0 : 16); ++c) {
-        __syncthreads();                                  // chunk c is in its stage; the other stage and tb parity are free
+        if (!(abl & 16384)) __syncthreads();              // chunk c is in its stage; the other stage and tb parity are free
         if (c + 1 < 16 && !(abl & 1024)) wreg = w3_load(w3h, 64 * (c + 1), wave, lane);
         if ((c & 3) == 0 && c > 0 && !(abl & 256)) {        // the ring's four chunks are complete (barrier above): one per wave
             publish(c - 4 + wave);
-            __syncthreads();                              // before this chunk's triples overwrite slot 0
+            __syncthreads();                              // before this chunk's pairs overwrite slot 0
         }
         const char* st = fl + stage * F_STAGE3;
         qf16x8 wf0[8], wf1[8];
@@ -497,31 +543,34 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         // chain of a chunk (second point block x channels 32..63: accP) has no successor inside the chunk: it runs under the FIRST
         // MFMA block of the next chunk (8 dependent MFMAs that had nothing to cover them), except before a publish (c = 3, 7, 11, 15).
         f32x16 accA, accB;
-        float a1 = NEG_BIG, a2 = NEG_BIG, a3m = NEG_BIG;
+        float m1, m2;
         F_MFMA_BLOCK(accA, 0, wf0);
         if (pending) {
-            F_CHAIN_BLOCK(accP, 1, pb1, pb2, pb3);
+            F_CHAIN_BLOCK(accP, 1, m1, m2);
             F_INTERLEAVE();
-            if (!(abl & 512)) finish(c - 1, 1, pb1, pb2, pb3);
-            else if (pb1 + pb2 + pb3 == 12345.f) tb[lane] = pb1;
+            if (!(abl & 512)) finish(c - 1, 1, 1, m1, m2);
+            else if (m1 + m2 == 12345.f) tb[lane] = m1;
         }
         F_MFMA_BLOCK(accB, 1, wf0);
-        F_CHAIN_BLOCK(accA, 0, a1, a2, a3m);
+        F_CHAIN_BLOCK(accA, 0, m1, m2);
         F_INTERLEAVE();
+        if (!(abl & 512)) finish(c, 0, 0, m1, m2);
+        else if (m1 + m2 == 12345.f) tb[lane] = m1;
         F_MFMA_BLOCK(accA, 0, wf1);
-        F_CHAIN_BLOCK(accB, 1, a1, a2, a3m);
+        F_CHAIN_BLOCK(accB, 1, m1, m2);
         F_INTERLEAVE();
-        pb1 = NEG_BIG; pb2 = NEG_BIG; pb3 = NEG_BIG;
+        if (!(abl & 512)) finish(c, 0, 1, m1, m2);
+        else if (m1 + m2 == 12345.f) tb[lane] = m1;
         F_MFMA_BLOCK(accP, 1, wf1);
-        F_CHAIN_BLOCK(accA, 0, pb1, pb2, pb3);
+        F_CHAIN_BLOCK(accA, 0, m1, m2);
         F_INTERLEAVE();
-        if (!(abl & 512)) finish(c, 0, a1, a2, a3m);
-        else if (a1 + a2 + a3m == 12345.f) tb[lane] = a1;
+        if (!(abl & 512)) finish(c, 1, 0, m1, m2);
+        else if (m1 + m2 == 12345.f) tb[lane] = m1;
         pending = (c & 3) != 3;
         if (!pending) {
-            F_CHAIN_BLOCK(accP, 1, pb1, pb2, pb3);
-            if (!(abl & 512)) finish(c, 1, pb1, pb2, pb3);
-            else if (pb1 + pb2 + pb3 == 12345.f) tb[lane] = pb1;
+            F_CHAIN_BLOCK(accP, 1, m1, m2);
+            if (!(abl & 512)) finish(c, 1, 1, m1, m2);
+            else if (m1 + m2 == 12345.f) tb[lane] = m1;
         }
         if (c + 1 < 16 && !(abl & 1024)) w3_store(fl + (stage ^ 1) * F_STAGE3, wave, lane, wreg);
         stage ^= 1;
@@ -581,10 +630,10 @@ __device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k &
 
 // One workgroup per sample, 16 groups of 16 lanes.
 //   phase A (one thread per channel): best lower bound over the tiles; every kept score whose upper bound reaches it
-//           becomes a candidate point of the channel (table of 4 per channel, the rest in a list); flagged waves of tiles in
-//           contention become (channel, tile, wave) entries;
+//           becomes a candidate point of the channel (table of 4 per channel, the rest in a list); flagged 16-point groups of tiles
+//           in contention become (channel, tile, group) entries;
 //   phase B (one group per channel): the weight row once, its candidates' rows together, exact_dot, maximum;
-//   phase C (one wave per entry, no barrier): the 32 points of a flagged lane half of a wave; then, whole workgroup per channel, every
+//   phase C (one wave per entry, no barrier): the 16 points of a flagged group; then, whole workgroup per channel, every
 //           point for the channels on the "everything" list (DVQ_PN_EXHAUSTIVE / non-finite inputs).
 // stats (optional): channels with one candidate, with another count, wave entries, candidates.
 constexpr int PAIR_CAP = 1024;
@@ -670,7 +719,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
         auto consider = [&](int t, const f32x4& q) {
             const float et = bound(t);
             if (!(q[0] + et >= lb)) return;                 // the tile's largest score is out of range: so is the rest of it
-            unsigned flags = __float_as_uint(q[3]) & 255u;
+            unsigned flags = __float_as_uint(q[3]) & 0xFFFFu;   // one bit per 16-point group: 4 wave + 2 point block + lane half
             auto take = [&](float v) {                       // a kept score in range: its point becomes a candidate of the channel
                 int p = point_of_slot(t, slot_of_id(__float_as_uint(v) & 255u), deal);
                 if (p >= N) p %= N;                          // a padding slot: the real point it repeats
@@ -682,7 +731,10 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
                 else {
                     const int slot = atomicAdd(&pair_count, 1);
                     if (slot < pair_cap) pair_list[slot] = n | (p << 10);
-                    else flags |= 1u << ((__float_as_uint(v) >> 5) & 7u);   // list full (never seen): evaluate its 32-point half instead
+                    else {                                       // list full (never seen): evaluate its 16-point group instead
+                        const unsigned id = __float_as_uint(v);
+                        flags |= 1u << (4 * ((id >> 6) & 3u) + 2 * ((id >> 4) & 1u) + ((id >> 5) & 1u));
+                    }
                 }
                 ++cands;
             };
@@ -695,7 +747,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
                 if (q45[1] + et >= lb) take(q45[1]);
             }
             while (flags) {
-                const int wh = __ffs(flags) - 1;             // 2 * wave + lane half
+                const int wh = __ffs(flags) - 1;             // 4 * wave + 2 * point block + lane half
                 flags &= flags - 1;
                 const int slot = atomicAdd(&fb_count, 1);
                 if (slot < fb_cap) fb_list[slot] = n | (t << 10) | (wh << 20);
@@ -834,27 +886,27 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
         const float v = exact_dot(*reinterpret_cast<const f32x4*>(wr), *reinterpret_cast<const f32x4*>(wr + 4), h2 + (long)(code >> 10) * 128, j);
         if (j == 0) atomicMax(&best_k[n], f2key(v));
     }
-    // ---- phase C: flagged waves, one wave of the workgroup per entry, its four groups take 16 points each
+    // ---- phase C: flagged 16-point groups, one wave of the workgroup per entry, its four 16-lane groups take 4 points each
     const int nfb = (abl & 32) ? 0 : min(fb_count, fb_cap);
     for (int i = tid >> 6; i < nfb; i += 4) {
         const int code = fb_list[i];
-        const int n = code & 1023, t = (code >> 10) & 1023, w = (code >> 21) & 3, hh = (code >> 20) & 1;
+        const int n = code & 1023, t = (code >> 10) & 1023, w = (code >> 22) & 3, pb = (code >> 21) & 1, hh = (code >> 20) & 1;
         const float* wr = w3 + n * 128 + 8 * j;
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr), w1 = *reinterpret_cast<const f32x4*>(wr + 4);
         float best = NEG_BIG;
         {
-            f32x4 ha[8], hb[8];
+            f32x4 ha[4], hb[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {                   // this group's 8 of the half's 32 points (both point blocks)
-                const int i = 8 * (g & 3) + u, e = i & 15;
-                int p = point_of_slot(t, 64 * w + 32 * (i >> 4) + 8 * (e >> 2) + 4 * hh + (e & 3), deal);   // tail tile: both halves of i name its one block
+            for (int u = 0; u < 4; ++u) {                   // this lane group's 4 of the group's 16 points (accumulator registers e)
+                const int e = 4 * (g & 3) + u;
+                int p = point_of_slot(t, 64 * w + 32 * pb + 8 * (e >> 2) + 4 * hh + (e & 3), deal);   // tail tile: one block, pb = 0
                 if (p >= N) p %= N;
                 const float* hr = h2 + (long)p * 128 + 8 * j;
                 ha[u] = *reinterpret_cast<const f32x4*>(hr);
                 hb[u] = *reinterpret_cast<const f32x4*>(hr + 4);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) best = fmaxf(best, exact_dot_regs(w0, w1, ha[u], hb[u]));
+            for (int u = 0; u < 4; ++u) best = fmaxf(best, exact_dot_regs(w0, w1, ha[u], hb[u]));
         }
         if (j == 0) atomicMax(&best_k[n], f2key(best));
     }
@@ -989,17 +1041,29 @@ int dvq_launch_pn_filter_pack(const float* w3, void* image, hipStream_t st) {
     return DVQ_OK;
 }
 
-// tiles of 256 points; h2buf [B][Npad][128] fp32, part [B][tiles][1024] float4, hmax [B] (zeroed here)
-int dvq_launch_pn_trunk_filter(const float* pc, int C, int N, int Npad, long B, const float* trans, const float* W1, const float* b1,
-                               const float* W2, const uint16_t* W2p, const float* b2, const void* w3f, const float* w3, const float* b3,
-                               int relu, float* h2buf, void* part, unsigned* tstat, float* cbuf, float* feat, long ld_feat,
-                               unsigned long long* stats, hipStream_t st) {
-    const int tiles = (N + 255) / 256;
-    DVQ_REQUIRE(tiles <= MAX_TILES, "pointnet: the filtered trunk takes at most %d points", MAX_TILES * 256);
+// tiles of 256 points; h2buf [B][Npad][128] fp32, part [B][tiles][1024] float4 (+ float2 behind them), tstat [B][tiles][4] (zeroed here).
+// Two halves, so that the caller may put them on different streams (pointnet.hip: the exact stage of one launch runs beside the trunk
+// kernel of the next): dvq_launch_pn_filter_front = centres + trunk kernel(s), dvq_launch_pn_filter_back = pn_exact_kernel.
+static int pn_filter_geometry(int N, int* tiles, int* deal) {
+    *tiles = (N + 255) / 256;
+    DVQ_REQUIRE(*tiles <= MAX_TILES, "pointnet: the filtered trunk takes at most %d points", MAX_TILES * 256);
     // 1 .. 32 points beyond a multiple of 256 (the 778 MANO vertices: 3 x 256 + 10): a tail tile of one block, four samples per
     // workgroup, instead of a last full tile of padding (DVQ_PN_TAIL=0: the full tile, for A/B runs; same features bit for bit)
-    const int over = N - 256 * (tiles - 1);
-    const int deal = (tiles >= 2 && over <= 32 && dvq_knobs().pn_tail) ? tiles - 1 : tiles;
+    const int over = N - 256 * (*tiles - 1);
+    *deal = (*tiles >= 2 && over <= 32 && dvq_knobs().pn_tail) ? *tiles - 1 : *tiles;
+    return DVQ_OK;
+}
+#ifdef DVQ_DIAG
+static int pn_abl() { const char* e = getenv("DVQ_PN_ABL"); return e ? atoi(e) : 0; }   // timing-only ablations / phase stamps: diagnostics build only
+#else
+static constexpr int pn_abl() { return 0; }
+#endif
+
+int dvq_launch_pn_filter_front(const float* pc, int C, int N, int Npad, long B, const float* trans, const float* W1, const float* b1,
+                               const float* W2, const uint16_t* W2p, const float* b2, const void* w3f, float* h2buf, void* part,
+                               unsigned* tstat, float* cbuf, unsigned long long* stats, hipStream_t st) {
+    int tiles, deal;
+    DVQ_PROPAGATE(pn_filter_geometry(N, &tiles, &deal));
     static DvqOncePerDevice attr_once;
     {
         const hipError_t e = attr_once.run([] {
@@ -1035,12 +1099,7 @@ int dvq_launch_pn_trunk_filter(const float* pc, int C, int N, int Npad, long B, 
     }
     DVQ_CHECK_LAUNCH("pn_center");
     const double pts = (double)B * (deal * 256 + (deal < tiles ? 32 : 0));
-#ifdef DVQ_DIAG
-    const char* abl_e = getenv("DVQ_PN_ABL");              // timing-only ablations / phase stamps: diagnostics build only
-    const int abl = abl_e ? atoi(abl_e) : 0;
-#else
-    constexpr int abl = 0;
-#endif
+    const int abl = pn_abl();
     {
         DVQ_PROF("pn_trunk", 2.0 * pts * (4.0 * 64 + 64.0 * 128 + 128.0 * 1024), pts * (16 + 512) + (double)grid * 16384, st);
         if (C == 3)
@@ -1060,6 +1119,15 @@ int dvq_launch_pn_trunk_filter(const float* pc, int C, int N, int Npad, long B, 
         }
     }
     DVQ_CHECK_LAUNCH("pn_trunk_filter");
+    return DVQ_OK;
+}
+
+int dvq_launch_pn_filter_back(int N, int Npad, long B, const void* w3f, const float* w3, const float* b3, int relu, const float* h2buf,
+                              const void* part, const unsigned* tstat, float* feat, long ld_feat, unsigned long long* stats, hipStream_t st) {
+    int tiles, deal;
+    DVQ_PROPAGATE(pn_filter_geometry(N, &tiles, &deal));
+    const qf32x2* part2 = reinterpret_cast<const qf32x2*>((const char*)part + (size_t)B * tiles * 1024 * 16);
+    const int abl = pn_abl();
     const DvqKnobs& kn = dvq_knobs();
     const int exhaustive = kn.pn_exhaustive;
     int pair_cap = PAIR_CAP, fb_cap = FB_CAP;              // tests shrink the lists to reach the overflow paths
@@ -1085,17 +1153,25 @@ int dvq_launch_pn_trunk_filter(const float* pc, int C, int N, int Npad, long B, 
             const unsigned v = ts[4 * i + 3];
             a += v & 255; b2_ += (v >> 8) & 255; c += (v >> 16) & 255; d += (v >> 24) & 255;
         }
-        fprintf(stderr, "[dvq pn] mean phase ticks per workgroup (s_memtime, 100 MHz?): start->loaded %.0f, conv1+conv2 %.0f, centre/convert %.0f, conv3 loop %.0f\n",
+        fprintf(stderr, "[dvq pn] mean phase ticks per workgroup (s_memtime): start->loaded %.0f, conv1+conv2 %.0f, centre/convert %.0f, conv3 loop %.0f\n",
                 a / nrec * 64, b2_ / nrec * 64, c / nrec * 64, d / nrec * 512);
     }
     if (stats) {                                          // diagnostics (DVQ_PN_STATS=1): synchronises
         unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(h, stats, sizeof h, hipMemcpyDeviceToHost);
-        (void)hipMemset(stats, 0, sizeof h);
+        (void)hipMemset((void*)stats, 0, sizeof h);
         const double tot = (double)B * 1024;
-        fprintf(stderr, "[dvq pn] B=%ld N=%d: one candidate %.4f, other counts %.4f of the channels, flagged waves %.5f per channel; %.3f candidate dots per channel\n",
+        fprintf(stderr, "[dvq pn] B=%ld N=%d: one candidate %.4f, other counts %.4f of the channels, flagged 16-point groups %.5f per channel; %.3f candidate dots per channel\n",
                 B, N, h[0] / tot, h[1] / tot, h[2] / tot, h[3] / tot);
     }
     return DVQ_OK;
+}
+
+int dvq_launch_pn_trunk_filter(const float* pc, int C, int N, int Npad, long B, const float* trans, const float* W1, const float* b1,
+                               const float* W2, const uint16_t* W2p, const float* b2, const void* w3f, const float* w3, const float* b3,
+                               int relu, float* h2buf, void* part, unsigned* tstat, float* cbuf, float* feat, long ld_feat,
+                               unsigned long long* stats, hipStream_t st) {
+    DVQ_PROPAGATE(dvq_launch_pn_filter_front(pc, C, N, Npad, B, trans, W1, b1, W2, W2p, b2, w3f, h2buf, part, tstat, cbuf, stats, st));
+    return dvq_launch_pn_filter_back(N, Npad, B, w3f, w3, b3, relu, h2buf, part, tstat, feat, ld_feat, stats, st);
 }
