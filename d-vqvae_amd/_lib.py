@@ -96,6 +96,7 @@ SIGNATURES = {
                                      C.c_void_p, C.c_size_t, c_stream]),
     "dvq_vq_lookup": (C.c_int, [c_f32p, c_i64p, C.c_int64, C.c_int64, C.c_int, C.c_int, c_f32p, C.c_int64, c_i32p, c_stream]),
     "dvq_pointnet_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "dvq_pointnet_fault_counters": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
     "dvq_pointnet_filter_bytes": (C.c_size_t, []),
     "dvq_pointnet_pack_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dvq_pointnet_encode": (C.c_int, [C.POINTER(PointnetWeights), c_f32p, C.c_int64, C.c_int, c_f32p, C.c_int64, c_f32p,
@@ -137,7 +138,9 @@ def build(force: bool = False) -> str:
     if force and os.path.exists(LIB_PATH):
         os.remove(LIB_PATH)
     jobs = str(min(8, os.cpu_count() or 1))
-    r = subprocess.run(["make", "-C", CSRC, "-j", jobs], capture_output=True, text=True)
+    # "diag": the diagnostics twin (tools/diag/, -DDVQ_DIAG: timing ablations, phase stamps, fault injection for the run-time checks);
+    # never loaded by the product path -- tests/test_gpu_parity.py::test_pointnet_runtime_checks loads it in a child process
+    r = subprocess.run(["make", "-C", CSRC, "-j", jobs, "all", "diag"], capture_output=True, text=True)
     if r.returncode != 0 or not os.path.exists(LIB_PATH):
         raise RuntimeError("building libdvq_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
     return LIB_PATH

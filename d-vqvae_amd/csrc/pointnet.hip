@@ -25,7 +25,9 @@ int dvq_launch_pn_filter_front(const float* pc, int C, int N, int Npad, long B, 
                                const float* W2, const uint16_t* W2p, const float* b2, const void* w3f, float* h2buf, void* part,
                                unsigned* tstat, float* cbuf, unsigned long long* stats, hipStream_t st);
 int dvq_launch_pn_filter_back(int N, int Npad, long B, const void* w3f, const float* w3, const float* b3, int relu, const float* h2buf,
-                              const void* part, const unsigned* tstat, float* feat, long ld_feat, unsigned long long* stats, hipStream_t st);
+                              const void* part, const unsigned* tstat, const float* cbuf, float* feat, long ld_feat, unsigned long long* stats,
+                              hipStream_t st);
+int dvq_pn_fault_counters(unsigned long long* out2, int reset);
 
 namespace {
 
@@ -265,7 +267,7 @@ int encode_two_streams(const dvq_pointnet_weights* w, const float* pc, int64_t B
             PN_HIP(hipStreamWaitEvent(s2, sd->event(e_front + idx % s.slots), 0), "hipStreamWaitEvent");
             if (pass == 0) {
                 // STN3d: trunk with ReLU on the last layer, then fc1/fc2 (BN folded, ReLU) and fc3 (+identity)
-                rc = dvq_launch_pn_filter_back(N, s.Npad, Bc, w->s_w3f, w->s_w3, w->s_b3, 1, sl.h2, sl.part, sl.tstat, s.f0, 1024, stats, s2);
+                rc = dvq_launch_pn_filter_back(N, s.Npad, Bc, w->s_w3f, w->s_w3, w->s_b3, 1, sl.h2, sl.part, sl.tstat, sl.cbuf, s.f0, 1024, stats, s2);
                 PN_HIP(hipEventRecord(sd->event(e_free + idx % s.slots), s2), "hipEventRecord");
                 if (rc == DVQ_OK) rc = dense(s.f0, 1024, 1024, w->s_f1, w->s_f1p, w->s_c1, Bc, 512, 1, s.f1, 512, s2);
                 if (rc == DVQ_OK) rc = dense(s.f1, 512, 512, w->s_f2, w->s_f2p, w->s_c2, Bc, 256, 1, s.f2, 256, s2);
@@ -273,7 +275,7 @@ int encode_two_streams(const dvq_pointnet_weights* w, const float* pc, int64_t B
                 PN_HIP(hipEventRecord(sd->event(e_tr + c), s2), "hipEventRecord");
             } else {
                 // main trunk on the transformed cloud; no ReLU after the last BN (pointnet_encoder.py:162)
-                rc = dvq_launch_pn_filter_back(N, s.Npad, Bc, w->w3f, w->w3, w->b3, 0, sl.h2, sl.part, sl.tstat, feat + b0 * ld_feat, ld_feat, stats, s2);
+                rc = dvq_launch_pn_filter_back(N, s.Npad, Bc, w->w3f, w->w3, w->b3, 0, sl.h2, sl.part, sl.tstat, sl.cbuf, feat + b0 * ld_feat, ld_feat, stats, s2);
                 PN_HIP(hipEventRecord(sd->event(e_free + idx % s.slots), s2), "hipEventRecord");
             }
         }
@@ -325,6 +327,15 @@ extern "C" int dvq_pointnet_encode(const dvq_pointnet_weights* w, const float* p
 }
 
 extern "C" size_t dvq_pointnet_filter_bytes(void) { return dvq_pn_filter_image_bytes(); }
+
+extern "C" int dvq_pointnet_fault_counters(uint64_t* out, int reset) {
+    DVQ_REQUIRE(out, "pointnet_fault_counters: null pointer");
+    unsigned long long v[2] = {0, 0};
+    DVQ_PROPAGATE(dvq_pn_fault_counters(v, reset));
+    out[0] = v[0];
+    out[1] = v[1];
+    return DVQ_OK;
+}
 
 extern "C" int dvq_pointnet_pack_filter(const float* w3, void* image, dvq_stream_t stream) {
     DVQ_REQUIRE(w3 && image && dvq_aligned16(image), "pointnet_pack_filter: null/unaligned pointer");

@@ -426,6 +426,14 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
             t1[gi] = q[0];
             t2[gi] = q[64];
         }
+        // Run-time check of the hand-over: finish() stamps bits [6:5] of what it stores with (chunk / 4) mod 4, so a value left in
+        // this ring slot by an earlier chunk -- a store that did not happen or was not seen -- shows.  One stale input and the record
+        // cannot be trusted: every group is flagged (pn_exact_kernel then evaluates the whole tile for this channel) and bit 16 says
+        // why (counted: dvq_pointnet_fault_counters).  The pair of a group is ONE LDS store: checking its first value covers both.
+        unsigned tagdiff = 0;
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) tagdiff |= __float_as_uint(t1[gi]) ^ (unsigned)(((c >> 2) & 3) << 5);
+        const bool suspect = (tagdiff & 0x60u) != 0;
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
             const int w = TAIL ? 0 : gi >> 2, hh = gi & 1;
@@ -455,6 +463,8 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
             const float u = t1[gi] < c5 ? t1[gi] : t2[gi];
             flags = flags + flags + (unsigned)(u >= thr);
         }
+        if (suspect) flags = 0x1FFFFu;
+        if (DVQ_DIAG_ON && (abl & 32768) && c == 5 && lane == 7) c1 = fabsf(c1) * 1.0e3f + 1.0f;   // diagnostics: a record that lies about its tile
         if (live) {
             part[rec * 1024 + 64 * c + lane] = f32x4{c1, c2, c3, __uint_as_float(flags)};
             part2[rec * 1024 + 64 * c + lane] = qf32x2{c4, c5};
@@ -488,8 +498,11 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     // every lane hands its own sorted pair of a block over (16 points of one channel); the publishing wave merges the sixteen groups
     // of a (tile, channel) -- one lane per channel there
     auto finish = [&](int c, int jn, int pb, float m1, float m2) {
+        if (DVQ_DIAG_ON && (abl & 65536) && c == 9 && wave == 2 && jn == 0) return;   // diagnostics: a hand-over that does not happen
         float* dst = tb + (c & 3) * F_SLOT + ((wave * 2 + pb) * 2 + h) * 128 + 32 * jn + r;
-        dst[0] = m1; dst[64] = m2;
+        const unsigned ctag = (unsigned)(((c >> 2) & 3) << 5);   // which of the four chunks that share this ring slot (checked by publish())
+        dst[0] = __uint_as_float((__float_as_uint(m1) & ~0x60u) | ctag);
+        dst[64] = __uint_as_float((__float_as_uint(m2) & ~0x60u) | ctag);
     };
     int stage = 0;
     if constexpr (TAIL) {
@@ -628,6 +641,12 @@ __device__ __forceinline__ unsigned f2key(float v) {
 }
 __device__ __forceinline__ float key2f(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
+// Run-time consistency counters (dvq_pointnet_fault_counters): [0] tile records the trunk kernel marked suspect (a ring value whose
+// chunk tag is not the published chunk's: stale or missing input of the merge), [1] channels whose exact maximum lies outside the
+// interval the tile records promise (max_t (top_t - E_t) <= max - w.c <= max_t (top_t + E_t)).  Either way the channel is evaluated
+// over ALL the points concerned, so the feature is right; a non-zero counter says the filter's bookkeeping was not.
+__device__ unsigned long long g_pn_faults[2];
+
 // One workgroup per sample, 16 groups of 16 lanes.
 //   phase A (one thread per channel): best lower bound over the tiles; every kept score whose upper bound reaches it
 //           becomes a candidate point of the channel (table of 4 per channel, the rest in a list); flagged 16-point groups of tiles
@@ -643,7 +662,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
                                                        const float* __restrict__ h2buf,
                                                        int N, int Npad, const float* __restrict__ w3, const float* __restrict__ b3,
                                                        const float* __restrict__ wnorm, const float* __restrict__ rnorm,
-                                                       const unsigned* __restrict__ tstat, int relu, int exhaustive,
+                                                       const unsigned* __restrict__ tstat, const float* __restrict__ cbuf, int relu, int exhaustive,
                                                        int pair_cap, int fb_cap, float* __restrict__ feat, long ld_feat,
                                                        unsigned long long* __restrict__ stats, int abl_arg) {
     const int abl = DVQ_DIAG_ON ? abl_arg : 0;
@@ -653,7 +672,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
     __shared__ int fb_list[FB_CAP];
     __shared__ short all_list[1024];
     __shared__ int pair_count, fb_count, all_count;
-    __shared__ float fb_part[16];
+    __shared__ float fb_part[4][16];
     __shared__ float hm[MAX_TILES], dm[MAX_TILES], rd[MAX_TILES];
     __shared__ unsigned best_k[1024];
     __shared__ int pcnt[1024];                             // pairs per point -> first slot of the point -> fill cursor
@@ -661,6 +680,8 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
     __shared__ int wave_tot[4];
     const int tid = threadIdx.x, g = tid >> 4, j = tid & 15;
     const long b = blockIdx.x;
+    float* wcs = reinterpret_cast<float*>(pcnt);           // w_n . c per channel (consistency check): pcnt is dead once the pairs are sorted
+    const f32x4 cen_a = *reinterpret_cast<const f32x4*>(cbuf + b * 128 + 8 * j), cen_b = *reinterpret_cast<const f32x4*>(cbuf + b * 128 + 8 * j + 4);
     if (tid == 0) { pair_count = 0; fb_count = 0; all_count = 0; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) pcnt[tid + 256 * i] = 0;
@@ -675,8 +696,12 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
     const f32x4* pt = part + b * (long)tiles * 1024;
     const qf32x2* pt2 = part2 + b * (long)tiles * 1024;     // the fourth and fifth id-carrying scores: read only where the third is in range
     // ---- phase A
-    unsigned n_single = 0, n_multi = 0, n_cand = 0, n_wave = 0;
-    for (int n = tid; n < 1024; n += 256) {
+    unsigned n_single = 0, n_multi = 0, n_cand = 0, n_wave = 0, n_suspect = 0;
+    float lo_n[4], hi_n[4];                                 // the interval the records promise for (max - w.c) of channels tid + 256 i; lo > hi: not checked
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+        const int n = tid + 256 * ci;
+        lo_n[ci] = 1.f; hi_n[ci] = 0.f;
         best_k[n] = f2key(NEG_BIG);
         const float wn = wnorm[n], rn = rnorm[n];
         float lb, e_all;
@@ -686,15 +711,18 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
                     f3 = pt[min(3, tiles - 1) * 1024 + n];
         // a non-finite bound or top score in ANY tile sends the channel to the "everything" path (fmaxf drops a NaN: tested apart)
         bool nonfinite = false;
+        float ub;
         auto fold = [&](float e, float top) {
             nonfinite = nonfinite || !(e < 3.0e38f) || !(fabsf(top) < 3.0e38f);
             e_all = fmaxf(e_all, e);
             lb = fmaxf(lb, top - e);
+            ub = fmaxf(ub, top + e);
         };
         {
             const float e0 = bound(0);
             e_all = e0;
             lb = f0[0] - e0;
+            ub = f0[0] + e0;
             nonfinite = !(e0 < 3.0e38f) || !(fabsf(f0[0]) < 3.0e38f);
             if (tiles > 1) fold(bound(1), f1[0]);
             if (tiles > 2) fold(bound(2), f2[0]);
@@ -716,9 +744,14 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
             cand_n[n] = 0;
             continue;
         }
+        lo_n[ci] = lb; hi_n[ci] = ub;
         auto consider = [&](int t, const f32x4& q) {
             const float et = bound(t);
-            if (!(q[0] + et >= lb)) return;                 // the tile's largest score is out of range: so is the rest of it
+            const unsigned suspect = (__float_as_uint(q[3]) >> 16) & 1u;   // the trunk kernel did not trust its own merge: it flagged every group
+            n_suspect += suspect;
+            // the tile's largest score is out of range: so is the rest of it -- unless the record is suspect: then its scores prove
+            // nothing about the tile and all its points are evaluated (a bogus top score that RAISES lb is caught by the check below)
+            if (!suspect && !(q[0] + et >= lb)) return;
             unsigned flags = __float_as_uint(q[3]) & 0xFFFFu;   // one bit per 16-point group: 4 wave + 2 point block + lane half
             auto take = [&](float v) {                       // a kept score in range: its point becomes a candidate of the channel
                 int p = point_of_slot(t, slot_of_id(__float_as_uint(v) & 255u), deal);
@@ -771,6 +804,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
             if (t0 + 3 < tiles) consider(t0 + 3, q3);
         }
         cand_n[n] = whole ? 0 : (unsigned char)min(cands, 4);
+        if (whole) { lo_n[ci] = 1.f; hi_n[ci] = 0.f; }      // evaluated in full below: nothing to check
         n_single += cands == 1;
         n_multi += cands != 1;
         n_cand += cands;
@@ -837,7 +871,8 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float v = exact_dot_regs(w0[u], w1[u], ha[u], hb[u]);
-                if (j == 0 && i + u < i1) atomicMax(&best_k[nn[u]], f2key(v));
+                const float wc = exact_dot_regs(w0[u], w1[u], cen_a, cen_b);     // the centre term of this channel (check below)
+                if (j == 0 && i + u < i1) { atomicMax(&best_k[nn[u]], f2key(v)); wcs[nn[u]] = wc; }
             }
         }
     }
@@ -862,6 +897,8 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
             const int n = n0 + 16 * u;
             if (cn[u] == 0) continue;
             float best = exact_dot_regs(w0[u], w1[u], ha[u], hb[u]);
+            const float wc = exact_dot_regs(w0[u], w1[u], cen_a, cen_b);
+            if (j == 0) wcs[n] = wc;
             if (cn[u] > 1) {
                 f32x4 xa[3], xb[3];
 #pragma unroll
@@ -911,23 +948,62 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
         if (j == 0) atomicMax(&best_k[n], f2key(best));
     }
     __syncthreads();
-    // ---- phase C: everything (NaN-propagating maximum, torch.max semantics)
-    const int nall = all_count;
-    for (int i = 0; i < nall; ++i) {
-        const int n = all_list[i];
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(w3 + n * 128 + 8 * j);
-        const f32x4 w1 = *reinterpret_cast<const f32x4*>(w3 + n * 128 + 8 * j + 4);
-        float best = NEG_BIG;
-        for (int p = g; p < N; p += 16) best = max_nan(best, exact_dot(w0, w1, h2 + (long)p * 128, j));
-        if (j == 0) fb_part[g] = best;
-        __syncthreads();
-        if (tid == 0) {
-            float v = fb_part[0];
-            for (int k = 1; k < 16; ++k) v = max_nan(v, fb_part[k]);
-            best_k[n] = (v != v) ? 0xffffffffu : f2key(v);       // NaN: the largest key, decoded below
+    // ---- phase C: everything (NaN-propagating maximum, torch.max semantics): the channels on all_list over ALL points, four channels
+    // per sweep of the rows (a row's slice is loaded once for the four)
+    auto eval_all_list = [&](int count) {
+        for (int i = 0; i < count; i += 4) {
+            f32x4 w0[4], w1[4];
+            float best[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int n = all_list[min(i + u, count - 1)];
+                w0[u] = *reinterpret_cast<const f32x4*>(w3 + n * 128 + 8 * j);
+                w1[u] = *reinterpret_cast<const f32x4*>(w3 + n * 128 + 8 * j + 4);
+                best[u] = NEG_BIG;
+            }
+            for (int p = g; p < N; p += 16) {
+                const float* hr = h2 + (long)p * 128 + 8 * j;
+                const f32x4 ha = *reinterpret_cast<const f32x4*>(hr), hb = *reinterpret_cast<const f32x4*>(hr + 4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) best[u] = max_nan(best[u], exact_dot_regs(w0[u], w1[u], ha, hb));
+            }
+            if (j == 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) fb_part[u][g] = best[u];
+            }
+            __syncthreads();
+            if (tid < 4 && i + tid < count) {
+                float v = fb_part[tid][0];
+                for (int k = 1; k < 16; ++k) v = max_nan(v, fb_part[tid][k]);
+                best_k[all_list[i + tid]] = (v != v) ? 0xffffffffu : f2key(v);       // NaN: the largest key, decoded below
+            }
+            __syncthreads();
         }
-        __syncthreads();
+    };
+    eval_all_list(all_count);
+    // ---- consistency: the exact maximum of a channel must lie where its tile records said it would.  |approx + w.c - exact| <= E_t
+    // for every point of tile t, so  max_t (top_t - E_t) <= max - w.c <= max_t (top_t + E_t).  A maximum outside that interval means a
+    // record did not describe its tile (a wrong score or id; a missing input that was the tile's best shows up in the trunk kernel's
+    // own tag check instead): such a channel is evaluated over all points, and counted.
+    __syncthreads();                                       // best_k / wcs complete; all_list free again
+    if (tid == 0) all_count = 0;
+    __syncthreads();
+    unsigned n_bad = 0;
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+        const int n = tid + 256 * ci;
+        if (!(lo_n[ci] <= hi_n[ci])) continue;
+        const float v = key2f(best_k[n]), wc = wcs[n];
+        const float x = v - wc, slack = 4.0e-7f * (fabsf(v) + fabsf(wc));   // the subtraction's own rounding
+        if (!(x >= lo_n[ci] - slack && x <= hi_n[ci] + slack)) {
+            all_list[atomicAdd(&all_count, 1)] = (short)n;
+            ++n_bad;
+        }
     }
+    __syncthreads();
+    eval_all_list(all_count);
+    if (n_suspect) atomicAdd(&g_pn_faults[0], (unsigned long long)n_suspect);
+    if (n_bad) atomicAdd(&g_pn_faults[1], (unsigned long long)n_bad);
     for (int n = tid; n < 1024; n += 256) {
         const unsigned k = best_k[n];
         const float v = (k == 0xffffffffu ? __builtin_nanf("") : key2f(k)) + b3[n];
@@ -1123,7 +1199,8 @@ int dvq_launch_pn_filter_front(const float* pc, int C, int N, int Npad, long B, 
 }
 
 int dvq_launch_pn_filter_back(int N, int Npad, long B, const void* w3f, const float* w3, const float* b3, int relu, const float* h2buf,
-                              const void* part, const unsigned* tstat, float* feat, long ld_feat, unsigned long long* stats, hipStream_t st) {
+                              const void* part, const unsigned* tstat, const float* cbuf, float* feat, long ld_feat, unsigned long long* stats,
+                              hipStream_t st) {
     int tiles, deal;
     DVQ_PROPAGATE(pn_filter_geometry(N, &tiles, &deal));
     const qf32x2* part2 = reinterpret_cast<const qf32x2*>((const char*)part + (size_t)B * tiles * 1024 * 16);
@@ -1139,7 +1216,7 @@ int dvq_launch_pn_filter_back(int N, int Npad, long B, const void* w3f, const fl
         DVQ_PROF("pn_exact", 2.0 * (double)B * 1024 * 128, (double)B * (tiles * 16384.0 + 1024.0 * 512 + 4096), st);
         DVQ_LAUNCH(pn_exact_kernel, dim3((unsigned)B), dim3(256), 0, st, (const f32x4*)part, part2, tiles, deal, h2buf, N, Npad, w3, b3,
                    reinterpret_cast<const float*>((const char*)w3f + 1024 * 256 + 4096),
-                   reinterpret_cast<const float*>((const char*)w3f + 1024 * 256 + 8192), tstat, relu, exhaustive, pair_cap, fb_cap,
+                   reinterpret_cast<const float*>((const char*)w3f + 1024 * 256 + 8192), tstat, cbuf, relu, exhaustive, pair_cap, fb_cap,
                    feat, ld_feat, stats, abl);
     }
     DVQ_CHECK_LAUNCH("pn_exact");
@@ -1173,5 +1250,21 @@ int dvq_launch_pn_trunk_filter(const float* pc, int C, int N, int Npad, long B, 
                                int relu, float* h2buf, void* part, unsigned* tstat, float* cbuf, float* feat, long ld_feat,
                                unsigned long long* stats, hipStream_t st) {
     DVQ_PROPAGATE(dvq_launch_pn_filter_front(pc, C, N, Npad, B, trans, W1, b1, W2, W2p, b2, w3f, h2buf, part, tstat, cbuf, stats, st));
-    return dvq_launch_pn_filter_back(N, Npad, B, w3f, w3, b3, relu, h2buf, part, tstat, feat, ld_feat, stats, st);
+    return dvq_launch_pn_filter_back(N, Npad, B, w3f, w3, b3, relu, h2buf, part, tstat, cbuf, feat, ld_feat, stats, st);
+}
+
+// host side of the consistency counters: [0] suspect tile records, [1] channels outside their records' interval (per device)
+int dvq_pn_fault_counters(unsigned long long* out2, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_pn_faults), 16) != hipSuccess) {
+        dvq_set_error("pointnet_fault_counters: reading the device counters failed");
+        return DVQ_ELAUNCH;
+    }
+    if (reset) {
+        const unsigned long long z[2] = {0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_pn_faults), z, 16) != hipSuccess) {
+            dvq_set_error("pointnet_fault_counters: resetting the device counters failed");
+            return DVQ_ELAUNCH;
+        }
+    }
+    return DVQ_OK;
 }

@@ -379,6 +379,16 @@ def pointnet_encode(packed, pc: Tensor, out: Optional[Tensor] = None, want_trans
     return out, trans
 
 
+def pointnet_fault_counters(reset: bool = False) -> Tuple[int, int]:
+    """(suspect tile records, channels outside their records' interval) the filtered PointNet trunk has counted on the current device
+    since the last reset -- its run-time consistency checks (dvq_pointnet_fault_counters).  Both are re-evaluated in full when they
+    happen, so the features stay right; anything but (0, 0) means the filter's bookkeeping failed and should be reported."""
+    lib = _lib.load()
+    out = (C.c_uint64 * 2)()
+    check(lib.dvq_pointnet_fault_counters(out, 1 if reset else 0), "dvq_pointnet_fault_counters")
+    return int(out[0]), int(out[1])
+
+
 # ------------------------------------------------------------------------------------------ PixelCNN
 def pixelcnn_sample(packed, label: Tensor, noise: Tensor, return_logits: bool = False, err: Optional[Tensor] = None, _retry: bool = False):
     """label [B] int64, noise [B,9,n_in] Exp(1) -> codes [B,3,3] int64 (+ logits [B,9,n_in]).

@@ -170,6 +170,11 @@ typedef struct {
 
 /* Filter image of one conv3 weight matrix w3 [1024,128] (device pointers): fp16 rows scaled by a per-row power of two in
  * the k order the trunk kernel consumes, the inverse scales and the row norms.  dvq_pointnet_filter_bytes() bytes. */
+/* Run-time consistency counters of the filtered trunk on the current device (v8): out[0] = tile records the trunk kernel marked
+ * suspect (an input of its merge was stale), out[1] = channels whose exact maximum lay outside the interval their tile records
+ * promised.  Both kinds are re-evaluated over all the points concerned (the features stay right); a non-zero count means the
+ * filter's bookkeeping failed and should be reported.  Synchronises the device.  reset != 0: zero them after reading. */
+int dvq_pointnet_fault_counters(uint64_t* out /* [2] */, int reset);
 size_t dvq_pointnet_filter_bytes(void);
 int dvq_pointnet_pack_filter(const float* w3, void* image, dvq_stream_t stream);
 

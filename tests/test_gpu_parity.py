@@ -1047,23 +1047,37 @@ def test_gen_range_fallback_regenerates_only_the_rows_that_need_it():
     assert torch.equal(r[keep], rc[keep]) and torch.equal(p[keep], pc[keep]), "rows inside the range must keep their bits"
     rb, pb = _with_env("DVQ_GEMM", "bf16x3", lambda: net.gen(obj, seed=5, row0=300, stream_id=2))
     assert torch.equal(r[bad], rb[bad]) and torch.equal(p[bad], pb[bad]), "the regenerated row must be the six-product result"
-    # the cost at the benchmark's batch: one bad row in 65 536
-    big = clean[torch.arange(65536, device=DEV) % B].contiguous()
-    net.gen(big[:512], seed=6)                                                   # images of both kinds exist from here on
-    def timed(x):
+    # the cost at the benchmark's batch: ONE row of 65 536 out of range.  (Not through a scaled cloud: such a cloud is also a
+    # degenerate input of the PointNet filter -- most of its points tie -- and costs milliseconds by itself.)  One entry of the first
+    # hand codebook is made huge and the prior's noise is set so that exactly one row draws it: that row's decoder input overflows.
+    Bb, row, j = 65536, 40000, 77
+    big = clean[torch.arange(Bb, device=DEV) % B].contiguous()
+    q = torch.empty(Bb, 9, 512, device=DEV).exponential_()
+    q[:, 1, j] = 1.0e30                                                          # grid position (0, 1) -> vqvae0 (gen_net.CODE_SLOTS): never code j ...
+    E0 = net.vqvae0.vector_quantization.embedding.weight
+    saved = E0[j].clone()
+
+    def timed(x, noise):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        net.gen(x, seed=6, row0=0, stream_id=1)
+        out = net.gen(x, noise=noise, return_aux=True)
         torch.cuda.synchronize()
-        return time.perf_counter() - t0
-    timed(big)
-    t_clean = min(timed(big), timed(big))
-    big[40000] *= scale
-    timed(big)
-    n1 = net.range_fallback_rows
-    t_bad = min(timed(big), timed(big))
-    assert net.range_fallback_rows == n1 + 2
-    assert t_bad <= 1.05 * t_clean + 0.005, f"one out-of-range row: {t_bad * 1e3:.1f} ms against {t_clean * 1e3:.1f} ms for a clean step"
+        return time.perf_counter() - t0, out
+    try:
+        with torch.no_grad():
+            E0[j] = 3.0e6
+        timed(big, q)
+        t_clean = min(timed(big, q)[0], timed(big, q)[0])
+        n1 = net.range_fallback_rows
+        q[row, 1, j] = 1.0e-30                                                   # ... except this row
+        timed(big, q)                                                            # (first fallback: the bf16x3 images are built)
+        t_bad, (rr, pp, aux_b) = min((timed(big, q) for _ in range(2)), key=lambda v: v[0])
+        assert net.range_fallback_rows == n1 + 3 and aux_b["fallback_rows"].tolist() == [row]
+        assert int(aux_b["codes"].view(Bb, 9)[row, 1]) == j and bool(torch.isfinite(rr).all()) and bool(torch.isfinite(pp).all())
+    finally:
+        with torch.no_grad():
+            E0[j] = saved
+    assert t_bad <= 1.05 * t_clean + 0.002, f"one out-of-range row: {t_bad * 1e3:.1f} ms against {t_clean * 1e3:.1f} ms for a clean step"
 
 
 def test_every_entry_point_survives_the_fp16_range():
@@ -1153,6 +1167,62 @@ def test_checkpoint_files_load_like_the_reference(tmp_path):
     torch.save(prior_u, pck)
     with pytest.raises(RuntimeError, match="out of range"):
         generate.main("ho3d", argv + ["--n_embeddings", "128"])
+
+
+_RUNTIME_CHECK_CHILD = r"""
+import os, sys, json, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import dvqvae_amd
+from dvqvae_amd import synth, ops, _lib
+from dvqvae_amd.network.pointnet_encoder import PointNetEncoder
+from util import load_synth
+dev = torch.device("cuda:0")
+net = PointNetEncoder(channel=4); load_synth(net, 3); net = net.eval().to(dev)
+x = synth.synthetic_clouds(48, 1024, seed=5).to(dev)
+def run(**env):
+    for k, v in env.items(): os.environ[k] = v
+    _lib.load().dvq_reload_env()
+    ops.pointnet_fault_counters(reset=True)
+    f, tr, _ = net(x)
+    torch.cuda.synchronize()
+    c = ops.pointnet_fault_counters(reset=True)
+    for k in env: del os.environ[k]
+    _lib.load().dvq_reload_env()
+    return f, tr, c
+f_ref, tr_ref, c_ref = run(DVQ_PN_EXHAUSTIVE="1")
+f, tr, c = run()
+print(json.dumps({"equal": bool(torch.equal(f, f_ref) and torch.equal(tr, tr_ref)), "counters": c, "counters_exhaustive": c_ref}))
+"""
+
+
+def test_pointnet_runtime_checks():
+    """The filtered trunk's run-time consistency checks, with faults INJECTED (diagnostics build of the library, child processes):
+    (a) a tile record whose top score lies about its tile -> pn_exact_kernel finds the exact maximum outside the interval the
+    records promise, evaluates the channel over all points and counts it; (b) a hand-over of top scores that does not happen (the
+    ring slot keeps an older chunk's values) -> the publishing wave sees the wrong chunk tag, flags the whole tile and marks the
+    record suspect.  Both times the features equal the exhaustive evaluation bit for bit and the counters are not zero; without
+    an injected fault both counters stay zero."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    diag = os.path.join(root, "tools", "diag", "libdvq_hip_diag.so")
+    if not os.path.exists(diag):
+        r = subprocess.run(["make", "-C", os.path.join(root, "d-vqvae_amd", "csrc"), "-j", "8", "diag"], capture_output=True, text=True)
+        assert r.returncode == 0 and os.path.exists(diag), r.stdout[-2000:] + r.stderr[-2000:]
+
+    def child(abl):
+        env = dict(os.environ, DVQ_DIAG_LIB="1", DVQ_PN_ABL=str(abl))
+        r = subprocess.run([sys.executable, "-c", _RUNTIME_CHECK_CHILD, root], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    clean = child(0)
+    assert clean["equal"] and clean["counters"] == [0, 0], clean
+    lie = child(32768)
+    assert lie["equal"], "a lying record must not change a feature"
+    assert lie["counters"][1] > 0, lie
+    lost = child(65536)
+    assert lost["equal"], "a lost hand-over must not change a feature"
+    assert lost["counters"][0] > 0, lost
+    assert ops.pointnet_fault_counters() == (0, 0), "the product library must not have seen an inconsistency in this test session"
 
 
 def test_gen_sharded_equals_unsharded_with_device_noise():
