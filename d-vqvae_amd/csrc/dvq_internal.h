@@ -215,7 +215,7 @@ struct DvqKnobs {
     int pn_caps[2];       // candidate-list capacities (tests shrink them to reach the overflow paths); <= 0: default
     long pn_chunk;        // samples per PointNet launch (<= 0: at most 4 096, at least four launches per pass; DVQ_PN_CHUNK)
     int pn_streams;       // 1 (default): the exact stage / STN FCs of a launch on a second stream beside the next launch's trunk kernel (DVQ_PN_STREAMS=0: one stream)
-    int pn_slots;         // scratch sets the launches rotate through (<= 0: 3; DVQ_PN_SLOTS)
+    int pn_slots;         // scratch sets the launches rotate through (<= 0: 2; DVQ_PN_SLOTS)
     int pn_stats;
     long pixelcnn_chunk;  // <= 0: default
     int pixelcnn_tables;  // 1 (default): what depends on the class label only is evaluated once per class (DVQ_PIXELCNN_TABLES=0: per row)

@@ -242,6 +242,7 @@ int dvq_launch_gemm(const GemmParams& p, GemmEpilogue epi, hipStream_t stream) {
             if (split) return dvq_launch_gemm_bf16x3(p, epi, stream);
             return launch<EPI_GATE>(p, stream);
         case EPI_ARGMIN:
+        case EPI_STATE:                                   // (fp16-plane kernels only: rejected above)
             break;
         case EPI_COLMAX:
             DVQ_REQUIRE(p.partial && p.rows_per_group > 0 && p.rows_per_group % BM == 0 && p.valid_rows > 0,

@@ -133,12 +133,14 @@ __device__ __forceinline__ void chain_pair_x8(const float* __restrict__ zr, cons
         x[u] = active ? *reinterpret_cast<const f32x4*>(zr + 32 * q + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
         y[u] = active ? *reinterpret_cast<const f32x4*>(er + 32 * q + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // The accumulator travels lane q - 1 -> lane q by DPP (row_shr:1: one vector instruction; the ds_bpermute broadcasts this replaced
+    // were sixteen LDS round trips per pair, about a microsecond of the kernel's tail).  Lane q's value counts in round q only, so
+    // what lane 0 of a group receives from the neighbouring group is never used.  The result is LANE 7's (q == 7): the caller reads it there.
     float a = 0.f, b = 0.f;
-    const int lane = threadIdx.x & 63, base = lane & ~7;
 #pragma unroll
     for (int round = 0; round < 8; ++round) {
-        const float a_in = round ? __shfl(a, base + round - 1) : 0.f;
-        const float b_in = round ? __shfl(b, base + round - 1) : 0.f;
+        const float a_in = round ? dpp_f<0x111>(a) : 0.f;
+        const float b_in = round ? dpp_f<0x111>(b) : 0.f;
         float ta = a_in, tb = b_in;
 #pragma unroll
         for (int u = 0; u < 8; ++u)
@@ -149,8 +151,8 @@ __device__ __forceinline__ void chain_pair_x8(const float* __restrict__ zr, cons
             }
         if (q == round) { a = ta; b = tb; }
     }
-    zz = __shfl(a, base + 7);
-    dot = __shfl(b, base + 7);
+    zz = a;                                                     // valid in lane q == 7
+    dot = b;
 }
 __device__ __forceinline__ void chain_pair(const float* __restrict__ zr, const float* __restrict__ er, float& zz, float& dot) {
     float a = 0.f, b = 0.f;
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(NT) void vq_stream16_kernel(const float* __restrict
             const int rowslot = (int)(pr >> 16), k = (int)(pr & 0xffffu);
             float zz, dot;
             chain_pair_x8(z + grow_of(rowslot) * D, E + (long)k * D, q, act, zz, dot);
-            if (act && q == 0) {
+            if (act && q == 7) {                                  // the chain ends in the group's last lane
                 const float tsum = zz + ee_g[k];
                 atomicMin(&s_res[rowslot], order_key(tsum - 2.0f * dot, k));
             }
