@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
             flags = flags + flags + (unsigned)(u >= thr);
         }
         if (suspect) flags = 0x1FFFFu;
-        if (DVQ_DIAG_ON && (abl & 32768) && c == 5 && lane == 7) c1 = fabsf(c1) * 1.0e3f + 1.0f;   // diagnostics: a record that lies about its tile
+        if ((abl & 32768) && c == 5 && lane == 7) c1 = fabsf(c1) * 1.0e3f + 1.0f;   // diagnostics: a record that lies about its tile
         if (live) {
             part[rec * 1024 + 64 * c + lane] = f32x4{c1, c2, c3, __uint_as_float(flags)};
             part2[rec * 1024 + 64 * c + lane] = qf32x2{c4, c5};
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     // every lane hands its own sorted pair of a block over (16 points of one channel); the publishing wave merges the sixteen groups
     // of a (tile, channel) -- one lane per channel there
     auto finish = [&](int c, int jn, int pb, float m1, float m2) {
-        if (DVQ_DIAG_ON && (abl & 65536) && c == 9 && wave == 2 && jn == 0) return;   // diagnostics: a hand-over that does not happen
+        if ((abl & 65536) && c == 9 && wave == 2 && jn == 0) return;   // diagnostics: a hand-over that does not happen
         float* dst = tb + (c & 3) * F_SLOT + ((wave * 2 + pb) * 2 + h) * 128 + 32 * jn + r;
         const unsigned ctag = (unsigned)(((c >> 2) & 3) << 5);   // which of the four chunks that share this ring slot (checked by publish())
         dst[0] = __uint_as_float((__float_as_uint(m1) & ~0x60u) | ctag);

@@ -31,7 +31,7 @@ def test_graft_entry_build_passes():
 def test_workspace_queries_need_no_gpu():
     lib = _lib.load()
     assert lib.dvq_vq_argmin_workspace_bytes(65536, 512) >= 65536 * 4
-    assert lib.dvq_pointnet_workspace_bytes(8, 1024) > 8 * 1024 * 192 * 4
+    assert lib.dvq_pointnet_workspace_bytes(8, 1024) > 8 * 1024 * 128 * 4      # the conv2 rows of the filtered trunk, at least
     assert lib.dvq_pointnet_workspace_bytes(0, 1024) > 0
 
 
