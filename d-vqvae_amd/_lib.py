@@ -98,7 +98,7 @@ SIGNATURES = {
     "dvq_pointnet_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "dvq_pointnet_fault_counters": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
     "dvq_pointnet_filter_bytes": (C.c_size_t, []),
-    "dvq_pointnet_pack_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dvq_pointnet_pack_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dvq_pointnet_encode": (C.c_int, [C.POINTER(PointnetWeights), c_f32p, C.c_int64, C.c_int, c_f32p, C.c_int64, c_f32p,
                                       C.c_void_p, C.c_size_t, c_stream]),
     "dvq_pixelcnn_tables_bytes": (C.c_size_t, [C.POINTER(PixelcnnWeights)]),

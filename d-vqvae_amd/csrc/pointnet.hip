@@ -16,7 +16,7 @@ int dvq_launch_pn_trunk(const float* pc, int C, int N, long B, const float* tran
                         hipStream_t st);
 // pointnet_filter.hip
 size_t dvq_pn_filter_image_bytes();
-int dvq_launch_pn_filter_pack(const float* w3, void* image, hipStream_t st);
+int dvq_launch_pn_filter_pack(const float* w2, const float* w3, void* image, hipStream_t st);
 int dvq_launch_pn_trunk_filter(const float* pc, int C, int N, int Npad, long B, const float* trans, const float* W1, const float* b1,
                                const float* W2, const uint16_t* W2p, const float* b2, const void* w3f, const float* w3, const float* b3,
                                int relu, float* h2buf, void* part, unsigned* tstat, float* cbuf, float* feat, long ld_feat,
@@ -343,9 +343,9 @@ extern "C" int dvq_pointnet_fault_counters(uint64_t* out, int reset) {
     return DVQ_OK;
 }
 
-extern "C" int dvq_pointnet_pack_filter(const float* w3, void* image, dvq_stream_t stream) {
-    DVQ_REQUIRE(w3 && image && dvq_aligned16(image), "pointnet_pack_filter: null/unaligned pointer");
-    return dvq_launch_pn_filter_pack(w3, image, (hipStream_t)stream);
+extern "C" int dvq_pointnet_pack_filter(const float* w2, const float* w3, void* image, dvq_stream_t stream) {
+    DVQ_REQUIRE(w2 && w3 && image && dvq_aligned16(image), "pointnet_pack_filter: null/unaligned pointer");
+    return dvq_launch_pn_filter_pack(w2, w3, image, (hipStream_t)stream);
 }
 
 // =====================================================================================================================

@@ -42,19 +42,24 @@ constexpr float DELTA = 1.0e-6f;
 constexpr float NEG_BIG = -3.0e38f;
 constexpr int MAX_TILES = 64;                             // filtered trunk: N <= 16384 points
 
-constexpr int F_STAGE2 = 3 * 64 * 128;                    // conv2: one half of W2's planes (3 x 64 rows x 128 B)
+constexpr int F_STAGE2 = 2 * 64 * 128;                    // conv2: one half of W2's two fp16 planes (2 x 64 rows x 128 B)
+// the filter image of a trunk (dvq_pointnet_pack_filter): conv3 [1024][128] fp16 | 1 / scale [1024] | |w_n| [1024] | |w_n - image| [1024]
+// | conv2 as two fp16 planes [2][128][64] of w * 2^t_n (the second: the remainder * 2^11) | 2^-t_n [128]
+constexpr int IMG_OFF_TI = 1024 * 256, IMG_OFF_WN = IMG_OFF_TI + 4096, IMG_OFF_RN = IMG_OFF_WN + 4096;
+constexpr int IMG_OFF_W2 = IMG_OFF_RN + 4096, IMG_OFF_K2 = IMG_OFF_W2 + 2 * 128 * 128, IMG_BYTES = IMG_OFF_K2 + 512;
 constexpr int F_STAGE3 = 64 * 256;                        // conv3: 64 channels x 128 k fp16
 constexpr int F_OFF_TB = 2 * F_STAGE3;                    // conv3 phase: record ring [4 chunks][4 waves][2 point blocks][2 halves][2][64] fp32 (32 KiB) behind the two W3 stages
 constexpr int F_SLOT = 4 * 2 * 2 * 2 * 64;                // floats per chunk slot of the ring
 constexpr int F_OFF_W1 = F_OFF_TB + 8 * 4 * 4 * 64 * 4;   // [64][4] fp32
 constexpr int F_OFF_B1 = F_OFF_W1 + 64 * 4 * 4;           // [64]
 constexpr int F_OFF_B2 = F_OFF_B1 + 64 * 4;               // [128]
-constexpr int F_OFF_SC = F_OFF_B2 + 128 * 4;              // [4] 1 / (wave scale)
+constexpr int F_OFF_K2 = F_OFF_B2 + 128 * 4;              // [128] 2^-t_n of conv2's weight rows
+constexpr int F_OFF_SC = F_OFF_K2 + 128 * 4;              // [4] 1 / (wave scale)
 constexpr int F_OFF_TI = F_OFF_SC + 64;                   // [1024] 1 / (channel scale)
 constexpr int F_OFF_CS = F_OFF_TI + 4096;                 // [128] centre of the sample
 constexpr int F_OFF_WS = F_OFF_CS + 512;                  // [3][4] per-wave |h|max, |d|max, |rd|max
 constexpr int F_OFF_E2 = F_OFF_WS + 64;                   // [1024] 2 E of the tile per channel ([4][1024] in the tail kernel: a tile per wave)
-constexpr int F_LDS = F_OFF_E2 + 4096;                    // 76 160 B -> 2 workgroups per CU
+constexpr int F_LDS = F_OFF_E2 + 4096;                    // 76 672 B -> 2 workgroups per CU
 constexpr int F_LDS_TAIL = F_LDS + 3 * 4096 + 4 * 512;    // tail kernel: three more e2 tables, one centre per wave (its own sample) behind them
 static_assert(F_OFF_W1 >= 2 * F_STAGE2, "the conv3 stages and the triple buffer cover the W2 region");
 
@@ -69,28 +74,31 @@ __device__ __forceinline__ float mix_diff(unsigned hp, float x) {
 __device__ __forceinline__ float max_nc(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, 3.0e38f); }
 __device__ __forceinline__ float min_nc(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, NEG_BIG); }
 
-__device__ __forceinline__ void q_split_pair(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
-    const unsigned a0 = __float_as_uint(x0) & 0xffff0000u, a1 = __float_as_uint(x1) & 0xffff0000u;
-    const float r0 = x0 - __uint_as_float(a0), r1 = x1 - __uint_as_float(a1);
-    const unsigned b0 = __float_as_uint(r0) & 0xffff0000u, b1 = __float_as_uint(r1) & 0xffff0000u;
-    const float s0 = r0 - __uint_as_float(b0), s1 = r1 - __uint_as_float(b1);
-    p1 = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
-    p2 = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
-    p3 = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
-}
-__device__ __forceinline__ void q_split8(const float (&v)[8], qbf16x8 (&out)[3]) {
-    unsigned p[3][4];
+// Eight values x (already scaled into fp16's range) -> the two fp16 pieces of the three-product split (csrc/gemm_f16x2.hip):
+// p1 = fp16(x), p2 = fp16((x - p1) * 2^11), the second ONE rounding of the exact fma(p1, -2048, 2048 x) (v_fma_mixlo / mixhi_f16).
+__device__ __forceinline__ void q_split2(const float (&v)[8], qf16x8& p1, qf16x8& p2) {
+    unsigned hb[4], lb[4];
+    const float m2048 = -2048.0f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) q_split_pair(v[2 * q], v[2 * q + 1], p[0][q], p[1][q], p[2][q]);
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) out[pl] = __builtin_bit_cast(qbf16x8, uint4{p[pl][0], p[pl][1], p[pl][2], p[pl][3]});
+    for (int j = 0; j < 4; ++j) {
+        const float a0 = v[2 * j], a1 = v[2 * j + 1];
+        qf32x2 pr;
+        pr[0] = a0; pr[1] = a1;
+        hb[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, qf16x2));                // v_cvt_pk_f16_f32, round to nearest even
+        const float t0 = a0 * 2048.0f, t1 = a1 * 2048.0f;
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lb[j]) : "v"(hb[j]), "v"(m2048), "v"(t0));
+        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lb[j]) : "v"(hb[j]), "v"(m2048), "v"(t1));
+    }
+    p1 = __builtin_bit_cast(qf16x8, uint4{hb[0], hb[1], hb[2], hb[3]});
+    p2 = __builtin_bit_cast(qf16x8, uint4{lb[0], lb[1], lb[2], lb[3]});
 }
 
-// W2 planes: same image and DMA pattern as pn_trunk_kernel (rows of 128 B, chunk c of row r at c ^ ((r >> 1) & 7))
+// W2 planes [2][128][64] fp16: rows of 128 B, chunk c of row r lands at c ^ ((r >> 1) & 7); one half = 64 rows of both planes =
+// sixteen 1 KiB DMA pieces, four per wave
 __device__ __forceinline__ void w2_issue(const uint16_t* __restrict__ planes, int row0, char* stage, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int id = wave * 6 + i;
+    for (int i = 0; i < 4; ++i) {
+        const int id = wave * 4 + i;
         const int pl = id >> 3, rb = id & 7;
         const int row = rb * 8 + (lane >> 3);
         const uint16_t* src = planes + pl * (128L * 64) + (long)(row0 + row) * 64 + 8 * ((lane & 7) ^ ((row >> 1) & 7));
@@ -98,8 +106,8 @@ __device__ __forceinline__ void w2_issue(const uint16_t* __restrict__ planes, in
                                          (__attribute__((address_space(3))) void*)(stage + (pl * 64 + rb * 8) * 128), 16, 0, 0);
     }
 }
-__device__ __forceinline__ qbf16x8 w2_frag(const char* stage, int pl, int row, int chunk) {
-    return *reinterpret_cast<const qbf16x8*>(stage + (pl * 64 + row) * 128 + 16 * (chunk ^ ((row >> 1) & 7)));
+__device__ __forceinline__ qf16x8 w2_frag(const char* stage, int pl, int row, int chunk) {
+    return *reinterpret_cast<const qf16x8*>(stage + (pl * 64 + row) * 128 + 16 * (chunk ^ ((row >> 1) & 7)));
 }
 
 // W3 filter image: [1024][128] fp16, rows of 256 B = 16 chunks; in LDS chunk c of row r sits at chunk c ^ (r & 15).
@@ -131,16 +139,6 @@ __device__ __forceinline__ void w3_store(char* stage, int wave, int lane, const 
 __device__ __forceinline__ qf16x8 w3_frag(const char* stage, int row, int chunk) {
     return *reinterpret_cast<const qf16x8*>(stage + row * 256 + 16 * (chunk ^ (row & 15)));
 }
-
-#define Q_MFMA6(ACC, X, Y)                                                            \
-    do {                                                                              \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[2], Y[0], ACC, 0, 0, 0);      \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[0], Y[2], ACC, 0, 0, 0);      \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[1], Y[1], ACC, 0, 0, 0);      \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[1], Y[0], ACC, 0, 0, 0);      \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[0], Y[1], ACC, 0, 0, 0);      \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X[0], Y[0], ACC, 0, 0, 0);      \
-    } while (0)
 
 // top three of the union of two descending triples
 __device__ __forceinline__ void merge3(float& a1, float& a2, float& a3, float b1, float b2, float b3) {
@@ -176,7 +174,7 @@ __device__ __forceinline__ int slot_of_id(unsigned id) {
 template <int C, bool TAIL>
 __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __restrict__ pc, const float* __restrict__ trans,
                                                                  int N, int Npad, int tiles, int deal, long B, const float* __restrict__ W1,
-                                                                 const float* __restrict__ b1, const uint16_t* __restrict__ W2p,
+                                                                 const float* __restrict__ b1,
                                                                  const float* __restrict__ b2, const char* __restrict__ w3f,
                                                                  float* __restrict__ h2buf, f32x4* __restrict__ part, qf32x2* __restrict__ part2,
                                                                  unsigned* __restrict__ tstat, const float* __restrict__ cbuf,
@@ -204,12 +202,15 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
 
     const unsigned long long t_start = (abl & 4096) ? __builtin_amdgcn_s_memtime() : 0ull;
     unsigned long long t_a = 0, t_b = 0, t_c = 0;
-    w2_issue(W2p, 0, fl, wave, lane);
-    w2_issue(W2p, 64, fl + F_STAGE2, wave, lane);
+    const uint16_t* w2pl = reinterpret_cast<const uint16_t*>(w3f + IMG_OFF_W2);
+    w2_issue(w2pl, 0, fl, wave, lane);
+    w2_issue(w2pl, 64, fl + F_STAGE2, wave, lane);
+    float* k2s = reinterpret_cast<float*>(fl + F_OFF_K2);
+    if (tid < 128) k2s[tid] = reinterpret_cast<const float*>(w3f + IMG_OFF_K2)[tid];
     w1s[tid] = W1[tid];
     if (tid < 64) b1s[tid] = b1[tid];
     if (tid < 128) b2s[tid] = b2[tid];
-    *reinterpret_cast<f32x4*>(tis + 4 * tid) = *reinterpret_cast<const f32x4*>(w3f + 1024 * 256 + 16 * tid);
+    *reinterpret_cast<f32x4*>(tis + 4 * tid) = *reinterpret_cast<const f32x4*>(w3f + IMG_OFF_TI + 16 * tid);
     if (TAIL) { cs[lane] = cbuf[b * 128 + lane]; cs[64 + lane] = cbuf[b * 128 + 64 + lane]; }
     else if (tid < 128) cs[tid] = cbuf[b * 128 + tid];
 
@@ -249,14 +250,18 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         cnorm = sqrtf(cq) * 1.0001f;
     }
 
-    // ---- conv1 + conv2 (six-product split-bf16), h2 = relu(conv2 + b2) kept in fp32: hv[pb][16 t4 + e]
+    // ---- conv1 + conv2, h2 = relu(conv2 + b2) kept in fp32: hv[pb][16 t4 + e].  conv2 runs on the fp16 THREE-product split of
+    // csrc/gemm_f16x2.hip since round 5 (six bf16 products before): weights as two fp16 planes of w * 2^t_n (per output row), the
+    // activations of a point as two fp16 pieces of h1 * s_p with s_p a power of two that puts the POINT's largest activation in
+    // [2^14, 2^15) -- a function of the point alone, so a row's bits do not depend on which points share its wave (tail tile ==
+    // full tile, batched == single); hi += a1 w1, lo += a1 w2 + a2 w1, h2 = (hi + lo 2^-11) / s_p 2^-t_n + b2.
     float hv[NPB][64];
 #pragma unroll
     for (int pb = 0; pb < NPB; ++pb) {
-        qbf16x8 h1f[4][3];
+        float v[4][8];
+        float amax = 0.f;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k = 16 * s + 8 * h + j;
@@ -265,33 +270,45 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
                 a = fmaf(xin[pb][1], w[1], a);
                 a = fmaf(xin[pb][2], w[2], a);
                 a = fmaf(xin[pb][3], w[3], a);
-                v[j] = fmaxf(a + b1s[k], 0.f);
+                v[s][j] = fmaxf(a + b1s[k], 0.f);
+                amax = fmaxf(amax, v[s][j]);               // (a NaN is dropped here and reaches the products through the pieces)
             }
-            q_split8(v, h1f[s]);
+        }
+        amax = fmaxf(amax, __shfl_xor(amax, 32));          // the lane halves hold the two halves of a point's 64 activations
+        float s_p = 1.f, r_p = 1.f;
+        {
+            const int ex = (int)((__float_as_uint(amax) >> 23) & 255u);              // amax in [2^(ex-127), 2^(ex-126))
+            if (ex > 20 && ex < 235) {
+                s_p = __uint_as_float((unsigned)(127 + 15 - (ex - 126)) << 23);
+                r_p = __uint_as_float((unsigned)(127 - 15 + (ex - 126)) << 23);
+            }
+        }
+        qf16x8 h1a[4], h1b[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[s][j] *= s_p;
+            q_split2(v[s], h1a[s], h1b[s]);
         }
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
             const char* st = fl + (t4 >> 1) * F_STAGE2;
             const int row = 32 * (t4 & 1) + r;
-            f32x16 acc;
+            f32x16 hi, lo;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            for (int e = 0; e < 16; ++e) { hi[e] = 0.f; lo[e] = 0.f; }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                qbf16x8 wf[3];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) wf[pl] = w2_frag(st, pl, row, 2 * s + h);
-                if (abl & 8) {                                // timing only: what a three-product conv2 would cost in matrix work
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1], h1f[s][0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], h1f[s][1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], h1f[s][0], acc, 0, 0, 0);
-                } else
-                Q_MFMA6(acc, wf, h1f[s]);
+                const qf16x8 w1f = w2_frag(st, 0, row, 2 * s + h), w2f = w2_frag(st, 1, row, 2 * s + h);
+                hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1f, h1a[s], hi, 0, 0, 0);
+                lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2f, h1a[s], lo, 0, 0, 0);
+                lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1f, h1b[s], lo, 0, 0, 0);
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int ch = 32 * t4 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                hv[pb][16 * t4 + e] = fmaxf(acc[e] + b2s[ch], 0.f);
+                const float x = fmaf(lo[e], 1.0f / 2048.0f, hi[e]) * r_p;
+                hv[pb][16 * t4 + e] = fmaxf(fmaf(x, k2s[ch], b2s[ch]), 0.f);
             }
             if (pidx[pb] < N && live && !(abl & 1)) {     // natural channel order: 4 consecutive channels per 16-byte store
                 float* dst = h2buf + ((b * Npad + pidx[pb]) * 128 + 32 * t4 + 4 * h);
@@ -383,8 +400,8 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     {
         // 2 E of this tile for every channel, once, into the LDS (the publishing waves used to fetch the two weight norms of their
         // channels from global memory at the top of every publish: an L2 round trip in front of four idle waves, four times)
-        const float* wnorm_g = reinterpret_cast<const float*>(w3f + 1024 * 256 + 4096);
-        const float* rnorm_g = reinterpret_cast<const float*>(w3f + 1024 * 256 + 8192);
+        const float* wnorm_g = reinterpret_cast<const float*>(w3f + IMG_OFF_WN);
+        const float* rnorm_g = reinterpret_cast<const float*>(w3f + IMG_OFF_RN);
         // the tile's maxima: over its four waves -- over the wave alone where every wave is a tile of its own (TAIL)
         const float hm = (TAIL ? wst[wave] : fmaxf(fmaxf(wst[0], wst[1]), fmaxf(wst[2], wst[3]))) * 1.00001f;
         const float dmx = (TAIL ? wst[4 + wave] : fmaxf(fmaxf(wst[4], wst[5]), fmaxf(wst[6], wst[7]))) * 1.00001f;
@@ -1104,16 +1121,38 @@ __global__ __launch_bounds__(256) void pn_filter_pack_kernel(const float* __rest
     }
 }
 
+// One wave per conv2 output channel (128 rows of 64): the two fp16 planes of w * 2^t_n (row maximum in [2^14, 2^15)) -- the second the
+// remainder * 2^11, as csrc/gemm_f16x2.hip's packer -- and 2^-t_n.
+__global__ __launch_bounds__(256) void pn_filter_pack_w2_kernel(const float* __restrict__ w2, _Float16* __restrict__ planes,
+                                                                float* __restrict__ kinv) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const float v = w2[n * 64 + lane];
+    const float amax = wave_max(fabsf(v));
+    float t = 1.f;
+    const int ex = (int)((__float_as_uint(amax) >> 23) & 255u);
+    if (ex > 20 && ex < 235) t = __uint_as_float((unsigned)(127 + 15 - (ex - 126)) << 23);
+    const float vs = v * t;
+    const _Float16 p1 = (_Float16)vs;
+    const _Float16 p2 = (_Float16)((vs - (float)p1) * 2048.0f);
+    planes[n * 64 + lane] = p1;
+    planes[128 * 64 + n * 64 + lane] = p2;
+    if (lane == 0) kinv[n] = 1.0f / t;
+}
+
 }  // namespace
 
-size_t dvq_pn_filter_image_bytes() { return (size_t)1024 * 256 + 3 * 1024 * 4; }
+size_t dvq_pn_filter_image_bytes() { return (size_t)IMG_BYTES; }
 
-int dvq_launch_pn_filter_pack(const float* w3, void* image, hipStream_t st) {
+int dvq_launch_pn_filter_pack(const float* w2, const float* w3, void* image, hipStream_t st) {
     char* im = (char*)image;
     DVQ_LAUNCH(pn_filter_pack_kernel, dim3(256), dim3(256), 0, st, w3, reinterpret_cast<_Float16*>(im),
-               reinterpret_cast<float*>(im + 1024 * 256), reinterpret_cast<float*>(im + 1024 * 256 + 4096),
-               reinterpret_cast<float*>(im + 1024 * 256 + 8192));
+               reinterpret_cast<float*>(im + IMG_OFF_TI), reinterpret_cast<float*>(im + IMG_OFF_WN),
+               reinterpret_cast<float*>(im + IMG_OFF_RN));
     DVQ_CHECK_LAUNCH("pn_filter_pack");
+    DVQ_LAUNCH(pn_filter_pack_w2_kernel, dim3(32), dim3(256), 0, st, w2, reinterpret_cast<_Float16*>(im + IMG_OFF_W2),
+               reinterpret_cast<float*>(im + IMG_OFF_K2));
+    DVQ_CHECK_LAUNCH("pn_filter_pack_w2");
     return DVQ_OK;
 }
 
@@ -1179,18 +1218,18 @@ int dvq_launch_pn_filter_front(const float* pc, int C, int N, int Npad, long B, 
     {
         DVQ_PROF("pn_trunk", 2.0 * pts * (4.0 * 64 + 64.0 * 128 + 128.0 * 1024), pts * (16 + 512) + (double)grid * 16384, st);
         if (C == 3)
-            DVQ_LAUNCH((pn_trunk_filter_kernel<3, false>), dim3((unsigned)grid), dim3(256), F_LDS, st, pc, trans, N, Npad, tiles, deal, B, W1, b1, W2p,
+            DVQ_LAUNCH((pn_trunk_filter_kernel<3, false>), dim3((unsigned)grid), dim3(256), F_LDS, st, pc, trans, N, Npad, tiles, deal, B, W1, b1,
                        b2, (const char*)w3f, h2buf, (f32x4*)part, part2, tstat, cbuf, abl);
         else
-            DVQ_LAUNCH((pn_trunk_filter_kernel<4, false>), dim3((unsigned)grid), dim3(256), F_LDS, st, pc, trans, N, Npad, tiles, deal, B, W1, b1, W2p,
+            DVQ_LAUNCH((pn_trunk_filter_kernel<4, false>), dim3((unsigned)grid), dim3(256), F_LDS, st, pc, trans, N, Npad, tiles, deal, B, W1, b1,
                        b2, (const char*)w3f, h2buf, (f32x4*)part, part2, tstat, cbuf, abl);
         if (deal < tiles) {
             const unsigned tgrid = (unsigned)((B + 3) / 4);
             if (C == 3)
-                DVQ_LAUNCH((pn_trunk_filter_kernel<3, true>), dim3(tgrid), dim3(256), F_LDS_TAIL, st, pc, trans, N, Npad, tiles, deal, B, W1, b1, W2p,
+                DVQ_LAUNCH((pn_trunk_filter_kernel<3, true>), dim3(tgrid), dim3(256), F_LDS_TAIL, st, pc, trans, N, Npad, tiles, deal, B, W1, b1,
                            b2, (const char*)w3f, h2buf, (f32x4*)part, part2, tstat, cbuf, abl);
             else
-                DVQ_LAUNCH((pn_trunk_filter_kernel<4, true>), dim3(tgrid), dim3(256), F_LDS_TAIL, st, pc, trans, N, Npad, tiles, deal, B, W1, b1, W2p,
+                DVQ_LAUNCH((pn_trunk_filter_kernel<4, true>), dim3(tgrid), dim3(256), F_LDS_TAIL, st, pc, trans, N, Npad, tiles, deal, B, W1, b1,
                            b2, (const char*)w3f, h2buf, (f32x4*)part, part2, tstat, cbuf, abl);
         }
     }
@@ -1215,8 +1254,8 @@ int dvq_launch_pn_filter_back(int N, int Npad, long B, const void* w3f, const fl
     {
         DVQ_PROF("pn_exact", 2.0 * (double)B * 1024 * 128, (double)B * (tiles * 16384.0 + 1024.0 * 512 + 4096), st);
         DVQ_LAUNCH(pn_exact_kernel, dim3((unsigned)B), dim3(256), 0, st, (const f32x4*)part, part2, tiles, deal, h2buf, N, Npad, w3, b3,
-                   reinterpret_cast<const float*>((const char*)w3f + 1024 * 256 + 4096),
-                   reinterpret_cast<const float*>((const char*)w3f + 1024 * 256 + 8192), tstat, cbuf, relu, exhaustive, pair_cap, fb_cap,
+                   reinterpret_cast<const float*>((const char*)w3f + IMG_OFF_WN),
+                   reinterpret_cast<const float*>((const char*)w3f + IMG_OFF_RN), tstat, cbuf, relu, exhaustive, pair_cap, fb_cap,
                    feat, ld_feat, stats, abl);
     }
     DVQ_CHECK_LAUNCH("pn_exact");

@@ -125,15 +125,16 @@ def split_planes(w: Tensor, kind: Optional[int] = None) -> Planes:
     return Planes(_lib.PLANES_BF16X3, split_bf16x3(w))
 
 
-def pointnet_filter_image(w3: Tensor) -> Tensor:
-    """uint8 image of a conv3 weight matrix [1024,128] for the filtered PointNet trunk (dvq_pointnet_pack_filter)."""
+def pointnet_filter_image(w2: Tensor, w3: Tensor) -> Tensor:
+    """uint8 image of a trunk's conv2 [128,64] and conv3 [1024,128] weights (BatchNorm folded) for the filtered PointNet trunk
+    (dvq_pointnet_pack_filter)."""
     lib = _lib.load()
-    w3 = w3.contiguous()
-    if tuple(w3.shape) != (1024, 128):
-        raise RuntimeError(f"pointnet filter image: conv3 weight must be [1024,128], got {tuple(w3.shape)}")
+    w2, w3 = w2.contiguous(), w3.contiguous()
+    if tuple(w3.shape) != (1024, 128) or tuple(w2.shape) != (128, 64):
+        raise RuntimeError(f"pointnet filter image: conv2 / conv3 weights must be [128,64] / [1024,128], got {tuple(w2.shape)} / {tuple(w3.shape)}")
     out = torch.empty(lib.dvq_pointnet_filter_bytes(), dtype=torch.uint8, device=w3.device)
     with torch.cuda.device(w3.device):
-        _lib.check(lib.dvq_pointnet_pack_filter(w3.data_ptr(), out.data_ptr(),
+        _lib.check(lib.dvq_pointnet_pack_filter(w2.data_ptr(), w3.data_ptr(), out.data_ptr(),
                                                 torch.cuda.current_stream(w3.device).cuda_stream), "dvq_pointnet_pack_filter")
     return out
 
@@ -234,7 +235,7 @@ class PackedPointNet(_Packed):
         s = _lib.PointnetWeights()
         s.C = self.C
         for key in ("w3", "s_w3"):                      # conv3 filter images (fp16 rows + scales + norms), built on the device
-            self.tensors[key + "__filter"] = pointnet_filter_image(self.tensors[key])
+            self.tensors[key + "__filter"] = pointnet_filter_image(self.tensors[key[:-1] + "2"], self.tensors[key])   # (s_)w2, (s_)w3
         for name, _ in _lib.PointnetWeights._fields_[2:]:
             if name.endswith("f"):
                 setattr(s, name, self.tensors[name[:-1] + "__filter"].data_ptr())

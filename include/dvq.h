@@ -163,20 +163,22 @@ typedef struct {
     const float *w3, *b3;     /* [1024,128] */
     /* optional split-bf16 planes ([3][out][in], dvq_split_bf16x3) of the GEMM weights; all-or-nothing */
     const uint16_t *s_w2p, *s_w3p, *s_f1p, *s_f2p, *s_f3p, *w2p, *w3p;
-    /* optional filter images of conv3's weights (dvq_pointnet_pack_filter); with them (and the planes) the trunk runs
-     * conv3 + max as an fp16 matrix-core filter followed by an exact fp32 re-evaluation of the candidate points */
+    /* optional filter images of a trunk's conv2 / conv3 weights (dvq_pointnet_pack_filter); with them (and the planes) the trunk
+     * runs conv3 + max as an fp16 matrix-core filter followed by an exact fp32 re-evaluation of the candidate points */
     const void *s_w3f, *w3f;
 } dvq_pointnet_weights;
 
-/* Filter image of one conv3 weight matrix w3 [1024,128] (device pointers): fp16 rows scaled by a per-row power of two in
- * the k order the trunk kernel consumes, the inverse scales and the row norms.  dvq_pointnet_filter_bytes() bytes. */
 /* Run-time consistency counters of the filtered trunk on the current device (v8): out[0] = tile records the trunk kernel marked
  * suspect (an input of its merge was stale), out[1] = channels whose exact maximum lay outside the interval their tile records
  * promised.  Both kinds are re-evaluated over all the points concerned (the features stay right); a non-zero count means the
  * filter's bookkeeping failed and should be reported.  Synchronises the device.  reset != 0: zero them after reading. */
 int dvq_pointnet_fault_counters(uint64_t* out /* [2] */, int reset);
+/* Filter image of one trunk (device pointers; dvq_pointnet_filter_bytes() bytes): conv3's weights w3 [1024,128] as fp16 rows scaled by
+ * a per-row power of two in the k order the trunk kernel consumes, the inverse scales and the row norms; and (v8) conv2's weights
+ * w2 [128,64] (BatchNorm folded) as the two fp16 planes of the three-product split of dvq_split_f16x2 with their row scales:
+ * the filtered trunk multiplies conv2 on them (six bf16 products per fp32 product before). */
 size_t dvq_pointnet_filter_bytes(void);
-int dvq_pointnet_pack_filter(const float* w3, void* image, dvq_stream_t stream);
+int dvq_pointnet_pack_filter(const float* w2, const float* w3, void* image, dvq_stream_t stream);
 
 size_t dvq_pointnet_workspace_bytes(int64_t B, int N);
 /* pc [B,C,N] (channel-major per sample, as the datasets emit it) -> feat [B,1024], trans [B,3,3] */
