@@ -13,6 +13,10 @@ run() { # name, then the rocprofv3 args
   echo "$name rc=$?"
 }
 BENCH_ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-latency --prof-steps 0" run bench_stats --kernel-trace --stats
+# the same with the PointNet on one stream: every kernel alone on the chip -- the durations bench.py's roofline objects quote
+export DVQ_PN_STREAMS=0
+BENCH_ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-latency --prof-steps 0" run bench_stats_serial --kernel-trace --stats
+unset DVQ_PN_STREAMS
 BENCH_ARGS="--vq-only" run vq_stats --kernel-trace --stats
 BENCH_ARGS="--vq-only" run vq_pmc_fetch --kernel-trace --pmc FETCH_SIZE
 BENCH_ARGS="--vq-only" run vq_pmc_write --kernel-trace --pmc WRITE_SIZE

@@ -46,7 +46,7 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
-    for stem in ("bench_stats", "vq_stats"):
+    for stem in ("bench_stats", "bench_stats_serial", "vq_stats"):
         p = find(os.path.join(src, stem), "*kernel_stats.csv")
         if p:
             shutil.copy(p, os.path.join(dst, f"{tag}_{stem}_rocprofv3_kernel_stats.csv"))
