@@ -12,9 +12,10 @@ zs = [torch.randn(M, D, device=dev) for _ in range(6)]
 E = torch.randn(K, D, device=dev)
 pk = ops.vq_pack(E)
 ref = None
-res = {k: [] for k in ("32", "16", "8")}
+KERNELS = tuple(os.environ.get("VQ_AB_KERNELS", "32,16,8").split(","))
+res = {k: [] for k in KERNELS}
 for rnd in range(5):
-    for kern in ("32", "16", "8"):
+    for kern in KERNELS:
         os.environ["DVQ_VQ_KERNEL"] = kern; lib.dvq_reload_env()
         for i in range(6): idx = ops.vq_argmin(zs[i], E, packed=pk)
         torch.cuda.synchronize()
