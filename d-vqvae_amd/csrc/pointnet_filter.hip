@@ -256,6 +256,12 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     // [2^14, 2^15) -- a function of the point alone, so a row's bits do not depend on which points share its wave (tail tile ==
     // full tile, batched == single); hi += a1 w1, lo += a1 w2 + a2 w1, h2 = (hi + lo 2^-11) / s_p 2^-t_n + b2.
     float hv[NPB][64];
+    if (abl & 131072) {                                    // timing only: a "consumer" workgroup -- no conv1 / conv2, rows from thin air
+#pragma unroll
+        for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+            for (int i = 0; i < 64; ++i) hv[pb][i] = xin[pb][i & 3] * (float)(i + 1);
+    } else
 #pragma unroll
     for (int pb = 0; pb < NPB; ++pb) {
         float v[4][8];
@@ -1215,6 +1221,25 @@ int dvq_launch_pn_filter_front(const float* pc, int C, int N, int Npad, long B, 
     DVQ_CHECK_LAUNCH("pn_center");
     const double pts = (double)B * (deal * 256 + (deal < tiles ? 32 : 0));
     const int abl = pn_abl();
+#ifdef DVQ_DIAG
+    if ((abl & 262144) && C == 4) {
+        // timing only (results INVALID): what splitting the trunk into a producer kernel (conv1 / conv2 / centring / conversion) and a
+        // consumer kernel (conv3 loop) would buy if the two ran BESIDE each other: the same grid twice, the halves of the work on two streams
+        static hipStream_t side = nullptr;
+        static hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (!side) { (void)hipStreamCreateWithFlags(&side, hipStreamNonBlocking); (void)hipEventCreateWithFlags(&ev0, hipEventDisableTiming); (void)hipEventCreateWithFlags(&ev1, hipEventDisableTiming); }
+        DVQ_PROF("pn_trunk", 2.0 * pts * (4.0 * 64 + 64.0 * 128 + 128.0 * 1024), pts * (16 + 512) + (double)grid * 16384, st);
+        (void)hipEventRecord(ev0, st);
+        (void)hipStreamWaitEvent(side, ev0, 0);
+        DVQ_LAUNCH((pn_trunk_filter_kernel<4, false>), dim3((unsigned)grid), dim3(256), F_LDS, st, pc, trans, N, Npad, tiles, deal, B, W1, b1,
+                   b2, (const char*)w3f, h2buf, (f32x4*)part, part2, tstat, cbuf, (abl & ~262144) | 2);
+        DVQ_LAUNCH((pn_trunk_filter_kernel<4, false>), dim3((unsigned)grid), dim3(256), F_LDS, side, pc, trans, N, Npad, tiles, deal, B, W1, b1,
+                   b2, (const char*)w3f, h2buf, (f32x4*)part, part2, tstat, cbuf, (abl & ~262144) | 131072 | 1);
+        (void)hipEventRecord(ev1, side);
+        (void)hipStreamWaitEvent(st, ev1, 0);
+        return DVQ_OK;
+    }
+#endif
     {
         DVQ_PROF("pn_trunk", 2.0 * pts * (4.0 * 64 + 64.0 * 128 + 128.0 * 1024), pts * (16 + 512) + (double)grid * 16384, st);
         if (C == 3)

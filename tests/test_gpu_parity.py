@@ -1225,6 +1225,30 @@ def test_pointnet_runtime_checks():
     assert ops.pointnet_fault_counters() == (0, 0), "the product library must not have seen an inconsistency in this test session"
 
 
+def test_gemm_kernels_repeat_bitwise_under_load():
+    """The f16x2 GEMM kernels use explicit packed-fp32 arithmetic in their epilogues (the one place the disassembly fence of
+    tests/test_abi.py allows it) and run two waves per SIMD -- the conditions under which round 3's PointNet fault appeared.  A soak
+    of their own: the tiled kernel at the benchmark's gated / residual / bias shapes (through the teacher-forced PixelCNN forward of
+    4 096 rows) and at a plain M = 16 384 linear, and the skinny kernel at M = 8, each call compared bit for bit with the first."""
+    torch.manual_seed(5)
+    net, _ = _gennet()
+    x = torch.randn(16384, 1536, device=DEV)
+    w, b = torch.randn(1024, 1536, device=DEV) / 40.0, torch.randn(1024, device=DEV)
+    pl = packing.split_planes(w)
+    y0 = ops.linear(x, w, b, relu=True, planes=pl)
+    ys0 = ops.linear(x[:8], w, b, planes=pl)
+    tok = gpu(torch.randint(0, 128, (4096, 3, 3), generator=torch.Generator().manual_seed(1)))
+    lab = gpu(torch.randint(0, 128, (4096,), generator=torch.Generator().manual_seed(2)))
+    lg0 = net.GatedPixelCNN(tok, lab)
+    bad = 0
+    for it in range(60):
+        bad += int(not torch.equal(ops.linear(x, w, b, relu=True, planes=pl), y0))
+        bad += int(not torch.equal(ops.linear(x[:8], w, b, planes=pl), ys0))
+        if it % 4 == 0:
+            bad += int(not torch.equal(net.GatedPixelCNN(tok, lab), lg0))
+    assert bad == 0, f"{bad} GEMM calls differed from the first call of the same inputs"
+
+
 def test_gen_sharded_equals_unsharded_with_device_noise():
     """with the device noise keyed by (seed, stream, global row), R contiguous shards of a batch -- each a
     separate gen() call with row0 = its first global row, as R ranks would make them -- reproduce the unsharded call bit for

@@ -50,4 +50,7 @@ for it in range(gens):
         bad_gen += 1
         print(f"gen call {it}: {diff} differ from the first call", flush=True)
 print(f"gen: {bad_gen} bad calls of {gens}")
-sys.exit(1 if (bad_enc or bad_gen) else 0)
+from dvqvae_amd import ops                                   # noqa: E402
+faults = ops.pointnet_fault_counters()
+print(f"run-time consistency counters of the filtered trunk (suspect records, channels outside their interval): {faults}")
+sys.exit(1 if (bad_enc or bad_gen or faults != (0, 0)) else 0)
