@@ -395,7 +395,9 @@ def mfma_entry(kernels, name, pe_ms, B):
         peak = BF16_MFMA_PEAK_TF if filtered else BF16_MFMA_PEAK_TF / 6.0
         note = ("dense fp16 MFMA 2500 TF: conv3 is ONE fp16 product per term (a filter; the exact fp32 re-evaluation of its candidates is "
                 "pn_exact)") if filtered else "dense bf16 MFMA 2500 TF / 6 partial products"
-        label = "pn_trunk_filter_kernel (conv1 + conv2 + conv3 filter)" if filtered else "pn_trunk_kernel (fused PointNet trunk)"
+        label = ("pn_trunk_filter_kernel (conv1 + conv2 + conv3 filter); one launch here = the kernel over <= 4096 clouds, plus its one-block "
+                 "tail kernel for the 778-vertex hand clouds: per step 64 launches on N=1024 object clouds (rocprofv3: pn_trunk_filter_kernel<4, false>) "
+                 "and 32 on hand clouds (<3, false> + <3, true>)") if filtered else "pn_trunk_kernel (fused PointNet trunk)"
     else:
         peak, note, label = GEMM_PEAK_TF, GEMM_PEAK_NOTE, f"gemm_{GEMM_MODE} {name}"
     achieved = v["flops"] / (v["ms"] * 1e-3) / 1e12
