@@ -845,6 +845,34 @@ def test_ops_on_two_streams_do_not_share_scratch():
     assert all(torch.equal(o, want_a) for o in outs_a) and all(torch.equal(o, want_b) for o in outs_b)
 
 
+def test_pointnet_pipeline_on_two_streams_and_one():
+    """dvq_pointnet_encode spreads a batch of >= 2 launches over the caller's stream and a library-owned second stream (exact stage and
+    STN FCs of launch i beside the trunk kernel of launch i + 1, two scratch sets).  Two caller streams encoding different batches at
+    the same time (each gets a side stream and scratch of its own), back to back, must both give the one-stream answers
+    (DVQ_PN_STREAMS=0) bit for bit, and so must the default path on the default stream."""
+    from dvqvae_amd.network.pointnet_encoder import PointNetEncoder
+    net = PointNetEncoder(channel=4)
+    load_synth(net, 3)
+    net = net.eval().to(DEV)
+    xa, xb = gpu(synth.synthetic_clouds(2304, 1024, seed=21)), gpu(synth.synthetic_clouds(2100, 778, seed=22))
+    want_a = _with_env("DVQ_PN_STREAMS", "0", lambda: net(xa))
+    want_b = _with_env("DVQ_PN_STREAMS", "0", lambda: net(xb))
+    fa, ta, _ = net(xa)
+    assert torch.equal(fa, want_a[0]) and torch.equal(ta, want_a[1])
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    outs_a, outs_b = [], []
+    for _ in range(6):
+        with torch.cuda.stream(sa):
+            outs_a.append(net(xa))
+        with torch.cuda.stream(sb):
+            outs_b.append(net(xb))
+    torch.cuda.synchronize()
+    assert all(torch.equal(o[0], want_a[0]) and torch.equal(o[1], want_a[1]) for o in outs_a)
+    assert all(torch.equal(o[0], want_b[0]) and torch.equal(o[1], want_b[1]) for o in outs_b)
+    assert ops.pointnet_fault_counters() == (0, 0)
+
+
 def test_vq_fast_scales_and_tie_prone_codebook():
     for scale_z, scale_e in [(1.0, 1.0 / 512), (100.0, 0.01), (1e-3, 1e3), (30.0, 30.0)]:
         E = synth.synthetic_uniform((512, 256), 10, f"vqs/E/{scale_e}", -scale_e, scale_e)
