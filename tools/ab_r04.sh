@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B: this tree's step against the round-4 tree (git worktree in tools/ab/r04, built there), alternating
+# same-box A/B: this tree's step against the round-4 tree, alternating.  Needs (here, before gpurun): git worktree add -f tools/ab/r04 d0b8d5b && make -C tools/ab/r04/d-vqvae_amd/csrc -j8   (tools/ab/ is git-ignored)
 for rep in 1 2; do
   for v in new old; do
     if [ $v = old ]; then b=tools/ab/r04/bench.py; else b=bench.py; fi
