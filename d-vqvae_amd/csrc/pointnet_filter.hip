@@ -566,11 +566,9 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         if (!(abl & 16384)) __syncthreads();              // chunk c is in its stage; the other stage and tb parity are free
         if (c + 1 < 16 && !(abl & 1024)) wreg = w3_load(w3h, 64 * (c + 1), wave, lane);
         if ((c & 3) == 0 && c > 0 && !(abl & 256)) {        // the ring's four chunks are complete (barrier above): one per wave
-            if (abl & 524288) __builtin_amdgcn_s_setprio(0);
             publish(c - 4 + wave);
             __syncthreads();                              // before this chunk's pairs overwrite slot 0
         }
-        if (abl & 524288) __builtin_amdgcn_s_setprio(1);  // timing experiment: the wave that feeds the matrix pipe wins the issue arbitration
         const char* st = fl + stage * F_STAGE3;
         qf16x8 wf0[8], wf1[8];
 #pragma unroll
