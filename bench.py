@@ -663,6 +663,7 @@ def main():
         # kernels sharing the chip each take longer than alone, so a per-launch duration measured that way is not the kernel's own.
         # The breakdown pass therefore runs ONE stream (DVQ_PN_STREAMS=0: same kernels, same launches, same results): its durations
         # are those rocprofv3 reports for the same setting (profiles/*_bench_stats_serial_*), and its step is a few ms longer.
+        pn_streams_was = os.environ.get("DVQ_PN_STREAMS")
         os.environ["DVQ_PN_STREAMS"] = "0"
         lib.dvq_reload_env()
         lib.dvq_prof_reset()
@@ -676,7 +677,10 @@ def main():
         lib.dvq_prof_enable(0)
         kernels = prof_read(lib, _lib)
         lib.dvq_prof_reset()
-        del os.environ["DVQ_PN_STREAMS"]
+        if pn_streams_was is None:
+            del os.environ["DVQ_PN_STREAMS"]
+        else:
+            os.environ["DVQ_PN_STREAMS"] = pn_streams_was
         lib.dvq_reload_env()
 
     out = None

@@ -88,26 +88,26 @@ def new_err_flag(dev: torch.device) -> Tensor:
 # its result once (one host synchronisation) and runs the call again on the six-product bf16 images, which have fp32's range, when
 # it holds a non-finite value; inputs that are themselves NaN / Inf come out non-finite there too, as in the reference.
 # GenNet.gen makes ONE such check for the whole path and switches the per-op checks off around its inner calls.
-_range_check_off = 0
+import threading
+
+_range_state = threading.local()                            # per host thread: one thread's gen() must not switch another's checks off
 
 
 class no_range_check:
     """``with ops.no_range_check(): ...`` -- the caller checks the final result itself (GenNet.gen: one synchronisation per call)."""
 
     def __enter__(self):
-        global _range_check_off
-        _range_check_off += 1
+        _range_state.off = getattr(_range_state, "off", 0) + 1
         return self
 
     def __exit__(self, *exc):
-        global _range_check_off
-        _range_check_off -= 1
+        _range_state.off -= 1
         return False
 
 
 def _out_of_range(kind, *outs: Tensor) -> bool:
     """True when a result of the fp16-image arithmetic holds a non-finite value and the per-op check is on (synchronises)."""
-    if _range_check_off or kind != _lib.PLANES_F16X2:
+    if getattr(_range_state, "off", 0) or kind != _lib.PLANES_F16X2:
         return False
     return not all(bool(torch.isfinite(o).all()) for o in outs if o is not None)
 
