@@ -201,6 +201,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     float* e2s = reinterpret_cast<float*>(fl + F_OFF_E2) + (TAIL ? 1024 * wave : 0);
 
     const unsigned long long t_start = (abl & 4096) ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long r_start = (abl & 8192) ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz: with 4096 | 8192 the record's word 3 holds the CLOCK
     unsigned long long t_a = 0, t_b = 0, t_c = 0;
     const uint16_t* w2pl = reinterpret_cast<const uint16_t*>(w3f + IMG_OFF_W2);
     w2_issue(w2pl, 0, fl, wave, lane);
@@ -626,6 +627,10 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
         auto q = [](unsigned long long d) { d >>= 6; return (unsigned)(d > 255 ? 255 : d); };
         tstat[4 * rec + 3] = q(t_a - t_start) | (q(t_b - t_a) << 8) | (q(t_c - t_b) << 16) | (q((t_end - t_c) >> 3) << 24);
+        if (abl & 8192) {                                   // in-kernel clock in MHz: shader cycles per 100 MHz tick over the workgroup's life
+            const unsigned long long r_end = __builtin_amdgcn_s_memrealtime();
+            tstat[4 * rec + 3] = (unsigned)((t_end - t_start) * 100ull / (r_end - r_start + 1));
+        }
     }
 }
 
@@ -1294,6 +1299,11 @@ int dvq_launch_pn_filter_back(int N, int Npad, long B, const void* w3f, const fl
             const unsigned v = ts[4 * i + 3];
             a += v & 255; b2_ += (v >> 8) & 255; c += (v >> 16) & 255; d += (v >> 24) & 255;
         }
+        if (abl & 8192) {
+            double mhz = 0;
+            for (long i = 0; i < nrec; ++i) mhz += ts[4 * i + 3];
+            fprintf(stderr, "[dvq pn] in-kernel clock of the trunk kernel: %.0f MHz (s_memtime over s_memrealtime, mean over %ld workgroups)\n", mhz / nrec, nrec);
+        } else
         fprintf(stderr, "[dvq pn] mean phase ticks per workgroup (s_memtime): start->loaded %.0f, conv1+conv2 %.0f, centre/convert %.0f, conv3 loop %.0f\n",
                 a / nrec * 64, b2_ / nrec * 64, c / nrec * 64, d / nrec * 512);
     }
