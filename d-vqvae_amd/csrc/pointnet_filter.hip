@@ -63,31 +63,22 @@ constexpr int F_LDS = F_OFF_E2 + 4096;                    // 76 672 B -> 2 workg
 constexpr int F_LDS_TAIL = F_LDS + 3 * 4096 + 4 * 512;    // tail kernel: three more e2 tables, one centre per wave (its own sample) behind them
 static_assert(F_OFF_W1 >= 2 * F_STAGE2, "the conv3 stages and the triple buffer cover the W2 region");
 
-// h - x with h the low (HI = 0) or high (HI = 1) fp16 half of hp: one v_fma_mix_f32, exact
-template <int HI>
-__device__ __forceinline__ float mix_diff(unsigned hp, float x) {
-    float d;
-    if (HI) asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hp), "v"(x));
-    else asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hp), "v"(x));
-    return d;
-}
 __device__ __forceinline__ float max_nc(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, 3.0e38f); }
 __device__ __forceinline__ float min_nc(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, NEG_BIG); }
 
-// Eight values x (already scaled into fp16's range) -> the two fp16 pieces of the three-product split (csrc/gemm_f16x2.hip):
-// p1 = fp16(x), p2 = fp16((x - p1) * 2^11), the second ONE rounding of the exact fma(p1, -2048, 2048 x) (v_fma_mixlo / mixhi_f16).
-__device__ __forceinline__ void q_split2(const float (&v)[8], qf16x8& p1, qf16x8& p2) {
+// Eight values x and a power of two s -> the two fp16 pieces of the three-product split of x s (csrc/gemm_f16x2.hip's, the second
+// piece NOT scaled by 2^11 here): p1 = fp16(x s), p2 = fp16(x s - p1), each ONE rounding of an exact fma (v_fma_mixlo / mixhi_f16) --
+// two vector instructions per value, no separate scaling or conversion.  (|p2| <= 2^-11 |p1|: with the point's largest activation in
+// [2^14, 2^15) a second piece below fp16's normal range belongs to an activation 2^-17 of the largest; what is lost there is 2^-40 of it.)
+__device__ __forceinline__ void q_split2(const float (&v)[8], float s, qf16x8& p1, qf16x8& p2) {
     unsigned hb[4], lb[4];
-    const float m2048 = -2048.0f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float a0 = v[2 * j], a1 = v[2 * j + 1];
-        qf32x2 pr;
-        pr[0] = a0; pr[1] = a1;
-        hb[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, qf16x2));                // v_cvt_pk_f16_f32, round to nearest even
-        const float t0 = a0 * 2048.0f, t1 = a1 * 2048.0f;
-        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lb[j]) : "v"(hb[j]), "v"(m2048), "v"(t0));
-        asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lb[j]) : "v"(hb[j]), "v"(m2048), "v"(t1));
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(hb[j]) : "v"(a0), "v"(s));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(hb[j]) : "v"(a1), "v"(s));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lb[j]) : "v"(a0), "v"(s), "v"(hb[j]));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lb[j]) : "v"(a1), "v"(s), "v"(hb[j]));
     }
     p1 = __builtin_bit_cast(qf16x8, uint4{hb[0], hb[1], hb[2], hb[3]});
     p2 = __builtin_bit_cast(qf16x8, uint4{lb[0], lb[1], lb[2], lb[3]});
@@ -217,6 +208,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
 
     float xin[NPB][4];
     int pidx[NPB];
+    bool badpt = false;
 #pragma unroll
     for (int pb = 0; pb < NPB; ++pb) {
         int p = point_of_slot(tile, TAIL ? r : wave * 64 + pb * 32 + r, deal);
@@ -234,6 +226,11 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
             x0 = n0; x1 = n1; x2 = n2;
         }
         xin[pb][0] = x0; xin[pb][1] = x1; xin[pb][2] = x2; xin[pb][3] = x3;
+        // a non-finite coordinate (after the transform): the reference's features of such a cloud are NaN in every channel -- affine
+        // layers and torch.max propagate it.  ReLU as fmaxf(x, 0) squashes it here, and the cloud would go on as a DEGENERATE one
+        // (all its points tie: every group flagged, every channel evaluated over all points by one workgroup -- the straggler of its
+        // launch).  The tile says so instead (word 3 of its maxima) and pn_exact_kernel writes the NaNs.
+        badpt = badpt || !(fabsf(x0) < 3.0e38f) || !(fabsf(x1) < 3.0e38f) || !(fabsf(x2) < 3.0e38f) || !(fabsf(x3) < 3.0e38f);
     }
     dvq_dma_barrier();                                    // W1/b1/b2 visible, W2 planes landed
     // The same wait once more in a form the compiler's counter model sees (vmcnt(0), the other counters untouched).  Without it the
@@ -255,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     // csrc/gemm_f16x2.hip since round 5 (six bf16 products before): weights as two fp16 planes of w * 2^t_n (per output row), the
     // activations of a point as two fp16 pieces of h1 * s_p with s_p a power of two that puts the POINT's largest activation in
     // [2^14, 2^15) -- a function of the point alone, so a row's bits do not depend on which points share its wave (tail tile ==
-    // full tile, batched == single); hi += a1 w1, lo += a1 w2 + a2 w1, h2 = (hi + lo 2^-11) / s_p 2^-t_n + b2.
+    // full tile, batched == single); acc = a1 w2 + a2 w1 + a1 w1 in ONE fp32 accumulator (second pieces unscaled), h2 = acc / s_p 2^-t_n + b2.
     float hv[NPB][64];
     if (abl & 131072) {                                    // timing only: a "consumer" workgroup -- no conv1 / conv2, rows from thin air
 #pragma unroll
@@ -273,13 +270,14 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
             for (int j = 0; j < 8; ++j) {
                 const int k = 16 * s + 8 * h + j;
                 const f32x4 w = *reinterpret_cast<const f32x4*>(w1s + 4 * k);
-                float a = xin[pb][0] * w[0];
+                float a = fmaf(xin[pb][0], w[0], b1s[k]);
                 a = fmaf(xin[pb][1], w[1], a);
                 a = fmaf(xin[pb][2], w[2], a);
-                a = fmaf(xin[pb][3], w[3], a);
-                v[s][j] = fmaxf(a + b1s[k], 0.f);
-                amax = fmaxf(amax, v[s][j]);               // (a NaN is dropped here and reaches the products through the pieces)
+                if constexpr (C > 3) a = fmaf(xin[pb][3], w[3], a);
+                v[s][j] = fmaxf(a, 0.f);
             }
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) amax = fmaxf(fmaxf(amax, v[s][j]), v[s][j + 1]);   // v_max3_f32 (a NaN is dropped here and reaches the products through the pieces)
         }
         amax = fmaxf(amax, __shfl_xor(amax, 32));          // the lane halves hold the two halves of a point's 64 activations
         float s_p = 1.f, r_p = 1.f;
@@ -292,30 +290,29 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         }
         qf16x8 h1a[4], h1b[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[s][j] *= s_p;
-            q_split2(v[s], h1a[s], h1b[s]);
-        }
+        for (int s = 0; s < 4; ++s) q_split2(v[s], s_p, h1a[s], h1b[s]);
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
             const char* st = fl + (t4 >> 1) * F_STAGE2;
             const int row = 32 * (t4 & 1) + r;
-            f32x16 hi, lo;
+            // ONE fp32 accumulator: the eight small products (a1 w2, a2 w1: 2^-11 of the large ones) first, the four large ones after
+            f32x16 acc;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { hi[e] = 0.f; lo[e] = 0.f; }
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            qf16x8 w1f[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const qf16x8 w1f = w2_frag(st, 0, row, 2 * s + h), w2f = w2_frag(st, 1, row, 2 * s + h);
-                hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1f, h1a[s], hi, 0, 0, 0);
-                lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2f, h1a[s], lo, 0, 0, 0);
-                lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1f, h1b[s], lo, 0, 0, 0);
+                w1f[s] = w2_frag(st, 0, row, 2 * s + h);
+                const qf16x8 w2f = w2_frag(st, 1, row, 2 * s + h);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2f, h1a[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1f[s], h1b[s], acc, 0, 0, 0);
             }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1f[s], h1a[s], acc, 0, 0, 0);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int ch = 32 * t4 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const float x = fmaf(lo[e], 1.0f / 2048.0f, hi[e]) * r_p;
-                hv[pb][16 * t4 + e] = fmaxf(fmaf(x, k2s[ch], b2s[ch]), 0.f);
+                hv[pb][16 * t4 + e] = fmaxf(fmaf(acc[e] * r_p, k2s[ch], b2s[ch]), 0.f);
             }
             if (pidx[pb] < N && live && !(abl & 1)) {     // natural channel order: 4 consecutive channels per 16-byte store
                 float* dst = h2buf + ((b * Npad + pidx[pb]) * 128 + 32 * t4 + 4 * h);
@@ -369,12 +366,13 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
             unsigned pk[4];
 #pragma unroll
             for (int j2 = 0; j2 < 4; ++j2) {
-                qf32x2 v;
-                v[0] = hv[pb][8 * st + 2 * j2] * s_pb;
-                v[1] = hv[pb][8 * st + 2 * j2 + 1] * s_pb;
-                const qf16x2 hpair = __builtin_convertvector(v, qf16x2);      // v_cvt_pk_f16_f32, round to nearest even
-                pk[j2] = __builtin_bit_cast(unsigned, hpair);
-                const float r0 = mix_diff<0>(pk[j2], v[0]), r1 = mix_diff<1>(pk[j2], v[1]);
+                // fp16(d s) and the rounding residual d s - fp16(d s), each one instruction on the exact product (s a power of two)
+                const float d0 = hv[pb][8 * st + 2 * j2], d1 = hv[pb][8 * st + 2 * j2 + 1];
+                asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(pk[j2]) : "v"(d0), "v"(s_pb));
+                asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(pk[j2]) : "v"(d1), "v"(s_pb));
+                float r0, r1;
+                asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(d0), "v"(s_pb), "v"(pk[j2]));
+                asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(d1), "v"(s_pb), "v"(pk[j2]));
                 sq = fmaf(r0, r0, sq);
                 sq = fmaf(r1, r1, sq);
             }
@@ -388,12 +386,14 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     // in the in-order counter) pending instead of sitting out their round trip (600 .. 3 000 cycles each under load)
     const char* w3h = w3f;
     W3Regs wreg = w3_load(w3h, 0, wave, lane);
+    const bool any_bad = __any(badpt);
     if (lane == 0) {              // per-tile maxima; non-negative floats (and NaN, above all of them) order as integers
         const float dmx = sqrtf(dn2), rdm = sqrtf(rn2) / s_w;
         const float hm = (dmx + cnorm) * 1.0001f;          // |h_p| <= |h_p - c| + |c|
         scs[wave] = 1.0f / s_w;
         wst[wave] = hm; wst[4 + wave] = dmx; wst[8 + wave] = rdm;
         if (live) {
+            if (any_bad && !(abl & 4096)) atomicMax(tstat + 4 * rec + 3, 1u);
             atomicMax(tstat + 4 * rec + 0, __float_as_uint(hm));
             atomicMax(tstat + 4 * rec + 1, __float_as_uint(dmx));
             atomicMax(tstat + 4 * rec + 2, __float_as_uint(rdm));
@@ -456,7 +456,8 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         // why (counted: dvq_pointnet_fault_counters).  The pair of a group is ONE LDS store: checking its first value covers both.
         unsigned tagdiff = 0;
 #pragma unroll
-        for (int gi = 0; gi < NG; ++gi) tagdiff |= __float_as_uint(t1[gi]) ^ (unsigned)(((c >> 2) & 3) << 5);
+        for (int gi = 0; gi + 1 < NG; gi += 2)             // v_xor_b32 + v_or3_b32 per two groups
+            tagdiff = tagdiff | (__float_as_uint(t1[gi]) ^ (unsigned)(((c >> 2) & 3) << 5)) | (__float_as_uint(t1[gi]) ^ __float_as_uint(t1[gi + 1]));
         const bool suspect = (tagdiff & 0x60u) != 0;
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
@@ -525,8 +526,8 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         if ((abl & 65536) && c == 9 && wave == 2 && jn == 0) return;   // diagnostics: a hand-over that does not happen
         float* dst = tb + (c & 3) * F_SLOT + ((wave * 2 + pb) * 2 + h) * 128 + 32 * jn + r;
         const unsigned ctag = (unsigned)(((c >> 2) & 3) << 5);   // which of the four chunks that share this ring slot (checked by publish())
-        dst[0] = __uint_as_float((__float_as_uint(m1) & ~0x60u) | ctag);
-        dst[64] = __uint_as_float((__float_as_uint(m2) & ~0x60u) | ctag);
+        dst[0] = __uint_as_float((__float_as_uint(m1) & ~0x60u) | ctag);   // the pair is ONE LDS store: the tag of its first value covers both
+        dst[64] = m2;
     };
     int stage = 0;
     if constexpr (TAIL) {
@@ -713,30 +714,55 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
     if (tid == 0) { pair_count = 0; fb_count = 0; all_count = 0; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) pcnt[tid + 256 * i] = 0;
+    int nonfinite_point = 0;
     if (tid < tiles) {
         const unsigned* ts = tstat + 4 * (b * tiles + tid);
         hm[tid] = __uint_as_float(ts[0]) * 1.00001f;
         dm[tid] = __uint_as_float(ts[1]) * 1.00001f;
         rd[tid] = __uint_as_float(ts[2]) * 1.00001f;
+        nonfinite_point = ts[3] != 0 && !(abl & 4096);      // (word 3 holds the phase stamps of the diagnostics build otherwise)
     }
-    __syncthreads();
+    if (__syncthreads_or(nonfinite_point)) {
+        // a cloud with a NaN / Inf coordinate: NaN in every channel, as the reference's affine layers and torch.max make it (the trunk
+        // kernel's ReLU squashed it; see there)
+        for (int n = tid; n < 1024; n += 256) feat[b * ld_feat + n] = __builtin_nanf("");
+        return;
+    }
     const float* h2 = h2buf + b * (long)Npad * 128;
+    const bool wrap_small = Npad <= 2 * N;                  // a padding slot's index is below 2 N: one subtraction instead of a division
     const f32x4* pt = part + b * (long)tiles * 1024;
     const qf32x2* pt2 = part2 + b * (long)tiles * 1024;     // the fourth and fifth id-carrying scores: read only where the third is in range
     // ---- phase A
+    const bool stamps = DVQ_DIAG_ON && stats && (abl & 4096);   // diagnostics: cycles per phase (tid 0's clock), summed into stats[4..7]
+    unsigned long long tp0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull, tp1 = 0, tp2 = 0, tp3 = 0;
     unsigned n_single = 0, n_multi = 0, n_cand = 0, n_wave = 0, n_suspect = 0;
-    float lo_n[4], hi_n[4];                                 // the interval the records promise for (max - w.c) of channels tid + 256 i; lo > hi: not checked
-#pragma unroll
+    // the interval the records promise for (max - w.c) of channels tid + 256 i; lo > hi: not checked.  Eight scalars updated through
+    // selects: the channel loop below stays ROLLED (unrolled it was 12 k instructions, 80 KB of code for a 64 KB instruction cache
+    // shared by two CUs) without turning an indexed array into scratch memory.
+    float lo_0 = 1.f, lo_1 = 1.f, lo_2 = 1.f, lo_3 = 1.f, hi_0 = 0.f, hi_1 = 0.f, hi_2 = 0.f, hi_3 = 0.f;
+    // the next channel's records (the first four tiles' entries -- N <= 1024: all of them) and norms are requested before the current
+    // channel is worked on: one exposed trip to memory instead of four
+    f32x4 nf0 = pt[tid], nf1 = pt[min(1, tiles - 1) * 1024 + tid], nf2 = pt[min(2, tiles - 1) * 1024 + tid], nf3 = pt[min(3, tiles - 1) * 1024 + tid];
+    // (the fourth and fifth scores with them: read where the third is in range, that was a trip to memory inside the tile loop whenever
+    // ONE lane of the wave needed it -- most iterations)
+    qf32x2 ng0 = pt2[tid], ng1 = pt2[min(1, tiles - 1) * 1024 + tid], ng2 = pt2[min(2, tiles - 1) * 1024 + tid], ng3 = pt2[min(3, tiles - 1) * 1024 + tid];
+    float nwn = wnorm[tid], nrn = rnorm[tid];
+#pragma unroll 1
     for (int ci = 0; ci < 4; ++ci) {
         const int n = tid + 256 * ci;
-        lo_n[ci] = 1.f; hi_n[ci] = 0.f;
         best_k[n] = f2key(NEG_BIG);
-        const float wn = wnorm[n], rn = rnorm[n];
+        const float wn = nwn, rn = nrn;
+        const f32x4 f0 = nf0, f1 = nf1, f2 = nf2, f3 = nf3;
+        const qf32x2 g0 = ng0, g1 = ng1, g2 = ng2, g3 = ng3;
+        if (ci < 3) {
+            const int nx = n + 256;
+            nf0 = pt[nx]; nf1 = pt[min(1, tiles - 1) * 1024 + nx]; nf2 = pt[min(2, tiles - 1) * 1024 + nx]; nf3 = pt[min(3, tiles - 1) * 1024 + nx];
+            ng0 = pt2[nx]; ng1 = pt2[min(1, tiles - 1) * 1024 + nx]; ng2 = pt2[min(2, tiles - 1) * 1024 + nx]; ng3 = pt2[min(3, tiles - 1) * 1024 + nx];
+            nwn = wnorm[nx]; nrn = rnorm[nx];
+        }
         float lb, e_all;
         auto bound = [&](int t) { return fmaf(rn, dm[t], fmaf(wn, rd[t], fmaf(C_ID * wn, dm[t], 2.0f * DELTA * wn * hm[t]))); };
-        // the first four tiles' entries are loaded once (N <= 1024: all of them), the rest in blocks of four
-        const f32x4 f0 = pt[n], f1 = pt[min(1, tiles - 1) * 1024 + n], f2 = pt[min(2, tiles - 1) * 1024 + n],
-                    f3 = pt[min(3, tiles - 1) * 1024 + n];
+        // (tiles beyond the first four: in blocks of four, below)
         // a non-finite bound or top score in ANY tile sends the channel to the "everything" path (fmaxf drops a NaN: tested apart)
         bool nonfinite = false;
         float ub;
@@ -772,8 +798,8 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
             cand_n[n] = 0;
             continue;
         }
-        lo_n[ci] = lb; hi_n[ci] = ub;
-        auto consider = [&](int t, const f32x4& q) {
+        float lo_c = lb, hi_c = ub;
+        auto consider = [&](int t, const f32x4& q, const qf32x2& q45) {
             const float et = bound(t);
             const unsigned suspect = (__float_as_uint(q[3]) >> 16) & 1u;   // the trunk kernel did not trust its own merge: it flagged every group
             n_suspect += suspect;
@@ -781,13 +807,12 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
             // nothing about the tile and all its points are evaluated (a bogus top score that RAISES lb is caught by the check below)
             if (!suspect && !(q[0] + et >= lb)) return;
             unsigned flags = __float_as_uint(q[3]) & 0xFFFFu;   // one bit per 16-point group: 4 wave + 2 point block + lane half
-            auto take = [&](float v) {                       // a kept score in range: its point becomes a candidate of the channel
+            // a kept score in range: its point becomes a candidate of the channel.  (No search for a point that is already one: only
+            // padding slots repeat a point, a repeated candidate costs one more dot, and the search was a third of this phase.)
+            auto take = [&](float v) {
                 int p = point_of_slot(t, slot_of_id(__float_as_uint(v) & 255u), deal);
-                if (p >= N) p %= N;                          // a padding slot: the real point it repeats
+                if (p >= N) p = wrap_small ? p - N : p % N;  // a padding slot: the real point it repeats
                 if (abl & 16) p &= 63;
-                bool seen = false;                           // a repeated point (padding slots) is evaluated once
-                for (int c2 = 0; c2 < min(cands, 4); ++c2) seen = seen || cand[n][c2] == (unsigned short)p;
-                if (seen) return;
                 if (cands < 4) cand[n][cands] = (unsigned short)p;
                 else {
                     const int slot = atomicAdd(&pair_count, 1);
@@ -799,13 +824,13 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
                 }
                 ++cands;
             };
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                if (q[k] + et >= lb) take(q[k]);
-            if (q[2] + et >= lb) {                           // all three in range: the record's second part (descending: c4 >= c5)
-                const qf32x2 q45 = pt2[(long)t * 1024 + n];
-                if (q45[0] + et >= lb) take(q45[0]);
-                if (q45[1] + et >= lb) take(q45[1]);
+            // descending scores: the ones in range are a prefix of (c1 .. c5)
+            const float sc5[5] = {q[0], q[1], q[2], q45[0], q45[1]};
+#pragma unroll 1
+            for (int k = 0; k < 5; ++k) {
+                const float v = k == 0 ? sc5[0] : k == 1 ? sc5[1] : k == 2 ? sc5[2] : k == 3 ? sc5[3] : sc5[4];
+                if (!(v + et >= lb)) break;
+                take(v);
             }
             while (flags) {
                 const int wh = __ffs(flags) - 1;             // 4 * wave + 2 * point block + lane half
@@ -819,25 +844,36 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
                 ++n_wave;
             }
         };
-        consider(0, f0);
-        if (tiles > 1) consider(1, f1);
-        if (tiles > 2) consider(2, f2);
-        if (tiles > 3) consider(3, f3);
-        for (int t0 = 4; t0 < tiles; t0 += 4) {
-            f32x4 q0 = pt[min(t0, tiles - 1) * 1024 + n], q1 = pt[min(t0 + 1, tiles - 1) * 1024 + n];
-            f32x4 q2 = pt[min(t0 + 2, tiles - 1) * 1024 + n], q3 = pt[min(t0 + 3, tiles - 1) * 1024 + n];
-            consider(t0, q0);
-            if (t0 + 1 < tiles) consider(t0 + 1, q1);
-            if (t0 + 2 < tiles) consider(t0 + 2, q2);
-            if (t0 + 3 < tiles) consider(t0 + 3, q3);
+        // one copy of the code above for every tile (rolled: see lo_0 .. hi_3); tiles beyond the first four are loaded in blocks of four
+        f32x4 q0 = f0, q1 = f1, q2 = f2, q3 = f3;
+        qf32x2 h0 = g0, h1 = g1, h2q = g2, h3 = g3;
+#pragma unroll 1
+        for (int t0 = 0; t0 < tiles; t0 += 4) {
+            if (t0 > 0) {
+                q0 = pt[min(t0, tiles - 1) * 1024 + n]; q1 = pt[min(t0 + 1, tiles - 1) * 1024 + n];
+                q2 = pt[min(t0 + 2, tiles - 1) * 1024 + n]; q3 = pt[min(t0 + 3, tiles - 1) * 1024 + n];
+                h0 = pt2[min(t0, tiles - 1) * 1024 + n]; h1 = pt2[min(t0 + 1, tiles - 1) * 1024 + n];
+                h2q = pt2[min(t0 + 2, tiles - 1) * 1024 + n]; h3 = pt2[min(t0 + 3, tiles - 1) * 1024 + n];
+            }
+#pragma unroll 1
+            for (int u = 0; u < 4 && t0 + u < tiles; ++u) {
+                const f32x4 q = u == 0 ? q0 : u == 1 ? q1 : u == 2 ? q2 : q3;
+                const qf32x2 q45 = u == 0 ? h0 : u == 1 ? h1 : u == 2 ? h2q : h3;
+                consider(t0 + u, q, q45);
+            }
         }
         cand_n[n] = whole ? 0 : (unsigned char)min(cands, 4);
-        if (whole) { lo_n[ci] = 1.f; hi_n[ci] = 0.f; }      // evaluated in full below: nothing to check
+        if (whole) { lo_c = 1.f; hi_c = 0.f; }              // evaluated in full below: nothing to check
+        lo_0 = ci == 0 ? lo_c : lo_0; hi_0 = ci == 0 ? hi_c : hi_0;
+        lo_1 = ci == 1 ? lo_c : lo_1; hi_1 = ci == 1 ? hi_c : hi_1;
+        lo_2 = ci == 2 ? lo_c : lo_2; hi_2 = ci == 2 ? hi_c : hi_2;
+        lo_3 = ci == 3 ? lo_c : lo_3; hi_3 = ci == 3 ? hi_c : hi_3;
         n_single += cands == 1;
         n_multi += cands != 1;
         n_cand += cands;
     }
     __syncthreads();
+    if (stamps) tp1 = __builtin_amdgcn_s_memtime();
     // ---- phase A2: the pairs in POINT order (counting sort in the LDS).  A cloud's 1 024 channels take their maxima at ~100-200
     // distinct points, so ~1 500 candidate pairs name each conv2 row ~10 times: evaluated channel by channel every pair fetched
     // its 512-byte row from HBM again (0.74 MB per cloud, the kernel ran at the HBM roofline); grouped by point a row is
@@ -880,6 +916,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
             sorted[atomicAdd(&pcnt[(code >> 10) & 1023], 1)] = (unsigned)code;
         }
         __syncthreads();
+        if (stamps) tp2 = __builtin_amdgcn_s_memtime();
         // ---- phase B, point order: every 16-lane group takes a contiguous share of the list, four pairs in flight
         const int per = (total + 15) >> 4, i0 = g * per, i1 = min(total, i0 + per);
         for (int i = i0; i < i1; i += 4) {
@@ -951,6 +988,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
         const float v = exact_dot(*reinterpret_cast<const f32x4*>(wr), *reinterpret_cast<const f32x4*>(wr + 4), h2 + (long)(code >> 10) * 128, j);
         if (j == 0) atomicMax(&best_k[n], f2key(v));
     }
+    if (stamps) tp3 = __builtin_amdgcn_s_memtime();
     // ---- phase C: flagged 16-point groups, one wave of the workgroup per entry, its four 16-lane groups take 4 points each
     const int nfb = (abl & 32) ? 0 : min(fb_count, fb_cap);
     for (int i = tid >> 6; i < nfb; i += 4) {
@@ -994,6 +1032,10 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
                 const f32x4 ha = *reinterpret_cast<const f32x4*>(hr), hb = *reinterpret_cast<const f32x4*>(hr + 4);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) best[u] = max_nan(best[u], exact_dot_regs(w0[u], w1[u], ha, hb));
+                // a NaN stays a NaN (torch.max): four NaN maxima need no more points.  A cloud that is non-finite as a whole -- the row
+                // of a grasp whose decoder output left fp16's range, on its way to the per-row fallback of GenNet.gen -- sent ONE
+                // workgroup through 1 024 channels x all points, the straggler of its launch (20 ms at the benchmark's batch).
+                if (best[0] != best[0] && best[1] != best[1] && best[2] != best[2] && best[3] != best[3]) break;
             }
             if (j == 0) {
 #pragma unroll
@@ -1020,10 +1062,11 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
 #pragma unroll
     for (int ci = 0; ci < 4; ++ci) {
         const int n = tid + 256 * ci;
-        if (!(lo_n[ci] <= hi_n[ci])) continue;
+        const float lo_c = ci == 0 ? lo_0 : ci == 1 ? lo_1 : ci == 2 ? lo_2 : lo_3, hi_c = ci == 0 ? hi_0 : ci == 1 ? hi_1 : ci == 2 ? hi_2 : hi_3;
+        if (!(lo_c <= hi_c) || (abl & (16 | 64))) continue;   // (the timing ablations leave maxima that are not maxima)
         const float v = key2f(best_k[n]), wc = wcs[n];
         const float x = v - wc, slack = 4.0e-7f * (fabsf(v) + fabsf(wc));   // the subtraction's own rounding
-        if (!(x >= lo_n[ci] - slack && x <= hi_n[ci] + slack)) {
+        if (!(x >= lo_c - slack && x <= hi_c + slack)) {
             all_list[atomicAdd(&all_count, 1)] = (short)n;
             ++n_bad;
         }
@@ -1036,6 +1079,10 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
         const unsigned k = best_k[n];
         const float v = (k == 0xffffffffu ? __builtin_nanf("") : key2f(k)) + b3[n];
         feat[b * ld_feat + n] = relu ? (v != v ? v : fmaxf(v, 0.f)) : v;
+    }
+    if (stamps && tid == 0) {
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        atomicAdd(stats + 4, tp1 - tp0); atomicAdd(stats + 5, tp2 - tp1); atomicAdd(stats + 6, tp3 - tp2); atomicAdd(stats + 7, t_end - tp3);
     }
     if (stats) {
         if (n_single) atomicAdd(stats + 0, (unsigned long long)n_single);
@@ -1133,7 +1180,7 @@ __global__ __launch_bounds__(256) void pn_filter_pack_kernel(const float* __rest
 }
 
 // One wave per conv2 output channel (128 rows of 64): the two fp16 planes of w * 2^t_n (row maximum in [2^14, 2^15)) -- the second the
-// remainder * 2^11, as csrc/gemm_f16x2.hip's packer -- and 2^-t_n.
+// remainder as it is (csrc/gemm_f16x2.hip's packer scales it by 2^11 for a second accumulator; conv2 here has one) -- and 2^-t_n.
 __global__ __launch_bounds__(256) void pn_filter_pack_w2_kernel(const float* __restrict__ w2, _Float16* __restrict__ planes,
                                                                 float* __restrict__ kinv) {
     const int lane = threadIdx.x & 63;
@@ -1145,7 +1192,7 @@ __global__ __launch_bounds__(256) void pn_filter_pack_w2_kernel(const float* __r
     if (ex > 20 && ex < 235) t = __uint_as_float((unsigned)(127 + 15 - (ex - 126)) << 23);
     const float vs = v * t;
     const _Float16 p1 = (_Float16)vs;
-    const _Float16 p2 = (_Float16)((vs - (float)p1) * 2048.0f);
+    const _Float16 p2 = (_Float16)(vs - (float)p1);
     planes[n * 64 + lane] = p1;
     planes[128 * 64 + n * 64 + lane] = p2;
     if (lane == 0) kinv[n] = 1.0f / t;
@@ -1194,9 +1241,9 @@ int dvq_launch_pn_filter_front(const float* pc, int C, int N, int Npad, long B, 
     {
         const hipError_t e = attr_once.run([] {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_trunk_filter_kernel<3, false>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, DVQ_DIAG_ON ? 100 * 1024 : F_LDS);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_trunk_filter_kernel<4, false>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, DVQ_DIAG_ON ? 100 * 1024 : F_LDS);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_trunk_filter_kernel<3, true>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_TAIL);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pn_trunk_filter_kernel<4, true>),
@@ -1247,11 +1294,12 @@ int dvq_launch_pn_filter_front(const float* pc, int C, int N, int Npad, long B, 
 #endif
     {
         DVQ_PROF("pn_trunk", 2.0 * pts * (4.0 * 64 + 64.0 * 128 + 128.0 * 1024), pts * (16 + 512) + (double)grid * 16384, st);
+        const int lds_main = (abl & 524288) ? 100 * 1024 : F_LDS;   // diagnostics: ONE workgroup per CU (what a wave costs when it has its SIMD to itself)
         if (C == 3)
-            DVQ_LAUNCH((pn_trunk_filter_kernel<3, false>), dim3((unsigned)grid), dim3(256), F_LDS, st, pc, trans, N, Npad, tiles, deal, B, W1, b1,
+            DVQ_LAUNCH((pn_trunk_filter_kernel<3, false>), dim3((unsigned)grid), dim3(256), lds_main, st, pc, trans, N, Npad, tiles, deal, B, W1, b1,
                        b2, (const char*)w3f, h2buf, (f32x4*)part, part2, tstat, cbuf, abl);
         else
-            DVQ_LAUNCH((pn_trunk_filter_kernel<4, false>), dim3((unsigned)grid), dim3(256), F_LDS, st, pc, trans, N, Npad, tiles, deal, B, W1, b1,
+            DVQ_LAUNCH((pn_trunk_filter_kernel<4, false>), dim3((unsigned)grid), dim3(256), lds_main, st, pc, trans, N, Npad, tiles, deal, B, W1, b1,
                        b2, (const char*)w3f, h2buf, (f32x4*)part, part2, tstat, cbuf, abl);
         if (deal < tiles) {
             const unsigned tgrid = (unsigned)((B + 3) / 4);
@@ -1315,6 +1363,9 @@ int dvq_launch_pn_filter_back(int N, int Npad, long B, const void* w3f, const fl
         const double tot = (double)B * 1024;
         fprintf(stderr, "[dvq pn] B=%ld N=%d: one candidate %.4f, other counts %.4f of the channels, flagged 16-point groups %.5f per channel; %.3f candidate dots per channel\n",
                 B, N, h[0] / tot, h[1] / tot, h[2] / tot, h[3] / tot);
+        if (abl & 4096)
+            fprintf(stderr, "[dvq pn] exact stage, mean cycles per workgroup: records -> candidates %.0f, sort by point %.0f, candidate dots %.0f, flagged groups + checks + store %.0f\n",
+                    (double)h[4] / B, (double)h[5] / B, (double)h[6] / B, (double)h[7] / B);
     }
     return DVQ_OK;
 }

@@ -1373,10 +1373,11 @@ def test_gemm_tile_variants_agree_bitwise(tmp_path):
 
 
 def test_pointnet_large_clouds_nonfinite_inputs_and_missing_filter_image():
-    """N > 16384 runs the six-product trunk (the filter's tile records are sized for 64 tiles); NaN / Inf coordinates (ReLU =
-    fmaxf(x, 0) squashes a NaN in conv1/conv2, as in every kernel of this path; Inf survives) neither crash nor leak into the
-    neighbouring samples, and the filtered result still equals the exhaustive one bit for bit; a weights struct without filter
-    images (raw ABI users) selects the six-product trunk."""
+    """N > 16384 runs the six-product trunk (the filter's tile records are sized for 64 tiles); a cloud with a NaN / Inf
+    coordinate comes out NaN in every channel on the filtered path (what the reference's affine layers and torch.max make of it;
+    the trunk kernel flags the tile, pn_exact_kernel writes the NaNs without evaluating anything), neither crashes nor leaks into
+    the neighbouring samples, and filtered == exhaustive still holds; a weights struct without filter images (raw ABI users)
+    selects the six-product trunk."""
     net, _ = _pointnet(4, SEED + 9)
     big = gpu(synth.synthetic_clouds(1, 17000, seed=3, channels=4))
     f_big, _, _ = net(big)
@@ -1388,6 +1389,7 @@ def test_pointnet_large_clouds_nonfinite_inputs_and_missing_filter_image():
     feat, _, _ = net(x)
     ref, _, _ = net(x[:1].contiguous())
     assert torch.equal(feat[0], ref[0]) and torch.isfinite(feat[0]).all(), "a finite sample next to non-finite ones must not change"
+    assert bool(torch.isnan(feat[1:]).all()), "a cloud with a non-finite coordinate has NaN features (pointnet_encoder.py:156-158 on such an input)"
     feat_all, _, _ = _with_env("DVQ_PN_EXHAUSTIVE", "1", lambda: net(x))
     same = (feat == feat_all) | (torch.isnan(feat) & torch.isnan(feat_all))
     assert bool(same.all()), "non-finite inputs: filtered != exhaustive"
