@@ -636,8 +636,10 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// exact_dot: THE definition of a conv3 score on this path.  16 lanes per dot, lane j owns k = 8j .. 8j+7 (fixed FMA
-// order), then a 16-lane butterfly (every lane gets the same bits).
+// exact_dot: THE definition of a conv3 score on this path.  16 lanes per dot, lane j owns k = 4j .. 4j+3 and 64+4j .. 64+4j+3 (fixed
+// FMA order), then a 16-lane butterfly (every lane gets the same bits).  (The two 16-byte pieces of a lane are 256 B apart so that the
+// sixteen lanes of a load read 256 CONTIGUOUS bytes: with k = 8j .. 8j+7 -- until round 5 -- every load touched four cache lines
+// and used half of each, and the exact stage's candidate dots ran at what the CU's vector memory path gives to such gathers.)
 template <int CTRL>
 __device__ __forceinline__ float q_dpp(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
@@ -658,7 +660,7 @@ __device__ __forceinline__ float exact_dot_regs(const f32x4& w0, const f32x4& w1
     return s;
 }
 __device__ __forceinline__ float exact_dot(const f32x4& w0, const f32x4& w1, const float* __restrict__ hrow, int j) {
-    return exact_dot_regs(w0, w1, *reinterpret_cast<const f32x4*>(hrow + 8 * j), *reinterpret_cast<const f32x4*>(hrow + 8 * j + 4));
+    return exact_dot_regs(w0, w1, *reinterpret_cast<const f32x4*>(hrow + 4 * j), *reinterpret_cast<const f32x4*>(hrow + 4 * j + 64));
 }
 // torch.max semantics: a NaN wins
 __device__ __forceinline__ float max_nan(float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b); }
@@ -710,7 +712,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
     const int tid = threadIdx.x, g = tid >> 4, j = tid & 15;
     const long b = blockIdx.x;
     float* wcs = reinterpret_cast<float*>(pcnt);           // w_n . c per channel (consistency check): pcnt is dead once the pairs are sorted
-    const f32x4 cen_a = *reinterpret_cast<const f32x4*>(cbuf + b * 128 + 8 * j), cen_b = *reinterpret_cast<const f32x4*>(cbuf + b * 128 + 8 * j + 4);
+    const f32x4 cen_a = *reinterpret_cast<const f32x4*>(cbuf + b * 128 + 4 * j), cen_b = *reinterpret_cast<const f32x4*>(cbuf + b * 128 + 4 * j + 64);
     if (tid == 0) { pair_count = 0; fb_count = 0; all_count = 0; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) pcnt[tid + 256 * i] = 0;
@@ -926,18 +928,23 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
             for (int u = 0; u < 4; ++u) {
                 const unsigned code = sorted[min(i + u, i1 - 1)];
                 nn[u] = (int)(code & 1023u);
-                const float* wr = w3 + nn[u] * 128 + 8 * j;
+                const float* wr = w3 + nn[u] * 128 + 4 * j;
                 w0[u] = *reinterpret_cast<const f32x4*>(wr);
-                w1[u] = *reinterpret_cast<const f32x4*>(wr + 4);
-                const float* hr = h2 + (long)(code >> 10) * 128 + 8 * j;
+                w1[u] = *reinterpret_cast<const f32x4*>(wr + 64);
+                const float* hr = h2 + (long)(code >> 10) * 128 + 4 * j;
                 ha[u] = *reinterpret_cast<const f32x4*>(hr);
-                hb[u] = *reinterpret_cast<const f32x4*>(hr + 4);
+                hb[u] = *reinterpret_cast<const f32x4*>(hr + 64);
             }
+            float v[4], wc[4];                              // all eight chains first (independent: they interleave), the LDS updates after
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float v = exact_dot_regs(w0[u], w1[u], ha[u], hb[u]);
-                const float wc = exact_dot_regs(w0[u], w1[u], cen_a, cen_b);     // the centre term of this channel (check below)
-                if (j == 0 && i + u < i1) { atomicMax(&best_k[nn[u]], f2key(v)); wcs[nn[u]] = wc; }
+                v[u] = exact_dot_regs(w0[u], w1[u], ha[u], hb[u]);
+                wc[u] = exact_dot_regs(w0[u], w1[u], cen_a, cen_b);             // the centre term of this channel (check below)
+            }
+            if (j == 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i + u < i1) { atomicMax(&best_k[nn[u]], f2key(v[u])); wcs[nn[u]] = wc[u]; }
             }
         }
     }
@@ -950,12 +957,12 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
         for (int u = 0; u < 4; ++u) {
             const int n = n0 + 16 * u;
             cn[u] = cand_n[n];
-            const float* wr = w3 + n * 128 + 8 * j;
+            const float* wr = w3 + n * 128 + 4 * j;
             w0[u] = *reinterpret_cast<const f32x4*>(wr);
-            w1[u] = *reinterpret_cast<const f32x4*>(wr + 4);
-            const float* hr = h2 + (long)(cn[u] ? cand[n][0] : 0) * 128 + 8 * j;
+            w1[u] = *reinterpret_cast<const f32x4*>(wr + 64);
+            const float* hr = h2 + (long)(cn[u] ? cand[n][0] : 0) * 128 + 4 * j;
             ha[u] = *reinterpret_cast<const f32x4*>(hr);
-            hb[u] = *reinterpret_cast<const f32x4*>(hr + 4);
+            hb[u] = *reinterpret_cast<const f32x4*>(hr + 64);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -969,9 +976,9 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
 #pragma unroll
                 for (int k = 1; k < 4; ++k)
                     if (k < cn[u]) {
-                        const float* hr = h2 + (long)cand[n][k] * 128 + 8 * j;
+                        const float* hr = h2 + (long)cand[n][k] * 128 + 4 * j;
                         xa[k - 1] = *reinterpret_cast<const f32x4*>(hr);
-                        xb[k - 1] = *reinterpret_cast<const f32x4*>(hr + 4);
+                        xb[k - 1] = *reinterpret_cast<const f32x4*>(hr + 64);
                     }
 #pragma unroll
                 for (int k = 1; k < 4; ++k)
@@ -984,8 +991,8 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
     for (int i = g; i < (by_point ? 0 : npairs); i += 16) {
         const int code = pair_list[i];
         const int n = code & 1023;
-        const float* wr = w3 + n * 128 + 8 * j;
-        const float v = exact_dot(*reinterpret_cast<const f32x4*>(wr), *reinterpret_cast<const f32x4*>(wr + 4), h2 + (long)(code >> 10) * 128, j);
+        const float* wr = w3 + n * 128 + 4 * j;
+        const float v = exact_dot(*reinterpret_cast<const f32x4*>(wr), *reinterpret_cast<const f32x4*>(wr + 64), h2 + (long)(code >> 10) * 128, j);
         if (j == 0) atomicMax(&best_k[n], f2key(v));
     }
     if (stamps) tp3 = __builtin_amdgcn_s_memtime();
@@ -994,8 +1001,8 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
     for (int i = tid >> 6; i < nfb; i += 4) {
         const int code = fb_list[i];
         const int n = code & 1023, t = (code >> 10) & 1023, w = (code >> 22) & 3, pb = (code >> 21) & 1, hh = (code >> 20) & 1;
-        const float* wr = w3 + n * 128 + 8 * j;
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr), w1 = *reinterpret_cast<const f32x4*>(wr + 4);
+        const float* wr = w3 + n * 128 + 4 * j;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr), w1 = *reinterpret_cast<const f32x4*>(wr + 64);
         float best = NEG_BIG;
         {
             f32x4 ha[4], hb[4];
@@ -1004,9 +1011,9 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
                 const int e = 4 * (g & 3) + u;
                 int p = point_of_slot(t, 64 * w + 32 * pb + 8 * (e >> 2) + 4 * hh + (e & 3), deal);   // tail tile: one block, pb = 0
                 if (p >= N) p %= N;
-                const float* hr = h2 + (long)p * 128 + 8 * j;
+                const float* hr = h2 + (long)p * 128 + 4 * j;
                 ha[u] = *reinterpret_cast<const f32x4*>(hr);
-                hb[u] = *reinterpret_cast<const f32x4*>(hr + 4);
+                hb[u] = *reinterpret_cast<const f32x4*>(hr + 64);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) best = fmaxf(best, exact_dot_regs(w0, w1, ha[u], hb[u]));
@@ -1023,13 +1030,13 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int n = all_list[min(i + u, count - 1)];
-                w0[u] = *reinterpret_cast<const f32x4*>(w3 + n * 128 + 8 * j);
-                w1[u] = *reinterpret_cast<const f32x4*>(w3 + n * 128 + 8 * j + 4);
+                w0[u] = *reinterpret_cast<const f32x4*>(w3 + n * 128 + 4 * j);
+                w1[u] = *reinterpret_cast<const f32x4*>(w3 + n * 128 + 4 * j + 64);
                 best[u] = NEG_BIG;
             }
             for (int p = g; p < N; p += 16) {
-                const float* hr = h2 + (long)p * 128 + 8 * j;
-                const f32x4 ha = *reinterpret_cast<const f32x4*>(hr), hb = *reinterpret_cast<const f32x4*>(hr + 4);
+                const float* hr = h2 + (long)p * 128 + 4 * j;
+                const f32x4 ha = *reinterpret_cast<const f32x4*>(hr), hb = *reinterpret_cast<const f32x4*>(hr + 64);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) best[u] = max_nan(best[u], exact_dot_regs(w0[u], w1[u], ha, hb));
                 // a NaN stays a NaN (torch.max): four NaN maxima need no more points.  A cloud that is non-finite as a whole -- the row
