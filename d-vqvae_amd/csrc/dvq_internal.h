@@ -31,6 +31,17 @@ __device__ __forceinline__ void dvq_dma_barrier() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 }
+// Workgroup barrier with the wave's own LDS operations COMPLETE before it arrives, spelled out.  __syncthreads() is supposed to
+// imply it, and the compiler normally emits "s_waitcnt lgkmcnt(0)" in front of s_barrier -- but not always: in pn_trunk3_kernel
+// (round 5) the barrier at the head of the conv3 loop came out WITHOUT the wait although the back edge carries LDS stores (the next
+// chunk's W3 rows, the ring pairs).  A wave then passes the barrier with its stores still in flight, its neighbours read the old
+// contents -- nothing at one workgroup per CU, where the four waves run in step, a wrong tile record every few thousand tiles as soon
+// as workgroups share a CU.  (This is the shape of the round-3 fault of pn_trunk_filter_kernel, whose barrier has the wait in the
+// current build.)  Every barrier that orders LDS traffic in the PointNet kernels goes through here.
+__device__ __forceinline__ void dvq_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
 #endif
 
 void dvq_set_error(const char* fmt, ...);
@@ -214,6 +225,7 @@ struct DvqKnobs {
     int pn_exhaustive;    // 1: exact stage evaluates every point (what the filter must reproduce bit for bit)
     int pn_caps[2];       // candidate-list capacities (tests shrink them to reach the overflow paths); <= 0: default
     long pn_chunk;        // samples per PointNet launch (<= 0: at most 4 096, at least four launches per pass; DVQ_PN_CHUNK)
+    int pn_trunk3;        // DVQ_PN_TRUNK3=1: full tiles on pn_trunk3_kernel (three workgroups per CU; measured 4.5 % slower); default 0: pn_trunk_filter_kernel (two)
     int pn_streams;       // 1 (default): the exact stage / STN FCs of a launch on a second stream beside the next launch's trunk kernel (DVQ_PN_STREAMS=0: one stream)
     int pn_slots;         // scratch sets the launches rotate through (<= 0: 2; DVQ_PN_SLOTS)
     int pn_stats;

@@ -159,6 +159,36 @@ __device__ __forceinline__ int slot_of_id(unsigned id) {
     return w * 64 + pb * 32 + 8 * (e >> 2) + 4 * h + (e & 3);
 }
 
+// Wave reductions without ds_bpermute (__shfl_xor: an LDS-crossbar instruction, an lgkmcnt wait and an address register per pattern):
+// lanes l and l ^ 32 through v_permlane32_swap, rows through DPP, the four rows through v_readlane.
+__device__ __forceinline__ float g_half_sum(float v) {    // v[l] + v[l ^ 32], in every lane
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float g_half_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+template <int CTRL>
+__device__ __forceinline__ float g_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float g_wave_max(float v) {    // uniform result
+    v = fmaxf(v, g_dpp<0xB1>(v));
+    v = fmaxf(v, g_dpp<0x4E>(v));
+    v = fmaxf(v, g_dpp<0x141>(v));
+    v = fmaxf(v, g_dpp<0x140>(v));                         // every lane: the maximum of its row of 16
+    v = g_half_max(v);                                     // rows 0 | 2, 1 | 3
+    return fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16)));
+}
+__device__ __forceinline__ float g_wave_sum(float v) {    // uniform result
+    v += g_dpp<0xB1>(v);
+    v += g_dpp<0x4E>(v);
+    v += g_dpp<0x141>(v);
+    v += g_dpp<0x140>(v);
+    v = g_half_sum(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+}
 // TAIL = false: one workgroup per (sample, dealt tile), blockIdx.x = sample * deal + tile (no workgroup for a tail tile: launched
 // and left at once they would all sit on two of the eight XCDs -- blockIdx % 4 == 3 -- and idle a quarter of the chip).  TAIL = true: the tail tiles of FOUR samples per workgroup, one per wave (one 32-point block each;
 // the staged W2 / W3 images are shared, everything per sample is per wave: centre, scales, records).
@@ -182,6 +212,11 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
+    // The lane half enters the LDS addresses of the small tables through an opaque copy: knowing h in {0, 1}, the compiler turns
+    // "base + 32 h + constant" into "(base | 32 h) | constant", cannot fold the constant into the instruction's offset field any more
+    // and keeps one address REGISTER per constant -- 32 of them for conv1's weights alone, live across both point blocks.
+    int h_op = h;
+    asm("" : "+v"(h_op));
     constexpr int NPB = TAIL ? 1 : 2;                       // 32-point blocks per wave
     const long b_raw = TAIL ? (long)blockIdx.x * 4 + wave : (long)(blockIdx.x / deal);
     const bool live = !TAIL || b_raw < B;                  // tail: the last workgroup's surplus waves work on sample B - 1, store nothing
@@ -242,10 +277,8 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     if (abl & 4096) t_a = __builtin_amdgcn_s_memtime();
     float cnorm;                                          // |c| (every wave for itself: no ordering between the waves needed)
     {
-        float cq = fmaf(cs[lane], cs[lane], cs[64 + lane] * cs[64 + lane]);
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) cq += __shfl_xor(cq, o);
-        cnorm = sqrtf(cq) * 1.0001f;
+        const float cq = fmaf(cs[lane], cs[lane], cs[64 + lane] * cs[64 + lane]);
+        cnorm = sqrtf(g_wave_sum(cq)) * 1.0001f;
     }
 
     // ---- conv1 + conv2, h2 = relu(conv2 + b2) kept in fp32: hv[pb][16 t4 + e].  conv2 runs on the fp16 THREE-product split of
@@ -268,9 +301,8 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int k = 16 * s + 8 * h + j;
-                const f32x4 w = *reinterpret_cast<const f32x4*>(w1s + 4 * k);
-                float a = fmaf(xin[pb][0], w[0], b1s[k]);
+                const f32x4 w = *reinterpret_cast<const f32x4*>(w1s + 32 * h_op + 64 * s + 4 * j);   // row k = 16 s + 8 h + j
+                float a = fmaf(xin[pb][0], w[0], (b1s + 8 * h_op)[16 * s + j]);
                 a = fmaf(xin[pb][1], w[1], a);
                 a = fmaf(xin[pb][2], w[2], a);
                 if constexpr (C > 3) a = fmaf(xin[pb][3], w[3], a);
@@ -279,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
 #pragma unroll
             for (int j = 0; j < 8; j += 2) amax = fmaxf(fmaxf(amax, v[s][j]), v[s][j + 1]);   // v_max3_f32 (a NaN is dropped here and reaches the products through the pieces)
         }
-        amax = fmaxf(amax, __shfl_xor(amax, 32));          // the lane halves hold the two halves of a point's 64 activations
+        amax = g_half_max(amax);                          // the lane halves hold the two halves of a point's 64 activations
         float s_p = 1.f, r_p = 1.f;
         {
             const int ex = (int)((__float_as_uint(amax) >> 23) & 255u);              // amax in [2^(ex-127), 2^(ex-126))
@@ -311,8 +343,8 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
             for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1f[s], h1a[s], acc, 0, 0, 0);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int ch = 32 * t4 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                hv[pb][16 * t4 + e] = fmaxf(fmaf(acc[e] * r_p, k2s[ch], b2s[ch]), 0.f);
+                const int ch = 32 * t4 + (e & 3) + 8 * (e >> 2);       // + 4 h
+                hv[pb][16 * t4 + e] = fmaxf(fmaf(acc[e] * r_p, (k2s + 4 * h_op)[ch], (b2s + 4 * h_op)[ch]), 0.f);
             }
             if (pidx[pb] < N && live && !(abl & 1)) {     // natural channel order: 4 consecutive channels per 16-byte store
                 float* dst = h2buf + ((b * Npad + pidx[pb]) * 128 + 32 * t4 + 4 * h);
@@ -330,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 c4 = *reinterpret_cast<const f32x4*>(cs + 32 * t4 + 8 * g + 4 * h);
+            const f32x4 c4 = *reinterpret_cast<const f32x4*>(cs + 4 * h_op + 32 * t4 + 8 * g);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -342,10 +374,10 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         float sq = 0.f;
 #pragma unroll
         for (int i = 0; i < 64; ++i) sq = fmaf(hv[pb][i], hv[pb][i], sq);
-        sq += __shfl_xor(sq, 32);                         // the two lane halves hold the two halves of a point's channels
+        sq = g_half_sum(sq);                              // the two lane halves hold the two halves of a point's channels
         dn2 = fmaxf(dn2, sq);
     }
-    dn2 = wave_max(dn2);
+    dn2 = g_wave_max(dn2);
     // per-wave power-of-two scale: (largest row norm) * s in [2^14, 2^15) -- every element is at most its row's norm
     float s_w = 1.f;
     const float dnorm = sqrtf(dn2) * 1.0001f;
@@ -378,10 +410,10 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
             }
             a3[pb][st] = __builtin_bit_cast(qf16x8, uint4{pk[0], pk[1], pk[2], pk[3]});
         }
-        sq += __shfl_xor(sq, 32);
+        sq = g_half_sum(sq);
         rn2 = fmaxf(rn2, sq);
     }
-    rn2 = wave_max(rn2);
+    rn2 = g_wave_max(rn2);
     // conv3's first W3 chunk: requested BEFORE the three atomics below -- the wait for these loads then leaves the atomics (younger,
     // in the in-order counter) pending instead of sitting out their round trip (600 .. 3 000 cycles each under load)
     const char* w3h = w3f;
@@ -399,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
             atomicMax(tstat + 4 * rec + 2, __float_as_uint(rdm));
         }
     }
-    __syncthreads();                                      // everybody is done with W2 in the stages; scs visible
+    dvq_lds_barrier();                                      // everybody is done with W2 in the stages; scs visible
     if (abl & 4096) t_c = __builtin_amdgcn_s_memtime();
 
     // ---- conv3, filtered: 16 chunks of 64 channels, one fp16 product, top two scores per channel and 16-point group
@@ -535,12 +567,12 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         // eight chunks of ITS sample after chunk 7 and after chunk 15
 #pragma unroll 1
         for (int c = 0; c < 16; ++c) {
-            __syncthreads();                              // chunk c is in its stage; the other stage and tb parity are free
+            dvq_lds_barrier();                              // chunk c is in its stage; the other stage and tb parity are free
             if (c + 1 < 16) wreg = w3_load(w3h, 64 * (c + 1), wave, lane);
             if ((c & 3) == 0 && c > 0) {                  // the ring's four chunks are complete (barrier above)
 #pragma unroll 1
                 for (int q = c - 4; q < c; ++q) publish(q);
-                __syncthreads();                          // before this chunk's pairs overwrite slot 0
+                dvq_lds_barrier();                          // before this chunk's pairs overwrite slot 0
             }
             const char* st = fl + stage * F_STAGE3;
             qf16x8 wf0[8], wf1[8];
@@ -565,11 +597,11 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     bool pending = false;
 #pragma unroll 1
     for (int c = 0; c < ((abl & 2) ? 0 : 16); ++c) {
-        if (!(abl & 16384)) __syncthreads();              // chunk c is in its stage; the other stage and tb parity are free
+        if (!(abl & 16384)) dvq_lds_barrier();              // chunk c is in its stage; the other stage and tb parity are free
         if (c + 1 < 16 && !(abl & 1024)) wreg = w3_load(w3h, 64 * (c + 1), wave, lane);
         if ((c & 3) == 0 && c > 0 && !(abl & 256)) {        // the ring's four chunks are complete (barrier above): one per wave
             publish(c - 4 + wave);
-            __syncthreads();                              // before this chunk's pairs overwrite slot 0
+            dvq_lds_barrier();                              // before this chunk's pairs overwrite slot 0
         }
         const char* st = fl + stage * F_STAGE3;
         qf16x8 wf0[8], wf1[8];
@@ -617,7 +649,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
 #undef F_MFMA_BLOCK
 #undef F_CHAIN_BLOCK
 #undef F_INTERLEAVE
-    __syncthreads();
+    dvq_lds_barrier();
     if constexpr (TAIL) {
 #pragma unroll 1
         for (int q = 12; q < 16; ++q) publish(q);
@@ -633,6 +665,384 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
             tstat[4 * rec + 3] = (unsigned)((t_end - t_start) * 100ull / (r_end - r_start + 1));
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// pn_trunk3_kernel: the full-tile trunk kernel laid out for THREE workgroups per CU (<= 168 registers, <= 53 KB of LDS); same
+// arithmetic for conv1 / conv2 / h2, same record format, same run-time checks as pn_trunk_filter_kernel<C, false>.  What differs:
+//   * conv3 in 32 chunks of 32 channels (two 8 KB W3 stages instead of two of 16 KB; 32 fragment registers instead of 64; two
+//     accumulator blocks in flight instead of three);
+//   * the ring holds eight small chunks (32 KB as before); after chunks 7, 15, 23, 31 every wave publishes TWO of them (lanes 0..31
+//     one, 32..63 the other: 64 consecutive channels, every lane busy);
+//   * 1 / scale and the two weight norms of a publishing lane's channel come from the image in L2, requested a chunk ahead (the
+//     8 KB of LDS tables are what did not fit); 2 E is four FMAs per publish;
+//   * the two point blocks of a wave go through conv1 / conv2 / centring / conversion one after the other, each with its OWN
+//     power-of-two scale (the exact stage never sees the scale: records are published in real units).
+constexpr int G_STAGE = 32 * 256;                         // one 32-channel chunk of the W3 image
+constexpr int G_OFF_TB = 2 * G_STAGE;                     // ring: [8 small chunks][4 waves][2 point blocks][2 halves][2][32] fp32
+constexpr int G_SLOT = 4 * 2 * 2 * 2 * 32;                // floats per small chunk
+constexpr int G_OFF_W1 = G_OFF_TB + 8 * G_SLOT * 4;       // 48 KB: [64][4]
+constexpr int G_OFF_B1 = G_OFF_W1 + 1024;
+constexpr int G_OFF_B2 = G_OFF_B1 + 256;
+constexpr int G_OFF_K2 = G_OFF_B2 + 512;
+constexpr int G_OFF_CS = G_OFF_K2 + 512;
+constexpr int G_OFF_SC = G_OFF_CS + 512;                  // [4][2] 1 / (point block scale)
+constexpr int G_OFF_WS = G_OFF_SC + 64;                   // [3][4] per-wave |h|max, |d|max, |rd|max
+constexpr int G_LDS = G_OFF_WS + 64;                      // 52 096 B -> 3 workgroups per CU
+static_assert(G_OFF_W1 >= 2 * F_STAGE2, "the stages and the ring cover the W2 region");
+static_assert(3 * G_LDS <= 160 * 1024, "three workgroups per CU");
+constexpr int pn_g_lds() { return G_LDS; }
+
+#ifndef PN3_WGS
+#define PN3_WGS 3
+#endif
+struct W3Half { uint4 a, b; };
+__device__ __forceinline__ W3Half g_w3_load(const char* __restrict__ w3h, int ch0, int wave, int lane) {
+    W3Half v;
+    const int row = wave * 8 + (lane >> 4);
+    v.a = *reinterpret_cast<const uint4*>(w3h + (long)(ch0 + row) * 256 + 16 * (lane & 15));
+    v.b = *reinterpret_cast<const uint4*>(w3h + (long)(ch0 + row + 4) * 256 + 16 * (lane & 15));
+    return v;
+}
+__device__ __forceinline__ void g_w3_store(char* stage, int wave, int lane, const W3Half& v) {
+    const int row = wave * 8 + (lane >> 4);
+    *reinterpret_cast<uint4*>(stage + row * 256 + 16 * ((lane & 15) ^ (row & 15))) = v.a;
+    *reinterpret_cast<uint4*>(stage + (row + 4) * 256 + 16 * ((lane & 15) ^ ((row + 4) & 15))) = v.b;
+}
+
+template <int C>
+__global__ __launch_bounds__(256, PN3_WGS) void pn_trunk3_kernel(const float* __restrict__ pc, const float* __restrict__ trans,
+                                                           int N, int Npad, int tiles, int deal, long B, const float* __restrict__ W1,
+                                                           const float* __restrict__ b1, const float* __restrict__ b2,
+                                                           const char* __restrict__ w3f, float* __restrict__ h2buf,
+                                                           f32x4* __restrict__ part, qf32x2* __restrict__ part2,
+                                                           unsigned* __restrict__ tstat, const float* __restrict__ cbuf,
+                                                           int abl_arg /* fault injection only (DVQ_PN_ABL, -DDVQ_DIAG builds) */) {
+    const int abl = DVQ_DIAG_ON ? abl_arg : 0;
+    extern __shared__ __attribute__((aligned(16))) char fl[];
+    float* tb = reinterpret_cast<float*>(fl + G_OFF_TB);
+    float* w1s = reinterpret_cast<float*>(fl + G_OFF_W1);
+    float* b1s = reinterpret_cast<float*>(fl + G_OFF_B1);
+    float* b2s = reinterpret_cast<float*>(fl + G_OFF_B2);
+    float* k2s = reinterpret_cast<float*>(fl + G_OFF_K2);
+    float* cs = reinterpret_cast<float*>(fl + G_OFF_CS);
+    float* scs = reinterpret_cast<float*>(fl + G_OFF_SC);
+    float* wst = reinterpret_cast<float*>(fl + G_OFF_WS);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    // The lane half enters the LDS addresses of the small tables through an opaque copy: knowing h in {0, 1}, the compiler turns
+    // "base + 32 h + constant" into "(base | 32 h) | constant", cannot fold the constant into the instruction's offset field any more
+    // and keeps one address REGISTER per constant -- 32 of them for conv1's weights alone, live across both point blocks.
+    int h_op = h;
+    asm("" : "+v"(h_op));
+    const float* w1h = w1s + 32 * h_op;
+    const float* b1h = b1s + 8 * h_op;
+    const float* k2h = k2s + 4 * h_op;
+    const float* b2h = b2s + 4 * h_op;
+    const float* csh = cs + 4 * h_op;
+    const long b = (long)(blockIdx.x / deal);
+    const int tile = (int)(blockIdx.x % deal);
+    const long rec = b * tiles + tile;                     // (sample, tile) record
+
+    const uint16_t* w2pl = reinterpret_cast<const uint16_t*>(w3f + IMG_OFF_W2);
+    w2_issue(w2pl, 0, fl, wave, lane);
+    w2_issue(w2pl, 64, fl + F_STAGE2, wave, lane);
+    if (tid < 128) k2s[tid] = reinterpret_cast<const float*>(w3f + IMG_OFF_K2)[tid];
+    w1s[tid] = W1[tid];
+    if (tid < 64) b1s[tid] = b1[tid];
+    if (tid < 128) b2s[tid] = b2[tid];
+    if (tid < 128) cs[tid] = cbuf[b * 128 + tid];
+
+    float xin[2][4];
+    int pidx[2];
+    bool badpt = false;
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+        int p = point_of_slot(tile, wave * 64 + pb * 32 + r, deal);
+        pidx[pb] = p;
+        if (p >= N) p %= N;                               // padding slots repeat real points cyclically
+        const float* src = pc + b * (long)C * N + p;
+        float x0 = src[0], x1 = src[N], x2 = src[2L * N];
+        const float x3 = (C > 3) ? src[3L * N] : 0.f;
+        if (trans) {                                      // xyz @ trans[b]  (pointnet_encoder.py:146)
+            const float* t = trans + b * 9;
+            const float n0 = fmaf(x2, t[6], fmaf(x1, t[3], x0 * t[0]));
+            const float n1 = fmaf(x2, t[7], fmaf(x1, t[4], x0 * t[1]));
+            const float n2 = fmaf(x2, t[8], fmaf(x1, t[5], x0 * t[2]));
+            x0 = n0; x1 = n1; x2 = n2;
+        }
+        xin[pb][0] = x0; xin[pb][1] = x1; xin[pb][2] = x2; xin[pb][3] = x3;
+        badpt = badpt || !(fabsf(x0) < 3.0e38f) || !(fabsf(x1) < 3.0e38f) || !(fabsf(x2) < 3.0e38f) || !(fabsf(x3) < 3.0e38f);   // see pn_trunk_filter_kernel
+    }
+    dvq_dma_barrier();                                    // W1/b1/b2/centre visible, W2 planes landed
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // (the compiler's counter model must see it: pn_trunk_filter_kernel)
+    float cnorm;                                          // |c|
+    {
+        const float cq = fmaf(cs[lane], cs[lane], cs[64 + lane] * cs[64 + lane]);
+        cnorm = sqrtf(g_wave_sum(cq)) * 1.0001f;
+    }
+
+    // ---- per point block: conv1, conv2 (three fp16 products, one accumulator), h2 to HBM, centring, norms, fp16 conversion
+    qf16x8 a3[2][8];
+    float dn2 = 0.f, rd2 = 0.f;                            // largest squared row norm of d; of the rounding residual in REAL units
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) {
+        // ONE point block at a time: left alone the compiler starts the second block's conv1 under the first block's MFMAs and
+        // spills its 32 activations (70 registers to scratch at the 168 this kernel may use)
+        asm volatile("" : "+v"(xin[pb][0]), "+v"(xin[pb][1]), "+v"(xin[pb][2]), "+v"(xin[pb][3]) : : "memory");
+        float v[4][8];
+        float amax = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(w1h + 64 * s + 4 * j);   // row k = 16 s + 8 h + j
+                float a = fmaf(xin[pb][0], w[0], b1h[16 * s + j]);
+                a = fmaf(xin[pb][1], w[1], a);
+                a = fmaf(xin[pb][2], w[2], a);
+                if constexpr (C > 3) a = fmaf(xin[pb][3], w[3], a);
+                v[s][j] = fmaxf(a, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) amax = fmaxf(fmaxf(amax, v[s][j]), v[s][j + 1]);
+        }
+        amax = g_half_max(amax);                          // the lane halves hold the two halves of a point's 64 activations
+        float s_p = 1.f, r_p = 1.f;
+        {
+            const int ex = (int)((__float_as_uint(amax) >> 23) & 255u);
+            if (ex > 20 && ex < 235) {
+                s_p = __uint_as_float((unsigned)(127 + 15 - (ex - 126)) << 23);
+                r_p = __uint_as_float((unsigned)(127 - 15 + (ex - 126)) << 23);
+            }
+        }
+        qf16x8 h1a[4], h1b[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) q_split2(v[s], s_p, h1a[s], h1b[s]);
+        float hv[64];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const char* st = fl + (t4 >> 1) * F_STAGE2;
+            const int row = 32 * (t4 & 1) + r;
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const qf16x8 w1f = w2_frag(st, 0, row, 2 * s + h), w2f = w2_frag(st, 1, row, 2 * s + h);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2f, h1a[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1f, h1b[s], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)                    // (the first plane's fragments once more from the LDS: 16 registers less)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2_frag(st, 0, row, 2 * s + h), h1a[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ch = 32 * t4 + (e & 3) + 8 * (e >> 2);       // + 4 h
+                hv[16 * t4 + e] = fmaxf(fmaf(acc[e] * r_p, k2h[ch], b2h[ch]), 0.f);
+            }
+            if (pidx[pb] < N) {                           // natural channel order: 4 consecutive channels per 16-byte store
+                float* dst = h2buf + ((b * Npad + pidx[pb]) * 128 + 32 * t4 + 4 * h);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(dst + 8 * g) = f32x4{hv[16 * t4 + 4 * g], hv[16 * t4 + 4 * g + 1], hv[16 * t4 + 4 * g + 2], hv[16 * t4 + 4 * g + 3]};
+            }
+            // centre these 16 channels at once
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(csh + 32 * t4 + 8 * g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hv[16 * t4 + 4 * g + i] -= c4[i];
+            }
+        }
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) sq = fmaf(hv[i], hv[i], sq);
+        sq = g_half_sum(sq);                              // the two lane halves hold the two halves of a point's channels
+        const float dn2_pb = g_wave_max(sq);
+        dn2 = fmaxf(dn2, dn2_pb);
+        // this point block's power-of-two scale: (largest row norm) * s in [2^14, 2^15)
+        float s_w = 1.f;
+        {
+            const float dnorm = sqrtf(dn2_pb) * 1.0001f;
+            const int ex = (int)((__float_as_uint(dnorm) >> 23) & 255u);
+            if (ex > 20 && ex < 235) s_w = __uint_as_float((unsigned)(127 + 15 - (ex - 126)) << 23);
+        }
+        float rq = 0.f;
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            unsigned pk[4];
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+                const float d0 = hv[8 * st + 2 * j2], d1 = hv[8 * st + 2 * j2 + 1];
+                asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "=v"(pk[j2]) : "v"(d0), "v"(s_w));
+                asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[0,0,0]" : "+v"(pk[j2]) : "v"(d1), "v"(s_w));
+                float r0, r1;
+                asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(d0), "v"(s_w), "v"(pk[j2]));
+                asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(d1), "v"(s_w), "v"(pk[j2]));
+                rq = fmaf(r0, r0, rq);
+                rq = fmaf(r1, r1, rq);
+            }
+            a3[pb][st] = __builtin_bit_cast(qf16x8, uint4{pk[0], pk[1], pk[2], pk[3]});
+        }
+        rq = g_half_sum(rq);
+        const float inv = 1.0f / s_w;                     // a power of two
+        rd2 = fmaxf(rd2, g_wave_max(rq) * inv * inv);
+        if (lane == 0) scs[wave * 2 + pb] = inv;
+        // the second half of the first block's fp16 rows waits in the upper half of the ring (idle until chunk 4; the W2 planes end
+        // below it) while the second block is worked on: 16 registers the second block's conv2 needs
+        uint4* park = reinterpret_cast<uint4*>(fl + 32768 + (wave * 64 + lane) * 64);
+        if (pb == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) park[i] = __builtin_bit_cast(uint4, a3[0][4 + i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a3[0][4 + i] = __builtin_bit_cast(qf16x8, park[i]);
+        }
+    }
+    // conv3's first W3 chunk: requested BEFORE the three atomics below (their round trip would sit in front of it in the in-order counter)
+    const char* w3h = w3f;
+    W3Half wreg = g_w3_load(w3h, 0, wave, lane);
+    const bool any_bad = __any(badpt);
+    if (lane == 0) {              // per-tile maxima; non-negative floats (and NaN, above all of them) order as integers
+        const float dmx = sqrtf(dn2), rdm = sqrtf(rd2);
+        const float hm = (dmx + cnorm) * 1.0001f;          // |h_p| <= |h_p - c| + |c|
+        wst[wave] = hm; wst[4 + wave] = dmx; wst[8 + wave] = rdm;
+        if (any_bad) atomicMax(tstat + 4 * rec + 3, 1u);
+        atomicMax(tstat + 4 * rec + 0, __float_as_uint(hm));
+        atomicMax(tstat + 4 * rec + 1, __float_as_uint(dmx));
+        atomicMax(tstat + 4 * rec + 2, __float_as_uint(rdm));
+    }
+    dvq_lds_barrier();                                      // everybody is done with W2 in the stages; scs / wst visible
+    g_w3_store(fl, wave, lane, wreg);
+    // the tile's maxima (uniform) for 2 E
+    const float t_hm = fmaxf(fmaxf(wst[0], wst[1]), fmaxf(wst[2], wst[3])) * 1.00001f;
+    const float t_dmx = fmaxf(fmaxf(wst[4], wst[5]), fmaxf(wst[6], wst[7])) * 1.00001f;
+    const float t_rdm = fmaxf(fmaxf(wst[8], wst[9]), fmaxf(wst[10], wst[11])) * 1.00001f;
+    const float* tinv_g = reinterpret_cast<const float*>(w3f + IMG_OFF_TI);
+    const float* wnorm_g = reinterpret_cast<const float*>(w3f + IMG_OFF_WN);
+    const float* rnorm_g = reinterpret_cast<const float*>(w3f + IMG_OFF_RN);
+    float p_ti = 0.f, p_wn = 0.f, p_rn = 0.f;             // of the channel this lane publishes next (requested a chunk ahead)
+
+    // publish the eight small chunks cbase .. cbase + 7: wave w the two chunks cbase + 2 w, + 2 w + 1 = channels n0 .. n0 + 63
+    auto publish = [&](int cbase) {
+        const int n = 32 * cbase + 64 * wave + lane;
+        const float* src = tb + ((cbase + 2 * wave + (lane >> 5)) & 7) * G_SLOT + (lane & 31);
+        float t1[16], t2[16];
+#pragma unroll
+        for (int gi = 0; gi < 16; ++gi) {                 // group gi = 4 w + 2 pb + hh
+            t1[gi] = src[gi * 64];
+            t2[gi] = src[gi * 64 + 32];
+        }
+        // run-time check of the hand-over (pn_trunk_filter_kernel): finish() stamps bits [6:5] with (chunk / 8) mod 4
+        const unsigned want = (unsigned)(((cbase >> 3) & 3) << 5);
+        unsigned tagdiff = 0;
+#pragma unroll
+        for (int gi = 0; gi < 16; gi += 2)
+            tagdiff = tagdiff | (__float_as_uint(t1[gi]) ^ want) | (__float_as_uint(t1[gi]) ^ __float_as_uint(t1[gi + 1]));
+        const bool suspect = (tagdiff & 0x60u) != 0;
+#pragma unroll
+        for (int gi = 0; gi < 16; ++gi) {
+            const float sc = scs[gi >> 1] * p_ti;          // 1 / (scale of wave gi >> 2's point block (gi >> 1) & 1) / (channel scale): a power of two
+            const unsigned tag = (unsigned)((gi >> 2) << 6) | (unsigned)((gi & 1) << 5);
+            t1[gi] = __uint_as_float((__float_as_uint(t1[gi] * sc) & ~0xE0u) | tag);
+            t2[gi] = __uint_as_float((__float_as_uint(t2[gi] * sc) & ~0xE0u) | tag);
+        }
+        const float e2 = 2.0f * fmaf(p_rn, t_dmx, fmaf(p_wn, t_rdm, fmaf(C_ID * p_wn, t_dmx, 2.0f * DELTA * p_wn * t_hm)));
+        float c1 = NEG_BIG, c2 = NEG_BIG, c3 = NEG_BIG, c4 = NEG_BIG, c5 = NEG_BIG;
+#pragma unroll
+        for (int gi = 0; gi < 16; ++gi) {
+            float x = t1[gi];
+            c5 = __builtin_amdgcn_fmed3f(c4, c5, x); c4 = __builtin_amdgcn_fmed3f(c3, c4, x);
+            c3 = __builtin_amdgcn_fmed3f(c2, c3, x); c2 = __builtin_amdgcn_fmed3f(c1, c2, x); c1 = max_nc(c1, x);
+            x = t2[gi];
+            c5 = __builtin_amdgcn_fmed3f(c4, c5, x); c4 = __builtin_amdgcn_fmed3f(c3, c4, x);
+            c3 = __builtin_amdgcn_fmed3f(c2, c3, x); c2 = __builtin_amdgcn_fmed3f(c1, c2, x);
+        }
+        const float thr = c1 - e2;
+        unsigned flags = 0;
+#pragma unroll
+        for (int gi = 15; gi >= 0; --gi) {
+            const float u = t1[gi] < c5 ? t1[gi] : t2[gi];
+            flags = flags + flags + (unsigned)(u >= thr);
+        }
+        if (suspect) flags = 0x1FFFFu;
+        if ((abl & 32768) && n == 327) c1 = fabsf(c1) * 1.0e3f + 1.0f;   // diagnostics: a record that lies about its tile
+        part[rec * 1024 + n] = f32x4{c1, c2, c3, __uint_as_float(flags)};
+        part2[rec * 1024 + n] = qf32x2{c4, c5};
+    };
+    auto request_norms = [&](int cbase) {                 // for publish(cbase)
+        const int n = 32 * cbase + 64 * wave + lane;
+        p_ti = tinv_g[n]; p_wn = wnorm_g[n]; p_rn = rnorm_g[n];
+    };
+#define G_MFMA_BLOCK(ACC, PB)                                                                                  \
+    do {                                                                                                       \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) ACC[e] = 0.f;                                           \
+        _Pragma("unroll") for (int s = 0; s < 8; ++s)                                                          \
+            ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3[PB][s], wf[s], ACC, 0, 0, 0);                      \
+    } while (0)
+#define G_CHAIN_BLOCK(ACC, PB, M1, M2)                                                                         \
+    do {                                                                                                       \
+        M1 = NEG_BIG; M2 = NEG_BIG;                                                                            \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                       \
+            const float x = __uint_as_float((__float_as_uint(ACC[e]) & ~31u) | (unsigned)(16 * (PB) + e));     \
+            M2 = __builtin_amdgcn_fmed3f(M1, M2, x);                                                           \
+            M1 = max_nc(M1, x);                                                                                \
+        }                                                                                                      \
+    } while (0)
+#define G_INTERLEAVE()                                                                                         \
+    do {                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 \
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                                                 \
+        }                                                                                                      \
+    } while (0)
+    auto finish = [&](int c, int pb, float m1, float m2) {
+        if ((abl & 65536) && c == 18 && wave == 2) return;   // diagnostics: a hand-over that does not happen
+        float* dst = tb + (c & 7) * G_SLOT + ((wave * 2 + pb) * 2 + h) * 64 + r;
+        const unsigned ctag = (unsigned)(((c >> 3) & 3) << 5);
+        dst[0] = __uint_as_float((__float_as_uint(m1) & ~0x60u) | ctag);   // the pair is ONE LDS store: the tag of its first value covers both
+        dst[32] = m2;
+    };
+    f32x16 accP;                                          // the chunk's second block, scored under the next chunk's first MFMAs
+    bool pending = false;
+#pragma unroll 1
+    for (int c = 0; c < 32; ++c) {
+        dvq_lds_barrier();                                  // chunk c is in its stage; the other stage and ring slot c & 7 are free
+        if (c + 1 < 32) wreg = g_w3_load(w3h, 32 * (c + 1), wave, lane);
+        if ((c & 7) == 0 && c > 0) {                      // the ring's eight chunks are complete (barrier above): two per wave
+            publish(c - 8);
+            dvq_lds_barrier();                              // before this chunk's pairs overwrite slot 0
+        }
+        if ((c & 7) == 6) request_norms(c - 6);            // for the publish two chunks from now
+        const char* st = fl + (c & 1) * G_STAGE;
+        qf16x8 wf[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) wf[s] = w3_frag(st, r, 2 * s + h);
+        f32x16 accA;
+        float m1, m2;
+        G_MFMA_BLOCK(accA, 0);
+        if (pending) {
+            G_CHAIN_BLOCK(accP, 1, m1, m2);
+            G_INTERLEAVE();
+            finish(c - 1, 1, m1, m2);
+        }
+        G_MFMA_BLOCK(accP, 1);
+        G_CHAIN_BLOCK(accA, 0, m1, m2);
+        G_INTERLEAVE();
+        finish(c, 0, m1, m2);
+        pending = (c & 7) != 7;
+        if (!pending) {
+            G_CHAIN_BLOCK(accP, 1, m1, m2);
+            finish(c, 1, m1, m2);
+        }
+        if (c + 1 < 32) g_w3_store(fl + ((c + 1) & 1) * G_STAGE, wave, lane, wreg);
+    }
+#undef G_MFMA_BLOCK
+#undef G_CHAIN_BLOCK
+#undef G_INTERLEAVE
+    dvq_lds_barrier();
+    publish(24);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -1302,6 +1712,16 @@ int dvq_launch_pn_filter_front(const float* pc, int C, int N, int Npad, long B, 
     {
         DVQ_PROF("pn_trunk", 2.0 * pts * (4.0 * 64 + 64.0 * 128 + 128.0 * 1024), pts * (16 + 512) + (double)grid * 16384, st);
         const int lds_main = (abl & 524288) ? 100 * 1024 : F_LDS;   // diagnostics: ONE workgroup per CU (what a wave costs when it has its SIMD to itself)
+        // three workgroups per CU (pn_trunk3_kernel) unless DVQ_PN_TRUNK3=0 or a timing diagnostic of the two-per-CU kernel is asked for
+        const bool three = dvq_knobs().pn_trunk3 && !(abl & ~(32768 | 65536));
+        const int G_LDS = getenv("DVQ_PN_G_LDS") ? atoi(getenv("DVQ_PN_G_LDS")) : pn_g_lds();   // EXPERIMENT
+        if (three && C == 3)
+            DVQ_LAUNCH((pn_trunk3_kernel<3>), dim3((unsigned)grid), dim3(256), G_LDS, st, pc, trans, N, Npad, tiles, deal, B, W1, b1,
+                       b2, (const char*)w3f, h2buf, (f32x4*)part, part2, tstat, cbuf, abl);
+        else if (three)
+            DVQ_LAUNCH((pn_trunk3_kernel<4>), dim3((unsigned)grid), dim3(256), G_LDS, st, pc, trans, N, Npad, tiles, deal, B, W1, b1,
+                       b2, (const char*)w3f, h2buf, (f32x4*)part, part2, tstat, cbuf, abl);
+        else
         if (C == 3)
             DVQ_LAUNCH((pn_trunk_filter_kernel<3, false>), dim3((unsigned)grid), dim3(256), lds_main, st, pc, trans, N, Npad, tiles, deal, B, W1, b1,
                        b2, (const char*)w3f, h2buf, (f32x4*)part, part2, tstat, cbuf, abl);

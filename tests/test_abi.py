@@ -109,3 +109,37 @@ def test_no_packed_fp32_instructions_outside_the_gemm_epilogues():
     bad = {fn: dict(c) for fn, c in hits.items() if "gemm_" not in fn}
     assert not bad, f"packed-fp32 instructions outside the GEMM kernels: {bad}"
     assert not any("pn_" in fn or "vq_" in fn for fn in hits), "PointNet / VQ kernels must stay free of packed-fp32 instructions"
+
+
+def test_every_barrier_waits_for_the_waves_own_lds_operations():
+    """Round 5: the barrier at the head of pn_trunk3_kernel's conv3 loop was compiled WITHOUT "s_waitcnt lgkmcnt(0)" although the
+    back edge carries LDS stores -- waves passed it with stores in flight and tile records came out wrong whenever workgroups shared
+    a CU (the shape of the round-3 fault; DESIGN.md 3.3, csrc/dvq_internal.h: dvq_lds_barrier).  Every HIP source is compiled to
+    assembly with the library's flags and tools/check_barriers.py follows every path to every s_barrier: none may be reachable with an
+    LDS operation of the wave possibly still pending."""
+    import concurrent.futures, glob, shutil, subprocess, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "d-vqvae_amd", "csrc")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        return
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import check_barriers
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-S", "--cuda-device-only"]
+    with tempfile.TemporaryDirectory() as tmp:
+        def build(src):
+            out = os.path.join(tmp, os.path.basename(src) + ".s")
+            r = subprocess.run([hipcc] + flags + ["-o", out, os.path.basename(src)], cwd=csrc, capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, r.stderr[-2000:]
+            return out
+        with concurrent.futures.ThreadPoolExecutor(max_workers=6) as ex:
+            listings = list(ex.map(build, sorted(glob.glob(os.path.join(csrc, "*.hip")))))
+        bad, barriers = [], 0
+        for path in listings:
+            text = open(path).read()
+            barriers += text.count("s_barrier")
+            for name, body in check_barriers.functions(text):
+                if "s_barrier" in body:
+                    bad += [(os.path.basename(path), name[:80], hit) for hit in check_barriers.check(body)]
+    assert barriers > 100, f"only {barriers} s_barrier instructions found"
+    assert not bad, f"s_barrier reachable with an LDS operation of the wave in flight: {bad}"

@@ -1311,6 +1311,22 @@ def test_fp32_gemm_branch_matches_goldens(tmp_path):
     assert " passed" in r.stdout
 
 
+def test_pointnet_three_workgroups_per_cu_kernel(tmp_path):
+    """DVQ_PN_TRUNK3=1 (read when the library loads) puts the full tiles on pn_trunk3_kernel -- the trunk kernel laid out for three
+    workgroups per CU (168 registers, 52 KB of LDS, 32-channel chunks; measured 4.5 % slower than the default and therefore not the
+    default).  A fresh process runs the PointNet tests of this file on it: goldens, filtered == exhaustive bit for
+    bit, tail tiles, ties, non-finite inputs, the run-time checks with their fault injection, and the two full-machine stress tests --
+    the ones that caught this kernel's barrier without an LDS wait (csrc/dvq_internal.h: dvq_lds_barrier)."""
+    import os, subprocess, sys
+    env = dict(os.environ, DVQ_PN_TRUNK3="1")
+    sel = ("test_pointnet_golden or test_pointnet_filter or test_pointnet_batched or test_pointnet_runtime_checks or "
+           "test_pointnet_large_clouds or test_pointnet_pipeline")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", sel,
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_bf16x3_gemm_branch_matches_goldens(tmp_path):
     """DVQ_GEMM=bf16x3 packs every GEMM weight as the exact three-plane bf16 split (six products, fp32's range: what the
     fp16 three-product default falls back to): a fresh process runs the same golden subset on it."""
