@@ -594,12 +594,19 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         }
     } else {
     f32x16 accP;                                          // the chunk's last accumulator block, scored under the next chunk's first MFMAs
-    bool pending = false;
+    // Four chunks per trip of the rolled loop, the four written out: the ring slot (c & 3), the stage (c & 1), "is a chain pending"
+    // and "is this a publishing chunk" are compile-time constants then -- LDS addresses become instruction offsets instead of vector
+    // additions per access, the conditions disappear (round 5: the kernel is vector-issue bound).
 #pragma unroll 1
-    for (int c = 0; c < ((abl & 2) ? 0 : 16); ++c) {
+    for (int c4 = 0; c4 < ((abl & 2) ? 0 : 16); c4 += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = c4 + u;
+        const int stage = u & 1;
+        const bool pending = u != 0;
         if (!(abl & 16384)) dvq_lds_barrier();              // chunk c is in its stage; the other stage and tb parity are free
         if (c + 1 < 16 && !(abl & 1024)) wreg = w3_load(w3h, 64 * (c + 1), wave, lane);
-        if ((c & 3) == 0 && c > 0 && !(abl & 256)) {        // the ring's four chunks are complete (barrier above): one per wave
+        if (u == 0 && c > 0 && !(abl & 256)) {              // the ring's four chunks are complete (barrier above): one per wave
             publish(c - 4 + wave);
             dvq_lds_barrier();                              // before this chunk's pairs overwrite slot 0
         }
@@ -636,14 +643,13 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         F_INTERLEAVE();
         if (!(abl & 512)) finish(c, 1, 0, m1, m2);
         else if (m1 + m2 == 12345.f) tb[lane] = m1;
-        pending = (c & 3) != 3;
-        if (!pending) {
+        if (u == 3) {                                     // nothing to cover it before a publish
             F_CHAIN_BLOCK(accP, 1, m1, m2);
             if (!(abl & 512)) finish(c, 1, 1, m1, m2);
             else if (m1 + m2 == 12345.f) tb[lane] = m1;
         }
         if (c + 1 < 16 && !(abl & 1024)) w3_store(fl + (stage ^ 1) * F_STAGE3, wave, lane, wreg);
-        stage ^= 1;
+    }
     }
     }
 #undef F_MFMA_BLOCK
@@ -1005,6 +1011,8 @@ __global__ __launch_bounds__(256, PN3_WGS) void pn_trunk3_kernel(const float* __
         dst[32] = m2;
     };
     f32x16 accP;                                          // the chunk's second block, scored under the next chunk's first MFMAs
+    // (written out eight chunks per trip -- ring slot, stage and conditions as constants, what pays 1.5 % in the two-per-CU kernel --
+    // this loop spills 33 registers instead of 14 and the kernel loses 6 %: it stays rolled)
     bool pending = false;
 #pragma unroll 1
     for (int c = 0; c < 32; ++c) {
