@@ -143,3 +143,41 @@ def test_every_barrier_waits_for_the_waves_own_lds_operations():
                     bad += [(os.path.basename(path), name[:80], hit) for hit in check_barriers.check(body)]
     assert barriers > 100, f"only {barriers} s_barrier instructions found"
     assert not bad, f"s_barrier reachable with an LDS operation of the wave in flight: {bad}"
+
+
+def test_barrier_checker_sees_the_round5_shape():
+    """tools/check_barriers.py on two synthetic listings: the loop of pn_trunk3_kernel as the compiler emitted it first (LDS stores on
+    the back edge, no wait in front of the barrier at the loop head) must be flagged; the same with the wait must pass, and so must a
+    trailing barrier in front of s_endpgm."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import check_barriers
+    def listing(wait):
+        return f"""
+kern:                                   ; @kern
+\ts_load_dwordx2 s[0:1], s[4:5], 0x0
+\tds_write_b32 v0, v1
+\ts_waitcnt lgkmcnt(0)
+\ts_barrier
+.LBB0_1:                                ; =>This Inner Loop Header: Depth=1
+{wait}\ts_barrier
+\tds_read_b128 v[4:7], v2
+\ts_waitcnt lgkmcnt(0)
+\tv_add_f32_e32 v4, v4, v5
+\tds_write_b128 v3, v[4:7]
+\ts_add_i32 s2, s2, 1
+\ts_cmp_lg_u32 s2, 16
+\ts_cbranch_scc1 .LBB0_1
+\ts_waitcnt lgkmcnt(0)
+\ts_barrier
+\tds_read_b32 v0, v2
+\ts_waitcnt lgkmcnt(0)
+\tds_write_b32 v2, v0
+\ts_barrier
+\ts_endpgm
+.Lfunc_end0:
+"""
+    bad = [check_barriers.check(body) for _, body in check_barriers.functions(listing(""))]
+    assert bad == [[(".LBB0_1", 0)]], bad
+    good = [check_barriers.check(body) for _, body in check_barriers.functions(listing("\ts_waitcnt lgkmcnt(0)\n"))]
+    assert good == [[]], good
