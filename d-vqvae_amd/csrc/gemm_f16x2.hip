@@ -472,10 +472,12 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp_kernel(const GemmParams 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (t + 2 < T) {
             char* nx = smem_c + nx_st * STAGE;
-            store_a(nx);                                    // tile t + 2
-            cw.issue(nx, wave);
+            // (timing-only ablations of the diagnostics build, DVQ_GEMM_ABL: 8 no weight DMA, 16 no split + plane store, 32 no
+            // activation loads; results are garbage)
+            if (!(DVQ_DIAG_ON && (p.dbg_abl & 16))) store_a(nx);   // tile t + 2
+            if (!(DVQ_DIAG_ON && (p.dbg_abl & 8))) cw.issue(nx, wave);
             cw.advance(p, n0, wave, lane);
-            if (t + 3 < T) load_a();                        // tile t + 3
+            if (t + 3 < T && !(DVQ_DIAG_ON && (p.dbg_abl & 32))) load_a();   // tile t + 3
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers (and the plane writes retired) before the phase ends
         __builtin_amdgcn_s_barrier();
@@ -901,6 +903,9 @@ int dvq_launch_gemm_f16x2_gate_group(const GemmParams* ps, int n, hipStream_t st
 
 int dvq_launch_gemm_f16x2(const GemmParams& p, GemmEpilogue epi, hipStream_t stream) {
     DVQ_PROPAGATE(check_f16x2(p, epi));
+#ifdef DVQ_DIAG
+    if (const char* e = getenv("DVQ_GEMM_ABL")) const_cast<GemmParams&>(p).dbg_abl = atoi(e);
+#endif
     if (dvq_knobs().gemm_skinny && p.M <= skinny_max_m(p)) switch (epi) {
         case EPI_BIAS: return launch_skinny<EPI_BIAS>(p, stream);
         case EPI_RESID: return launch_skinny<EPI_RESID>(p, stream);
