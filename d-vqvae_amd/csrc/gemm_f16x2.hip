@@ -464,6 +464,11 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp_kernel(const GemmParams 
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
+                if (DVQ_DIAG_ON && (p.dbg_abl & 64) && pl == 1) {   // timing only: half the fragment bytes (the second pieces = the first)
+                    af[i][1] = af[i][0];
+                    if (i < NJ) wf[i][1] = wf[i][0];
+                    continue;
+                }
                 af[i][pl] = *reinterpret_cast<const h8*>(st + pl * A_PL + (wm * 64 + i * 16) * 64 + rd);
                 if (i < NJ) wf[i][pl] = *reinterpret_cast<const h8*>(st + 2 * A_PL + pl * W_PL + (wn * 16 * NJ + i * 16) * 64 + rd);
             }
@@ -473,7 +478,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp_kernel(const GemmParams 
         if (t + 2 < T) {
             char* nx = smem_c + nx_st * STAGE;
             // (timing-only ablations of the diagnostics build, DVQ_GEMM_ABL: 8 no weight DMA, 16 no split + plane store, 32 no
-            // activation loads; results are garbage)
+            // activation loads, 64 half the fragment reads; results are garbage)
             if (!(DVQ_DIAG_ON && (p.dbg_abl & 16))) store_a(nx);   // tile t + 2
             if (!(DVQ_DIAG_ON && (p.dbg_abl & 8))) cw.issue(nx, wave);
             cw.advance(p, n0, wave, lane);
