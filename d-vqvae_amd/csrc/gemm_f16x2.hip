@@ -464,6 +464,11 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp_kernel(const GemmParams 
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
+                if (DVQ_DIAG_ON && (p.dbg_abl & 128)) {     // timing only: no fragment reads at all
+                    af[i][pl] = h8{};
+                    if (i < NJ) wf[i][pl] = h8{};
+                    continue;
+                }
                 if (DVQ_DIAG_ON && (p.dbg_abl & 64) && pl == 1) {   // timing only: half the fragment bytes (the second pieces = the first)
                     af[i][1] = af[i][0];
                     if (i < NJ) wf[i][1] = wf[i][0];
@@ -477,8 +482,9 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp_kernel(const GemmParams 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (t + 2 < T) {
             char* nx = smem_c + nx_st * STAGE;
-            // (timing-only ablations of the diagnostics build, DVQ_GEMM_ABL: 8 no weight DMA, 16 no split + plane store, 32 no
-            // activation loads, 64 half the fragment reads; results are garbage)
+            // (timing-only ablations of the diagnostics build, DVQ_GEMM_ABL: 2 no MFMAs, 8 no weight DMA, 16 no split + plane store, 32 no
+            // activation loads, 64 half the fragment reads, 128 none, 256 no epilogue, 512 one barrier per K-tile; results are garbage;
+            // tools/gemm_skeleton.py turns them into nanoseconds per K-tile)
             if (!(DVQ_DIAG_ON && (p.dbg_abl & 16))) store_a(nx);   // tile t + 2
             if (!(DVQ_DIAG_ON && (p.dbg_abl & 8))) cw.issue(nx, wave);
             cw.advance(p, n0, wave, lane);
@@ -488,6 +494,10 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp_kernel(const GemmParams 
         __builtin_amdgcn_s_barrier();
         // ---- compute phase: hi: (a1 w1); lo: (a1 w2) then (a2 w1) -- per output the order of gemm_f16x2_kernel
         __builtin_amdgcn_s_setprio(1);
+        if (DVQ_DIAG_ON && (p.dbg_abl & 2)) {               // timing only: no matrix work (the operands still have to arrive)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : : "v"(af[i][0]), "v"(af[i][1]), "v"(wf[i < NJ ? i : 0][0]), "v"(wf[i < NJ ? i : 0][1]));
+        } else {
 #pragma unroll
         for (int jn = 0; jn < NJ; ++jn)
 #pragma unroll
@@ -500,12 +510,17 @@ __global__ __launch_bounds__(512, 1) void gemm_f16x2_pp_kernel(const GemmParams 
         for (int jn = 0; jn < NJ; ++jn)
 #pragma unroll
             for (int i = 0; i < 4; ++i) lo[jn][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[jn][0], af[i][1], lo[jn][i], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_barrier();
+        if (!(DVQ_DIAG_ON && (p.dbg_abl & 512))) __builtin_amdgcn_s_barrier();   // (512: timing only, the loop with ONE barrier per K-tile)
         cur_st = cur_st == PP_STAGES - 1 ? 0 : cur_st + 1;
         nx_st = nx_st == PP_STAGES - 1 ? 0 : nx_st + 1;
     }
     if (wave < 4) __builtin_amdgcn_s_barrier();            // pairs with the late half's extra barrier
+    if (DVQ_DIAG_ON && (p.dbg_abl & 256)) {                // timing only: no epilogue (one store so that the accumulators stay alive)
+        if (hi[0][0][0] + lo[0][0][0] == 12345.678f) p.out[0] = 1.f;
+        return;
+    }
     f16x2_epilogue<EPI, NJ>(p, hi, lo, m0 + wm * 64, n0 + wn * 16 * NJ, (n0 >> 1) + wn * 32, lane);
 }
 
