@@ -535,12 +535,14 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         _Pragma("unroll") for (int s = 0; s < 8; ++s)                                                          \
             ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(a3[PB][s], WF[s], ACC, 0, 0, 0);                      \
     } while (0)
-#define F_CHAIN_BLOCK(ACC, PB, M1, M2)                                                                         \
+    /* CT: the ring tag of the chunk (bits [6:5], uniform): set HERE, with the id, by the one instruction per score that is needed    */ \
+    /* anyway -- finish() used to set it on the block's winner with an instruction of its own                                        */
+#define F_CHAIN_BLOCK(ACC, PB, M1, M2, CT)                                                                     \
     do {                                                                                                       \
         M1 = NEG_BIG; M2 = NEG_BIG;                                                                            \
         if (abl & 128) { M1 = ACC[0]; M2 = ACC[15]; } else   /* timing only: no chain */                       \
         _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                       \
-            const float x = __uint_as_float((__float_as_uint(ACC[e]) & ~31u) | (unsigned)(16 * (PB) + e));     \
+            const float x = __uint_as_float((__float_as_uint(ACC[e]) & id_mask) | (CT)[16 * (PB) + e]);        \
             M2 = __builtin_amdgcn_fmed3f(M1, M2, x);                                                           \
             M1 = max_nc(M1, x);                                                                                \
         }                                                                                                      \
@@ -557,10 +559,12 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     auto finish = [&](int c, int jn, int pb, float m1, float m2) {
         if ((abl & 65536) && c == 9 && wave == 2 && jn == 0) return;   // diagnostics: a hand-over that does not happen
         float* dst = tb + (c & 3) * F_SLOT + ((wave * 2 + pb) * 2 + h) * 128 + 32 * jn + r;
-        const unsigned ctag = (unsigned)(((c >> 2) & 3) << 5);   // which of the four chunks that share this ring slot (checked by publish())
-        dst[0] = __uint_as_float((__float_as_uint(m1) & ~0x60u) | ctag);   // the pair is ONE LDS store: the tag of its first value covers both
+        dst[0] = m1;                                        // bits [6:5] of both: the chunk's ring tag (F_CHAIN_BLOCK), checked by publish()
         dst[64] = m2;
     };
+    // (the mask in a vector register: id | tag is a scalar, and one v_and_or_b32 takes one scalar operand)
+    unsigned id_mask = ~127u;
+    asm volatile("" : "+v"(id_mask));
     int stage = 0;
     if constexpr (TAIL) {
         // one point block per wave: two MFMA blocks (channels 0..31, 32..63) and two chains per chunk; every wave publishes the
@@ -584,9 +588,12 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
             float a1, a2, q1, q2;
             F_MFMA_BLOCK(accA, 0, wf0);
             F_MFMA_BLOCK(accB, 0, wf1);
-            F_CHAIN_BLOCK(accA, 0, a1, a2);
+            unsigned ctag_c[32];                          // id | ring tag per accumulator register, as scalars (see sid4 below)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) asm("s_or_b32 %0, %1, %2" : "=s"(ctag_c[e]) : "s"((unsigned)(((c >> 2) & 3) << 5)), "i"(e));
+            F_CHAIN_BLOCK(accA, 0, a1, a2, ctag_c);
             F_INTERLEAVE();
-            F_CHAIN_BLOCK(accB, 0, q1, q2);
+            F_CHAIN_BLOCK(accB, 0, q1, q2, ctag_c);
             finish(c, 0, 0, a1, a2);
             finish(c, 1, 0, q1, q2);
             if (c + 1 < 16) w3_store(fl + (stage ^ 1) * F_STAGE3, wave, lane, wreg);
@@ -599,6 +606,12 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     // additions per access, the conditions disappear (round 5: the kernel is vector-issue bound).
 #pragma unroll 1
     for (int c4 = 0; c4 < ((abl & 2) ? 0 : 16); c4 += 4) {
+    // id (point block, register) | ring tag of this trip's four chunks, one SCALAR per accumulator register: the chain's one instruction
+    // per score is then v_and_or_b32 (score, mask in a vector register, this scalar).  (Written as "id | tag" in the expression the
+    // compiler makes it v_and_b32 + v_or3_b32: two vector instructions per score.)
+    unsigned ctag4[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) asm("s_or_b32 %0, %1, %2" : "=s"(ctag4[e]) : "s"((unsigned)(((c4 >> 2) & 3) << 5)), "i"(e));
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int c = c4 + u;
@@ -623,28 +636,28 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         float m1, m2;
         F_MFMA_BLOCK(accA, 0, wf0);
         if (pending) {
-            F_CHAIN_BLOCK(accP, 1, m1, m2);
+            F_CHAIN_BLOCK(accP, 1, m1, m2, ctag4);
             F_INTERLEAVE();
             if (!(abl & 512)) finish(c - 1, 1, 1, m1, m2);
             else if (m1 + m2 == 12345.f) tb[lane] = m1;
         }
         F_MFMA_BLOCK(accB, 1, wf0);
-        F_CHAIN_BLOCK(accA, 0, m1, m2);
+        F_CHAIN_BLOCK(accA, 0, m1, m2, ctag4);
         F_INTERLEAVE();
         if (!(abl & 512)) finish(c, 0, 0, m1, m2);
         else if (m1 + m2 == 12345.f) tb[lane] = m1;
         F_MFMA_BLOCK(accA, 0, wf1);
-        F_CHAIN_BLOCK(accB, 1, m1, m2);
+        F_CHAIN_BLOCK(accB, 1, m1, m2, ctag4);
         F_INTERLEAVE();
         if (!(abl & 512)) finish(c, 0, 1, m1, m2);
         else if (m1 + m2 == 12345.f) tb[lane] = m1;
         F_MFMA_BLOCK(accP, 1, wf1);
-        F_CHAIN_BLOCK(accA, 0, m1, m2);
+        F_CHAIN_BLOCK(accA, 0, m1, m2, ctag4);
         F_INTERLEAVE();
         if (!(abl & 512)) finish(c, 1, 0, m1, m2);
         else if (m1 + m2 == 12345.f) tb[lane] = m1;
         if (u == 3) {                                     // nothing to cover it before a publish
-            F_CHAIN_BLOCK(accP, 1, m1, m2);
+            F_CHAIN_BLOCK(accP, 1, m1, m2, ctag4);
             if (!(abl & 512)) finish(c, 1, 1, m1, m2);
             else if (m1 + m2 == 12345.f) tb[lane] = m1;
         }
