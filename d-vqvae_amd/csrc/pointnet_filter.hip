@@ -491,13 +491,16 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
         for (int gi = 0; gi + 1 < NG; gi += 2)             // v_xor_b32 + v_or3_b32 per two groups
             tagdiff = tagdiff | (__float_as_uint(t1[gi]) ^ (unsigned)(((c >> 2) & 3) << 5)) | (__float_as_uint(t1[gi]) ^ __float_as_uint(t1[gi + 1]));
         const bool suspect = (tagdiff & 0x60u) != 0;
+        unsigned tag_mask = ~0xE0u;
+        asm volatile("" : "+v"(tag_mask));
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
             const int w = TAIL ? 0 : gi >> 2, hh = gi & 1;
             const float sc = scs[TAIL ? wave : w] * ti;     // a power of two
-            const unsigned tag = (unsigned)(w << 6) | (unsigned)(hh << 5);
-            t1[gi] = __uint_as_float((__float_as_uint(t1[gi] * sc) & ~0xE0u) | tag);
-            t2[gi] = __uint_as_float((__float_as_uint(t2[gi] * sc) & ~0xE0u) | tag);
+            unsigned tag;                                   // (w << 6) | (hh << 5) as a SCALAR and the mask in a vector register: one
+            asm("s_mov_b32 %0, %1" : "=s"(tag) : "i"((w << 6) | (hh << 5)));   // v_and_or_b32 per value instead of v_and + v_or
+            t1[gi] = __uint_as_float((__float_as_uint(t1[gi] * sc) & tag_mask) | tag);
+            t2[gi] = __uint_as_float((__float_as_uint(t2[gi] * sc) & tag_mask) | tag);
         }
         const float e2 = e2s[64 * c + lane];               // 2 E of the tile for this channel (filled once, before the loop)
         float c1 = NEG_BIG, c2 = NEG_BIG, c3 = NEG_BIG, c4 = NEG_BIG, c5 = NEG_BIG;   // the tile's FIVE largest id-carrying scores
