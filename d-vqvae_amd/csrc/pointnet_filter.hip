@@ -106,8 +106,10 @@ __device__ __forceinline__ qf16x8 w2_frag(const char* stage, int pl, int row, in
 // at its end -- an LDS-DMA piece costs the issuing wave ~150 cycles, a load + a write a few).
 struct W3Regs { uint4 a, b, c, d; };
 __device__ __forceinline__ const uint4* w3_src(const char* __restrict__ w3h, int ch0, int wave, int lane, int i) {
-    const int row = (wave * 4 + i) * 4 + (lane >> 4);
-    return reinterpret_cast<const uint4*>(w3h + (long)(ch0 + row) * 256 + 16 * (lane & 15));
+    // uniform 64-bit base + 32-bit lane offset: the load takes the base from scalar registers (no 64-bit vector add per load)
+    const char* base = w3h + (long)(ch0 + (wave * 4 + i) * 4) * 256;
+    const unsigned off = (unsigned)(lane >> 4) * 256u + 16u * (unsigned)(lane & 15);
+    return reinterpret_cast<const uint4*>(base + off);
 }
 __device__ __forceinline__ W3Regs w3_load(const char* __restrict__ w3h, int ch0, int wave, int lane) {
     W3Regs v;
