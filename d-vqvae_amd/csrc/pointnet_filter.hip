@@ -1364,12 +1364,12 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
             for (int u = 0; u < 4; ++u) {
                 const unsigned code = sorted[min(i + u, i1 - 1)];
                 nn[u] = (int)(code & 1023u);
-                const float* wr = w3 + nn[u] * 128 + 4 * j;
-                w0[u] = *reinterpret_cast<const f32x4*>(wr);
-                w1[u] = *reinterpret_cast<const f32x4*>(wr + 64);
-                const float* hr = h2 + (long)(code >> 10) * 128 + 4 * j;
-                ha[u] = *reinterpret_cast<const f32x4*>(hr);
-                hb[u] = *reinterpret_cast<const f32x4*>(hr + 64);
+                // (uniform base + 32-bit offset: the loads take the base from scalar registers, no 64-bit vector add per row)
+                const unsigned woff = (code & 1023u) * 512u + 16u * (unsigned)j, hoff = (code >> 10) * 512u + 16u * (unsigned)j;
+                w0[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(w3) + woff);
+                w1[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(w3) + woff + 256);
+                ha[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(h2) + hoff);
+                hb[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(h2) + hoff + 256);
             }
             float v[4], wc[4];                              // all eight chains first (independent: they interleave), the LDS updates after
 #pragma unroll
