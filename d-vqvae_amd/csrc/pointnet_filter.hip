@@ -1393,7 +1393,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
         for (int u = 0; u < 4; ++u) {
             const int n = n0 + 16 * u;
             cn[u] = cand_n[n];
-            const float* wr = w3 + n * 128 + 4 * j;
+            const float* wr = reinterpret_cast<const float*>(reinterpret_cast<const char*>(w3) + ((unsigned)n * 512u + 16u * (unsigned)j));
             w0[u] = *reinterpret_cast<const f32x4*>(wr);
             w1[u] = *reinterpret_cast<const f32x4*>(wr + 64);
             const float* hr = h2 + (long)(cn[u] ? cand[n][0] : 0) * 128 + 4 * j;
@@ -1427,7 +1427,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
     for (int i = g; i < (by_point ? 0 : npairs); i += 16) {
         const int code = pair_list[i];
         const int n = code & 1023;
-        const float* wr = w3 + n * 128 + 4 * j;
+        const float* wr = reinterpret_cast<const float*>(reinterpret_cast<const char*>(w3) + ((unsigned)n * 512u + 16u * (unsigned)j));
         const float v = exact_dot(*reinterpret_cast<const f32x4*>(wr), *reinterpret_cast<const f32x4*>(wr + 64), h2 + (long)(code >> 10) * 128, j);
         if (j == 0) atomicMax(&best_k[n], f2key(v));
     }
@@ -1437,7 +1437,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
     for (int i = tid >> 6; i < nfb; i += 4) {
         const int code = fb_list[i];
         const int n = code & 1023, t = (code >> 10) & 1023, w = (code >> 22) & 3, pb = (code >> 21) & 1, hh = (code >> 20) & 1;
-        const float* wr = w3 + n * 128 + 4 * j;
+        const float* wr = reinterpret_cast<const float*>(reinterpret_cast<const char*>(w3) + ((unsigned)n * 512u + 16u * (unsigned)j));
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr), w1 = *reinterpret_cast<const f32x4*>(wr + 64);
         float best = NEG_BIG;
         {
@@ -1447,7 +1447,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
                 const int e = 4 * (g & 3) + u;
                 int p = point_of_slot(t, 64 * w + 32 * pb + 8 * (e >> 2) + 4 * hh + (e & 3), deal);   // tail tile: one block, pb = 0
                 if (p >= N) p %= N;
-                const float* hr = h2 + (long)p * 128 + 4 * j;
+                const float* hr = reinterpret_cast<const float*>(reinterpret_cast<const char*>(h2) + ((unsigned)p * 512u + 16u * (unsigned)j));
                 ha[u] = *reinterpret_cast<const f32x4*>(hr);
                 hb[u] = *reinterpret_cast<const f32x4*>(hr + 64);
             }
@@ -1471,7 +1471,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
                 best[u] = NEG_BIG;
             }
             for (int p = g; p < N; p += 16) {
-                const float* hr = h2 + (long)p * 128 + 4 * j;
+                const float* hr = reinterpret_cast<const float*>(reinterpret_cast<const char*>(h2) + ((unsigned)p * 512u + 16u * (unsigned)j));
                 const f32x4 ha = *reinterpret_cast<const f32x4*>(hr), hb = *reinterpret_cast<const f32x4*>(hr + 64);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) best[u] = max_nan(best[u], exact_dot_regs(w0[u], w1[u], ha, hb));
