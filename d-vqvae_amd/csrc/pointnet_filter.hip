@@ -1506,7 +1506,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
     for (int ci = 0; ci < 4; ++ci) {
         const int n = tid + 256 * ci;
         const float lo_c = ci == 0 ? lo_0 : ci == 1 ? lo_1 : ci == 2 ? lo_2 : lo_3, hi_c = ci == 0 ? hi_0 : ci == 1 ? hi_1 : ci == 2 ? hi_2 : hi_3;
-        if (!(lo_c <= hi_c) || (abl & (16 | 64))) continue;   // (the timing ablations leave maxima that are not maxima)
+        if (!(lo_c <= hi_c) || (abl & ~(4096 | 8192 | 32768 | 65536 | 524288))) continue;   // (the timing ablations -- of either kernel -- leave maxima that are not maxima)
         const float v = key2f(best_k[n]), wc = wcs[n];
         const float x = v - wc, slack = 4.0e-7f * (fabsf(v) + fabsf(wc));   // the subtraction's own rounding
         if (!(x >= lo_c - slack && x <= hi_c + slack)) {
