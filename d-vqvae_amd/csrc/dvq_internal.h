@@ -235,6 +235,8 @@ struct DvqKnobs {
 const DvqKnobs& dvq_knobs();
 int dvq_launch_vq_stream16(const float* z, const float* E, const void* packed, long M, int64_t* idx, unsigned long long* slow_rows,
                            unsigned long long* dbg, hipStream_t st);
+int dvq_launch_vq_pipe(const float* z, const float* E, const void* packed, long M, int64_t* idx, unsigned long long* slow_rows,
+                       unsigned long long* dbg, hipStream_t st);
 int dvq_launch_vq_rows(const float* z, const float* E, const void* packed, long M, int64_t* idx, unsigned long long* slow_rows,
                        hipStream_t st);
 // simple helpers implemented in misc.hip

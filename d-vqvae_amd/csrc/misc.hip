@@ -28,7 +28,7 @@ DvqKnobs* read_knobs() {
     k->gemm_skinny = is("DVQ_GEMM_SKINNY", '0') ? 0 : (is("DVQ_GEMM_SKINNY", '2') ? 2 : 1);   // 2: the register-staged variant
     {
         const int v = getenv("DVQ_VQ_KERNEL") ? atoi(getenv("DVQ_VQ_KERNEL")) : 0;
-        k->vq_kernel = v == 8 ? 8 : (v == 32 ? 32 : 16);       // default: the sixteen-wave kernel; 8: eight waves (generated tile body); 32: rows resident, codebook streamed
+        k->vq_kernel = v == 8 ? 8 : (v == 32 ? 32 : (v == 17 ? 17 : 16));       // default: the sixteen-wave kernel; 8: eight waves (generated tile body); 32: rows resident, codebook streamed
     }
     k->gemm_skinny_prefetch = !is("DVQ_GEMM_SKINNY_PREFETCH", '0');
     k->gemm_skinny_cols = (int)num("DVQ_GEMM_SKINNY_COLS");

@@ -923,7 +923,13 @@ extern "C" int dvq_vq_argmin_fast(const float* z, const float* E, const void* pa
     if (getenv("DVQ_VQ_DBG") || getenv("DVQ_VQ_ABL")) which = 8;                 // stamps / ablations of the eight-wave kernel
     if (getenv("DVQ_VQ16_DBG") || getenv("DVQ_VQ16_ABL")) which = 16;
     if (getenv("DVQ_VQ16_DBG")) dbg16 = (unsigned long long*)workspace;          // phase stamps of the sixteen-wave kernel
+    if (getenv("DVQ_VQP_DBG") || getenv("DVQ_VQP_ABL") || getenv("DVQ_VQP_VAR")) which = 17;
+    if (getenv("DVQ_VQP_DBG")) dbg16 = (unsigned long long*)workspace;           // phase / wave stamps of vq_pipe.hip
 #endif
+    if (which == 17) {
+        DVQ_PROF("vq_argmin_fast", 2.0 * M * K * D, (double)M * D * 4 + (double)K * D * 4 + (double)M * 8, st);
+        return dvq_launch_vq_pipe(z, E, packed, (long)M, idx, slow_rows, dbg16, st);
+    }
     if (which == 16) {
         DVQ_PROF("vq_argmin_fast", 2.0 * M * K * D, (double)M * D * 4 + (double)K * D * 4 + (double)M * 8, st);
         return dvq_launch_vq_stream16(z, E, packed, (long)M, idx, slow_rows, dbg16, st);
