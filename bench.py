@@ -58,9 +58,11 @@ DTYPE_NOTE = {
              "TWO fp32 accumulators (large / cross terms) on v_mfma_f32_16x16x32_f16; dropped: a2 b2 and the two residuals, "
              "<= 3*2^-22 |a||b| per product: fp32-GEMM-class accuracy, <= 4e-6*scale against fp64 in "
              "tests/test_gpu_parity.py::test_linear_fuzz... (measured ~1e-7*scale, a third of the six-product bf16 split kept "
-             "behind DVQ_GEMM=bf16x3), not IEEE-fp32 bitwise; PointNet conv1/conv2: six-product bf16 split; conv3 + max over "
-             "the points: fp16 matrix-core filter that only SELECTS candidate points, every emitted value is a plain fp32 FMA "
-             "dot product)"}[GEMM_MODE]
+             "behind DVQ_GEMM=bf16x3), not IEEE-fp32 bitwise; PointNet conv1: fp32 vector ALU; conv2: the same fp16 three-product "
+             "split with a per-point power-of-two activation scale (the six-product bf16 split only with DVQ_PN_FILTER=0 and for "
+             "shapes the filter does not cover); conv3 + max over the points: fp16 matrix-core filter that only SELECTS "
+             "candidate points, every emitted value is a plain fp32 FMA dot product; VQ argmin: fp16 matrix-core filter + "
+             "canonical fp32 refine, indices bit-exact)"}[GEMM_MODE]
 
 
 def parse():
@@ -504,6 +506,7 @@ def config_leg(args, lib, _lib, dev):
         codes = torch.randint(0, K, (B, 3, 3), device=dev, dtype=torch.int64, generator=torch.Generator(device=dev).manual_seed(7))
 
         @torch.no_grad()
+        @ops.no_range_check()        # as GenNet.gen: no per-op finiteness check + host sync inside the timed region (one check below)
         def step():
             z_out = torch.empty(B, 2560, device=dev)
             z_pos = torch.empty(B, 2048, device=dev)
@@ -531,6 +534,7 @@ def config_leg(args, lib, _lib, dev):
         feat = torch.randn(B, 1024, device=dev, generator=torch.Generator(device=dev).manual_seed(9))
 
         @torch.no_grad()
+        @ops.no_range_check()
         def step():
             step_no[0] += 1
             noise = ops.exp1_noise(B, 9 * pk.n_in, 20261003, 0, step_no[0], device=dev, perm=order).view(B, 9, pk.n_in)

@@ -88,13 +88,15 @@ def new_err_flag(dev: torch.device) -> Tensor:
 # its result once (one host synchronisation) and runs the call again on the six-product bf16 images, which have fp32's range, when
 # it holds a non-finite value; inputs that are themselves NaN / Inf come out non-finite there too, as in the reference.
 # GenNet.gen makes ONE such check for the whole path and switches the per-op checks off around its inner calls.
+import contextlib
 import threading
 
 _range_state = threading.local()                            # per host thread: one thread's gen() must not switch another's checks off
 
 
-class no_range_check:
-    """``with ops.no_range_check(): ...`` -- the caller checks the final result itself (GenNet.gen: one synchronisation per call)."""
+class no_range_check(contextlib.ContextDecorator):
+    """``with ops.no_range_check(): ...`` (or ``@ops.no_range_check()`` on a function) -- the caller checks the final result itself
+    (GenNet.gen: one synchronisation per call)."""
 
     def __enter__(self):
         _range_state.off = getattr(_range_state, "off", 0) + 1

@@ -56,7 +56,7 @@ L_UND = L_SLOW + MAX_TILES * TILE * 2
 UND_PER_WAVE = 16
 L_CNT = L_UND + NWV * UND_PER_WAVE * 2
 L_DBG = L_CNT + 128
-LDS_BYTES = L_DBG + NWV * 16 * 4
+LDS_BYTES = L_DBG + 128 + NWV * 16 * 4            # [16] u64 prologue stamps, then [16 waves][2 tiles][8] u32 period stamps
 
 # ---- registers
 ACC = 0
@@ -83,6 +83,22 @@ uid = [0]
 def label(name):
     uid[0] += 1
     return f".Lvqp_{name}_{uid[0]}_%="
+
+
+STAMPS = [False]
+
+
+def stamp(k):
+    """diagnostics: shader-clock stamp k (0..7) of periods 3 and 4 -> L_DBG + 128 + wave * 64 + (t - 3) * 32 + 4 k"""
+    if not STAMPS[0]:
+        return []
+    skip = label("nostamp")
+    return [f"s_sub_u32 s64, s{S_T}, 3", "s_cmp_gt_u32 s64, 1", f"s_cbranch_scc1 {skip}",
+            "s_memtime s[98:99]",
+            "s_lshl_b32 s64, s64, 5", f"s_lshl_b32 s65, {S_WAVE}, 6", "s_add_u32 s64, s64, s65", f"s_add_u32 s64, s64, {S_LDSB}",
+            f"s_add_u32 s64, s64, {L_DBG + 128 + 4 * k}",
+            "s_waitcnt lgkmcnt(0)", "v_mov_b32_e32 v26, s98", "v_mov_b32_e32 v27, s64", "ds_write_b32 v27, v26",
+            f"{skip}:"]
 
 
 def chain(mfma=True, reads=True):
@@ -125,7 +141,7 @@ def dpp_reduce(op, dst, src):
     return o
 
 
-def convert_load(st, conv=True, loads=True, wait=True):
+def convert_load(st, conv=True, loads=True, wait=True, nt=True, hot=False):
     """C: tile t + 2 from register set st -> fp16 image + {eps sE, flag}; then the rows of tile t + 4 into the set"""
     x = XSET[st]
     o = []
@@ -169,13 +185,16 @@ def convert_load(st, conv=True, loads=True, wait=True):
     if loads:
         # always issued (the counted wait above needs the same number of loads in flight in every period): tiles behind the
         # workgroup's last one and rows behind the end of the data read the last row again
-        o += [f"s_min_i32 s64, s{S_LDROW}, s{S_MM1}", "s_max_i32 s64, s64, 0",
+        ntm = " nt" if nt else ""
+        if hot:
+            o += ["s_mov_b32 s64, %[row0]"]
+        o += [(f"s_min_i32 s64, s{S_LDROW}, s{S_MM1}" if not hot else f"s_min_i32 s64, s64, s{S_MM1}"), "s_max_i32 s64, s64, 0",
               f"s_add_i32 s65, s{S_LDROW}, 1", f"s_cmp_lt_i32 s65, {S_M}", "s_cselect_b32 s65, -1, 0x3ff",
               f"v_and_b32_e32 v{T[0]}, s65, v{V_LOADOFF}",
               "s_mov_b32 s65, 0", "s_lshl_b64 s[64:65], s[64:65], 10",
               f"s_add_u32 s64, s64, %[zplo]", f"s_addc_u32 s65, s65, %[zphi]",
-              f"global_load_dwordx4 v[{x[0]}:{x[3]}], v{T[0]}, s[64:65] nt",
-              f"global_load_dwordx4 v[{x[4]}:{x[7]}], v{T[0]}, s[64:65] offset:512 nt"]
+              f"global_load_dwordx4 v[{x[0]}:{x[3]}], v{T[0]}, s[64:65]{ntm}",
+              f"global_load_dwordx4 v[{x[4]}:{x[7]}], v{T[0]}, s[64:65] offset:512{ntm}"]
     o.append(f"s_add_i32 s{S_LDROW}, s{S_LDROW}, {S_ROWSTEP}")
     return o
 
@@ -259,7 +278,7 @@ def advance():
 def period(st, rot, abl):
     P = chain(mfma=not (abl & 32), reads=not (abl & 64))
     S = scores(on=not (abl & 8))
-    C = convert_load(st, conv=not (abl & 4), loads=not (abl & 1), wait=not (abl & 1))
+    C = convert_load(st, conv=not (abl & 4), loads=not (abl & 1), wait=not (abl & 1) and not (abl & 128), nt=not (abl & 256), hot=bool(abl & 512))
     Mg = merge(on=not (abl & 2))
     o = ["s_waitcnt lgkmcnt(0)"]
     if not (abl & 16):
@@ -272,20 +291,24 @@ def period(st, rot, abl):
     # labels inside a phase are unique per instance: regenerate the phases for every copy
     def phases():
         return (chain(mfma=not (abl & 32), reads=not (abl & 64)), scores(on=not (abl & 8)),
-                convert_load(st, conv=not (abl & 4), loads=not (abl & 1), wait=not (abl & 1)), merge(on=not (abl & 2)))
-    p, s, c, m = phases()
-    o += c + m + p + s + [f"s_branch {le}", f"{l0}:"]                     # q = 3
-    p, s, c, m = phases()
-    o += p + s + c + m + [f"s_branch {le}", f"{l1}:"]                     # q = 0
-    p, s, c, m = phases()
-    o += c + p + s + m + [f"s_branch {le}", f"{l2}:"]                     # q = 1
-    p, s, c, m = phases()
-    o += m + c + p + s + [f"{le}:"]                                       # q = 2
+                convert_load(st, conv=not (abl & 4), loads=not (abl & 1), wait=not (abl & 1) and not (abl & 128), nt=not (abl & 256), hot=bool(abl & 512)), merge(on=not (abl & 2)))
+    def seq(order):
+        p, s, c, m = phases()
+        ph = {"P": stamp(1) + p + stamp(2), "S": s + stamp(3), "C": stamp(4) + c + stamp(5), "M": stamp(6) + m + stamp(7)}
+        out = stamp(0)
+        for x in order:
+            out += ph[x]
+        return out
+    o += seq("CMPS") + [f"s_branch {le}", f"{l0}:"]                       # q = 3
+    o += seq("PSCM") + [f"s_branch {le}", f"{l1}:"]                       # q = 0
+    o += seq("CPSM") + [f"s_branch {le}", f"{l2}:"]                       # q = 1
+    o += seq("MCPS") + [f"{le}:"]                                         # q = 2
     return o
 
 
-def program(rot=True, abl=0):
+def program(rot=True, abl=0, stamps=False):
     uid[0] = 0
+    STAMPS[0] = stamps
     lane = T[0]
     o = [  # ---- constants of the block
         f"s_cmp_eq_u32 %[evalid], 0", f"s_cselect_b64 s[{S_BADE}:{S_BADE + 1}], -1, 0",
@@ -315,6 +338,11 @@ def program(rot=True, abl=0):
           f"s_mul_i32 s64, {S_ROWSTEP}, 3", f"s_sub_u32 s{S_MROW}, %[row0], s64"]
     o += convert_load(0, conv=not (abl & 4), loads=not (abl & 1), wait=False) + advance()
     o += convert_load(1, conv=not (abl & 4), loads=not (abl & 1), wait=False) + advance()
+    # ---- (prologue done: a 100 MHz stamp per wave into L_DBG, read by the diagnostics build only)
+    o += ["s_memrealtime s[64:65]", f"s_lshl_b32 s66, {S_WAVE}, 3", f"s_add_u32 s66, s66, {S_LDSB}", f"s_add_u32 s66, s66, {L_DBG}",
+          "s_mov_b32 exec_lo, 1", "s_mov_b32 exec_hi, 0", "s_waitcnt lgkmcnt(0)",
+          f"v_mov_b32_e32 v{T[0]}, s64", f"v_mov_b32_e32 v{T[1]}, s65", f"v_mov_b32_e32 v{T[2]}, s66",
+          f"ds_write_b64 v{T[2]}, v[{T[0]}:{T[1]}]", "s_mov_b64 exec, -1"]
     # ---- tile loop, two periods per trip (register sets A, B)
     loop, done = label("loop"), label("done")
     o += [f"{loop}:"]
@@ -348,7 +376,8 @@ def main():
         f.write("#define VQP_ASM_DEFAULT \\\n    " + lit(program(rot=True)) + "\n")
         f.write("#ifdef DVQ_DIAG\n")
         f.write("#define VQP_ASM_NOROT \\\n    " + lit(program(rot=False)) + "\n")
-        for abl in (1, 2, 4, 8, 16, 32, 96, 15):
+        f.write("#define VQP_ASM_STAMPS \\\n    " + lit(program(rot=True, stamps=True)) + "\n")
+        for abl in (1, 2, 4, 8, 32, 96, 15, 130, 256, 512, 3):
             f.write(f"#define VQP_ASM_ABL{abl} \\\n    " + lit(program(rot=True, abl=abl)) + "\n")
         f.write("#endif\n")
         clob = [f'"v{i}"' for i in list(range(0, 48)) + [V_ZA] + list(range(64, 128))] + [f'"s{i}"' for i in range(S_FIRST, S_LAST + 1)]
