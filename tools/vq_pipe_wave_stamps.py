@@ -1,6 +1,5 @@
 """GPU box, diagnostics build: per-wave timeline of periods 3 and 4 of vq_pipe.hip's tile loop (shader-clock cycles after the
-first wave left the period's barrier; median over the workgroups).  Stamp k: 0 barrier left, 1/2 products begin/end, 3 scores
-stored, 4/5 conversion + loads begin/end, 6/7 merge begin/end."""
+first wave left the period's barrier; median over the workgroups)."""
 import os, sys
 os.environ["DVQ_DIAG_LIB"] = "1"; os.environ["DVQ_VQ_KERNEL"] = "17"; os.environ["DVQ_VQP_DBG"] = "1"; os.environ["DVQ_VQP_ABL"] = "1024"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,15 +16,14 @@ torch.cuda.synchronize()
 ws = ops.workspace(0, torch.device(dev))
 raw = ws[256 * 64: 256 * 64 + 256 * 1024].view(torch.int32).view(256, 16, 2, 8).cpu().numpy().astype(np.int64) & 0xffffffff
 assert torch.equal(idx, ops.vq_argmin(zs[5], E, fast=False)), "stamped kernel must still be exact"   # (overwrites the workspace)
-names = ["bar", "P0", "P1", "S1", "C0", "C1", "M0", "M1"]
 for tl in range(2):
-    st = raw[:, :, tl, :]                                     # [wg, wave, 8]
-    base = st[:, :, 0].min(axis=1, keepdims=True)[:, :, None]
+    st = raw[:, :, tl, :]                                     # [wg, wave, 8]: 0 barrier left, 2 matrix phase (+ conversion, merge) done,
+    base = st[:, :, 0].min(axis=1, keepdims=True)[:, :, None]  #                3 scores stored, 4 record done (= barrier reached)
     rel = (st - base) & 0xffffffff
-    med = np.median(rel, axis=0)                              # [wave, 8]
+    med = np.median(rel, axis=0)
     nxt = np.median(((raw[:, :, 1, 0].min(axis=1) - raw[:, :, 0, 0].min(axis=1)) & 0xffffffff)) if tl == 0 else float("nan")
     print(f"period {3 + tl}: cycles after the first wave left the barrier (next period's barrier: {nxt:.0f})")
-    print("wave q " + " ".join(f"{n:>6s}" for n in names) + "   |  P dur  S dur  C dur  M dur")
+    print("wave    bar  P+C+M done  scores done  record done")
     for w in range(16):
         m = med[w]
-        print(f"{w:4d} {w >> 2} " + " ".join(f"{v:6.0f}" for v in m) + f"   | {m[2] - m[1]:6.0f} {m[3] - m[2]:6.0f} {m[5] - m[4]:6.0f} {m[7] - m[6]:6.0f}")
+        print(f"{w:4d} {m[0]:6.0f} {m[2]:11.0f} {m[3]:12.0f} {m[4]:12.0f}")
