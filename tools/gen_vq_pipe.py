@@ -49,6 +49,7 @@ import os
 import sys
 
 FD = 2
+DEFAULT_VAR = 0                                # structure switches of period(): see there; stamps = 8 (diagnostics)
 
 # ---- LDS layout: must match vq_pipe.hip (static_assert'ed there through the VQP_* macros this file emits)
 K, TILE, MAX_TILES, NWV = 512, 32, 8, 16
@@ -84,7 +85,7 @@ S_UND, S_MASK, S_MM1 = 92, 93, 95
 S_FIRST, S_LAST = 64, 99
 # s64-s79 temporaries; s80 / s81: nonzero = nothing to record for the row (decided, or not live); s82:83 not-live masks
 S_M, S_NTL, S_ROWSTEP, S_EA, S_EB, S_EC, S_LDSB, S_WAVE = ("%[M]", "%[ntl]", "%[rowstep]", "%[epsa]", "%[epsb]", "%[epsc]",
-                                                           "%[ldsb]", "%[wave]")
+                                                           "%[ldsb]", "%[wave]")   # and %[q] = wave / 4, %[row0], %[zplo], %[zphi], %[img]
 
 uid = [0]
 
@@ -257,14 +258,15 @@ def record(tm):
     return o
 
 
-def schedule(head, steps, filler):
-    """head, then per step its instructions followed by a share of the filler; every `need` becomes a counted s_waitcnt lgkmcnt"""
+def schedule(head, steps, filler, gaps=None):
+    """head, then per step its instructions followed by a share of the filler (spread over the first `gaps` steps; default: all);
+    every `need` becomes a counted s_waitcnt lgkmcnt"""
     order = list(head)
-    n = max(len(steps), 1)
+    n = max(min(len(steps), gaps or len(steps)), 1)
     fi = 0
     for s, st in enumerate(steps):
         order += st
-        stop = len(filler) * (s + 1) // n
+        stop = len(filler) * min(s + 1, n) // n
         while fi < len(filler) and (fi < stop or filler[fi - 1]["glue"]):
             order.append(filler[fi])
             fi += 1
@@ -295,7 +297,11 @@ def stamp(t, k):
             "s_waitcnt lgkmcnt(0)", f"v_mov_b32_e32 v{W[0]}, s98", f"v_mov_b32_e32 v{W[1]}, s64", f"ds_write_b32 v{W[1]}, v{W[0]}"]
 
 
-def period(t, abl, interleave=True):
+def period(t, abl, var):
+    """var bits: 1 = the waves w >= 8 (the two younger of a SIMD's four) store the scores of tile t at the START of period t + 1, so that
+    their vector phase runs beside the older waves' matrix phase instead of behind everybody's (merges then lag two tiles);
+    2 = the vector work fills the first ten MFMA gaps only; 4 = static wave priority (block start)"""
+    lag = 2 if var & 1 else 1
     st = t % 2
     head, steps = products(t, mfma=not (abl & 32), reads=not (abl & 64))
     filler = []
@@ -304,30 +310,50 @@ def period(t, abl, interleave=True):
         filler += convert(t + 2, st, on=not (abl & 4), wait=wait)
     if t + 4 < MAX_TILES:
         filler += loads(t + 4, st, on=not (abl & 1), nt=not (abl & 256), hot=bool(abl & 512))
-    if t >= 1:
-        filler += merge(t - 1, on=not (abl & 2))
+    if t >= lag:
+        filler += merge(t - lag, on=not (abl & 2))
     o = ["s_waitcnt lgkmcnt(0)"]
     if not (abl & 16):
         o.append("s_barrier")
     o += stamp(t, 0)
-    if interleave:
-        o += schedule(head, steps, filler)
-    else:                                          # diagnostics: the vector work in front of the matrix phase instead of inside it
-        o += schedule(filler, [], []) + stamp(t, 1) + schedule(head, steps, [])
+    if (var & 1) and t >= 1:
+        skip = label("nodefer")
+        o += ["s_cmp_lt_u32 %[q], 2", f"s_cbranch_scc1 {skip}"] + [i["t"] for i in scores(t - 1, on=not (abl & 8))[1:]] + [f"{skip}:"]
+    o += stamp(t, 1)
+    o += schedule(head, steps, filler, gaps=10 if var & 2 else None)
     o += stamp(t, 2)
-    o += [i["t"] for i in scores(t, on=not (abl & 8))]
+    sc = [i["t"] for i in scores(t, on=not (abl & 8))]
+    if var & 1:
+        skip = label("deferred")
+        o += ["s_cmp_ge_u32 %[q], 2", f"s_cbranch_scc1 {skip}"] + sc + [f"{skip}:"]
+    else:
+        o += sc
     o += stamp(t, 3)
-    if t >= 1 and not (abl & 2):
-        o += record(t - 1)
+    if t >= lag and not (abl & 2):
+        o += record(t - lag)
     o += stamp(t, 4)
     return o
 
 
-def program(abl=0, stamps=False, interleave=True):
+def leave(t, abl, var):
+    """behind the workgroup's last period t: the deferred scores of that tile"""
+    if not (var & 1):
+        return []
+    skip = label("left")
+    return ["s_cmp_lt_u32 %[q], 2", f"s_cbranch_scc1 {skip}"] + [i["t"] for i in scores(t, on=not (abl & 8))] + [f"{skip}:"]
+
+
+def program(abl=0, var=0, stamps=False):
     uid[0] = 0
     STAMPS[0] = stamps
     lane = W[0]
-    o = [f"s_mov_b32 s{S_MASK}, 0xffffffe0", f"s_sub_u32 s{S_MM1}, {S_M}, 1", f"s_mov_b32 s{S_UND}, 0",
+    o = []
+    if var & 4:                                    # static priority: the younger a wave of a SIMD, the higher (age breaks ties the other way)
+        l1, l2, l3, le = label("p1"), label("p2"), label("p3"), label("pe")
+        o += ["s_cmp_eq_u32 %[q], 1", f"s_cbranch_scc1 {l1}", "s_cmp_eq_u32 %[q], 2", f"s_cbranch_scc1 {l2}", "s_cmp_eq_u32 %[q], 3",
+              f"s_cbranch_scc1 {l3}", f"s_branch {le}", f"{l1}:", "s_setprio 1", f"s_branch {le}", f"{l2}:", "s_setprio 2", f"s_branch {le}",
+              f"{l3}:", "s_setprio 3", f"{le}:"]
+    o += [f"s_mov_b32 s{S_MASK}, 0xffffffe0", f"s_sub_u32 s{S_MM1}, {S_M}, 1", f"s_mov_b32 s{S_UND}, 0",
          # resa = L_RES + (2 wave + lane / 32) * 8 from rsa = L_RS + (2 wave + lane / 32) * 4
          f"s_add_u32 s64, {S_LDSB}, {L_RS}", f"v_subrev_u32_e32 v{V_RESA}, s64, v{V_RSA}", f"v_lshlrev_b32_e32 v{V_RESA}, 1, v{V_RESA}",
          f"s_add_u32 s64, {S_LDSB}, {L_RES}", f"v_add_u32_e32 v{V_RESA}, s64, v{V_RESA}"]
@@ -356,10 +382,14 @@ def program(abl=0, stamps=False, interleave=True):
           f"ds_write_b64 v{W[2]}, v[{W[0]}:{W[1]}]", "s_mov_b64 exec, -1"]
     # ---- the eight periods; behind period t the block leaves when the workgroup has no tile t + 1
     done = label("done")
+    exits = []
     for t in range(MAX_TILES):
-        o += period(t, abl, interleave)
+        o += period(t, abl, var)
         if t + 1 < MAX_TILES:
-            o += [f"s_cmp_le_i32 {S_NTL}, {t + 1}", f"s_cbranch_scc1 {done}"]
+            ex = label(f"exit{t}")
+            o += [f"s_cmp_le_i32 {S_NTL}, {t + 1}", f"s_cbranch_scc1 {ex}"]
+            exits += [f"{ex}:"] + leave(t, abl, var) + [f"s_branch {done}"]
+    o += leave(MAX_TILES - 1, abl, var) + [f"s_branch {done}"] + exits
     o += [f"{done}:",
           "s_waitcnt vmcnt(0)",                                           # rows behind the last tile (never used) have landed
           # undecided-row count of this wave -> L_CNT[4 + wave]
@@ -368,6 +398,8 @@ def program(abl=0, stamps=False, interleave=True):
           f"v_mov_b32_e32 v{W[0]}, s64", f"v_mov_b32_e32 v{W[1]}, s{S_UND}", f"ds_write_b32 v{W[0]}, v{W[1]}",
           "s_mov_b64 exec, -1",
           "s_waitcnt lgkmcnt(0)"]
+    if var & 4:
+        o.append("s_setprio 0")
     return o
 
 
@@ -385,17 +417,27 @@ def main():
                      ("L_REC", L_REC), ("L_PAIR", L_PAIR), ("L_SLOW", L_SLOW), ("L_UND", L_UND), ("UND_PER_WAVE", UND_PER_WAVE),
                      ("L_CNT", L_CNT), ("L_DBG", L_DBG), ("LDS_BYTES", LDS_BYTES), ("FD", FD)):
             f.write(f"#define VQP_{k} {v}\n")
-        f.write("#define VQP_ASM_DEFAULT \\\n    " + lit(program()) + "\n")
+        f.write(f"#define VQP_DEFAULT_VAR {DEFAULT_VAR}\n")
+        f.write(f"#define VQP_ASM_0_{DEFAULT_VAR} \\\n    " + lit(program(var=DEFAULT_VAR)) + "\n")
+        combos = [(0, DEFAULT_VAR)]
         f.write("#ifdef DVQ_DIAG\n")
-        f.write("#define VQP_ASM_NOROT \\\n    " + lit(program(interleave=False)) + "\n")
-        f.write("#define VQP_ASM_STAMPS \\\n    " + lit(program(stamps=True)) + "\n")
-        for abl in (1, 2, 4, 8, 32, 96, 15, 130, 256, 512, 3):
-            f.write(f"#define VQP_ASM_ABL{abl} \\\n    " + lit(program(abl=abl)) + "\n")
+        for var in (0, 1, 2, 3, 4, 5, 7):
+            for stamps in (0, 8):
+                if (0, var | stamps) in combos:
+                    continue
+                combos.append((0, var | stamps))
+                f.write(f"#define VQP_ASM_0_{var | stamps} \\\n    " + lit(program(var=var, stamps=bool(stamps))) + "\n")
+        for abl in (1, 2, 4, 8, 32, 96, 15, 256, 512):
+            combos.append((abl, DEFAULT_VAR))
+            f.write(f"#define VQP_ASM_{abl}_{DEFAULT_VAR} \\\n    " + lit(program(abl=abl, var=DEFAULT_VAR)) + "\n")
+        f.write("#define VQP_VARIANTS(X) " + " ".join(f"X({a}, {v})" for a, v in combos) + "\n")
+        f.write("#else\n")
+        f.write(f"#define VQP_VARIANTS(X) X(0, {DEFAULT_VAR})\n")
         f.write("#endif\n")
         clob = ([f'"v{i}"' for i in list(range(0, 48)) + [V_RESA, V_THR, V_VAL] + list(range(64, 128))]
                 + [f'"s{i}"' for i in range(S_FIRST, S_LAST + 1)])
         f.write("#define VQP_ASM_CLOBBERS " + ", ".join(clob) + ', "vcc", "scc", "memory"\n')
-    prog = program()
+    prog = program(var=DEFAULT_VAR)
     per = [i for i, l in enumerate(prog) if l == "s_barrier"]
     print("wrote", os.path.normpath(out), "- instructions + labels in the default block:", len(prog),
           "; period 3:", per[4] - per[3] if len(per) > 4 else "?")

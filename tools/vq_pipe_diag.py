@@ -46,6 +46,11 @@ def stamps():
 
 
 os.environ["DVQ_VQ_KERNEL"] = "17"
+ONLY = os.environ.get("VQP_DIAG_ONLY")            # "var": the structure variants only
+if ONLY == "var":
+    VARIANTS_FILTER = lambda env: "DVQ_VQP_VAR" in env
+else:
+    VARIANTS_FILTER = lambda env: True
 setenv(DVQ_VQP_DBG=1)
 d, span, st = stamps()
 t0 = st[:, 0].min()
@@ -57,11 +62,14 @@ for k, v in ph.items():
 print("kernel span (first start .. last end): %.2f us" % span)
 print("pairs per workgroup: mean %.1f max %d; all-entries rows: %d" % (st[:, 5].mean(), st[:, 5].max(), st[:, 6].sum()))
 print("%-46s %8s | %8s %8s %8s %8s %8s" % ("variant", "call us", "prologue", "loop", "merge", "refine", "span"))
-VARIANTS = [({}, "default"), ({"DVQ_VQP_VAR": 0}, "no rotation")] + [({"DVQ_VQP_ABL": a}, f"ABL {a:3d} {w}") for a, w in (
-    (32, "no MFMA"), (96, "no MFMA, no fragment reads"), (4, "no conversion"), (8, "no scoring"), (2, "no merge"), (1, "no row loads"),
-    (15, "no loads/merge/conversion/scoring"), (130, "no merge, rows not waited for"), (3, "no merge, no row loads"),
-    (256, "row loads without nt"), (512, "row loads from tile 0 only (L2)"))]
+VARIANTS = ([({"DVQ_VQP_VAR": v}, f"VAR {v}: " + w) for v, w in (
+    (0, "as generated"), (1, "deferred scores of waves 8-15"), (2, "vector work in the first ten gaps"), (3, "1 + 2"),
+    (4, "static priority, younger first"), (5, "1 + 4"), (7, "1 + 2 + 4"))]
+    + [({"DVQ_VQP_ABL": a}, f"ABL {a:3d} {w}") for a, w in (
+        (32, "no MFMA"), (96, "no MFMA, no fragment reads"), (4, "no conversion"), (8, "no scoring"), (2, "no merge"), (1, "no row loads"),
+        (15, "no loads/merge/conversion/scoring"), (256, "row loads without nt"), (512, "row loads from tile 0 only (L2)"))])
 for env, what in VARIANTS:
+    if not VARIANTS_FILTER(env): continue
     setenv(**env)
     t = timeit()
     setenv(DVQ_VQP_DBG=1, **env)
