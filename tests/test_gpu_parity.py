@@ -1509,11 +1509,11 @@ def test_skinny_gemm_equals_tiled_kernels_bitwise(kind):
 
 
 def test_vq_kernel_variants_agree():
-    """The sixteen-wave streaming kernel (DVQ_VQ_KERNEL=16) returns the eight-wave kernel's indices on random rows, ragged
-    sizes, ties, near-ties, non-finite and out-of-range rows."""
+    """The streaming kernels (DVQ_VQ_KERNEL=16 default, 17 = round 6's generated instruction block, 32, 8) return the same indices on
+    random rows, ragged sizes (one tile, two launches), ties, near-ties, non-finite and out-of-range rows."""
     torch.manual_seed(11)
     E = gpu(torch.randn(512, 256))
-    cases = [gpu(torch.randn(M, 256)) for M in (1, 31, 33, 1000, 8192 + 5, 65536)]
+    cases = [gpu(torch.randn(M, 256)) for M in (1, 31, 33, 1000, 8192 + 5, 65536, 69632 + 7)]
     z = torch.randn(300, 256)
     z[0] = E[7].cpu(); z[1] = 0.5 * (E[3] + E[9]).cpu(); z[2, 5] = float("nan"); z[3, 9] = float("inf"); z[4] = 0.0
     z[5] = 7.0e4; z[6] = 1e-6 * z[6]; z[10:40] = E[100:130].cpu() + 1e-4 * torch.randn(30, 256)
@@ -1524,8 +1524,24 @@ def test_vq_kernel_variants_agree():
     def run():
         return [ops.vq_argmin(c_, E, packed=pk, fast=True) for c_ in cases] + [ops.vq_argmin(cases[3], Et, packed=pkt, fast=True)]
     a = run()
-    for kern in ("16", "32", "8"):                                    # 32: rows resident, codebook streamed (vq_rows.hip)
+    for kern in ("16", "17", "32", "8"):                              # 32: rows resident, codebook streamed (vq_rows.hip)
         b = _with_env("DVQ_VQ_KERNEL", kern, run)
         for i, (x, y) in enumerate(zip(a, b)):
             assert torch.equal(x, y), f"DVQ_VQ_KERNEL={kern}, case {i}: {int((x != y).sum())} rows differ"
     assert torch.equal(a[3], ops.vq_argmin(cases[3], E, fast=False))
+
+
+def test_vq_pipe_kernel_passes_the_fast_path_tests():
+    """DVQ_VQ_KERNEL=17 (vq_pipe.hip: the prologue and the eight tile periods as one generated instruction block, a-priori rounding
+    bound, merge decided on the scalar unit) under the fast path's own tests: adversarial rows, incomplete candidate lists (pair
+    list overflow -> all-entries scan), scales and the tie-prone codebook, ragged sizes against the C oracle, 160-case fuzz, full
+    size with repeatability."""
+    def run():
+        for M in (1, 31, 32, 33, 1000, 4096):
+            test_vq_fast_equals_exact_and_canonical(M)
+        test_vq_fast_adversarial_rows()
+        test_vq_fast_incomplete_candidate_lists()
+        test_vq_fast_scales_and_tie_prone_codebook()
+        test_vq_fast_fuzz_shapes_scales_and_degenerate_rows()
+        test_vq_fast_full_size()
+    _with_env("DVQ_VQ_KERNEL", "17", run)

@@ -1,3 +1,3 @@
-# correctness of every structure variant (diagnostics library), then timings
-for v in 1 2 3 4 5 7; do DVQ_DIAG_LIB=1 DVQ_VQP_VAR=$v timeout 120 python tools/vq_pipe_probe.py 70001 2>&1 | grep -v "amdgpu.ids\|DIAGNOSTICS" | tail -1; done
-VQP_STAGES="small full" VQP_STAMP_VARS="0 1 3" VQP_DIAG_ONLY=var bash tools/vq_pipe_gpu.sh
+mkdir -p gpurun_out/vqp
+timeout 300 python tools/vq_pipe_check.py full adv time 2>&1 | grep -v "amdgpu.ids" | tee gpurun_out/vqp/check.log | tail -14
+VQP_DIAG_ONLY=var timeout 600 python tools/vq_pipe_diag.py 2>&1 | grep -v "amdgpu.ids\|DIAGNOSTICS" | tee gpurun_out/vqp/diag.log | tail -18

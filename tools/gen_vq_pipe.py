@@ -49,7 +49,7 @@ import os
 import sys
 
 FD = 2
-DEFAULT_VAR = 0                                # structure switches of period(): see there; stamps = 8 (diagnostics)
+DEFAULT_VAR = 1                                # structure switches of period(): see there; stamps = 8 (diagnostics)
 
 # ---- LDS layout: must match vq_pipe.hip (static_assert'ed there through the VQP_* macros this file emits)
 K, TILE, MAX_TILES, NWV = 512, 32, 8, 16
@@ -114,7 +114,7 @@ def dpp_reduce(op, dst, src):
     return o
 
 
-def products(t, mfma=True, reads=True):
+def products(t, mfma=True, reads=True, prio=False):
     """matrix phase of tile t: head, then 16 steps (the instructions in front of each gap)"""
     zb = (t % NZB) * Z16_BUF
     head = [I(f"ds_read_b128 v[0:3], v{V_EESA}", lds="ci0"), I(f"ds_read_b128 v[4:7], v{V_EESA} offset:32", lds="ci1"),
@@ -130,7 +130,11 @@ def products(t, mfma=True, reads=True):
               else I("s_nop 0", need=need)]
         if s + FD < 16:
             st.append(I(f"ds_read_b128 {FRAG[s % FD]}, v{V_ZBASE}{off(zb + 32 * (s + FD))}", lds=f"f{s + FD}"))
+        if prio and s % 4 == 0:                    # the further behind a wave is, the higher its priority: the four waves of a SIMD
+            st.insert(0, I(f"s_setprio {3 - s // 4}"))     # go through the period side by side instead of one after the other
         steps.append(st)
+    if prio:
+        steps[-1].append(I("s_setprio 0"))
     return head, steps
 
 
@@ -245,6 +249,12 @@ def record(tm):
     for half, (flag, lane_exec) in enumerate(((80, ("1", "0")), (81, ("0", "1")))):
         nound = label("nound")
         o += [f"s_cmp_lg_u32 s{flag}, 0", f"s_cbranch_scc1 {nound}",
+              # the row's 1 KB -> L2, for the canonical chains behind the loop (one dword per 16 bytes touches its eight lines; the
+              # destination is never read; one more load in flight only makes the counted vmcnt waits longer)
+              f"s_mul_i32 s74, {S_ROWSTEP}, {tm}", "s_add_i32 s74, s74, %[row0]", f"s_add_i32 s74, s74, {half}",
+              "s_mov_b32 s75, 0", "s_lshl_b64 s[74:75], s[74:75], 10", "s_add_u32 s74, s74, %[zplo]", "s_addc_u32 s75, s75, %[zphi]",
+              f"v_mbcnt_lo_u32_b32 v{a}, -1, 0", f"v_mbcnt_hi_u32_b32 v{a}, -1, v{a}", f"v_lshlrev_b32_e32 v{a}, 4, v{a}",
+              f"global_load_dword v{V_VAL}, v{a}, s[74:75]",
               f"s_mov_b32 exec_lo, {lane_exec[0]}", f"s_mov_b32 exec_hi, {lane_exec[1]}",
               f"ds_write_b32 v{V_RESA}, v{V_THR}{off(L_REC - L_RES + tm * TILE * 8)}",
               # rowslot = tm * 32 + 2 wave + half; list address = L_UND + (wave * UND_PER_WAVE + und) * 2
@@ -300,10 +310,11 @@ def stamp(t, k):
 def period(t, abl, var):
     """var bits: 1 = the waves w >= 8 (the two younger of a SIMD's four) store the scores of tile t at the START of period t + 1, so that
     their vector phase runs beside the older waves' matrix phase instead of behind everybody's (merges then lag two tiles);
-    2 = the vector work fills the first ten MFMA gaps only; 4 = static wave priority (block start)"""
+    2 = the vector work fills the first ten MFMA gaps only; 4 = static wave priority (block start); 16 = priority by progress:
+    3 for MFMAs 0-3, 2 for 4-7, 1 for 8-11, 0 behind (a wave that is behind overtakes)"""
     lag = 2 if var & 1 else 1
     st = t % 2
-    head, steps = products(t, mfma=not (abl & 32), reads=not (abl & 64))
+    head, steps = products(t, mfma=not (abl & 32), reads=not (abl & 64), prio=bool(var & 16))
     filler = []
     if t + 2 < MAX_TILES:                          # tile t + 2 from its register set (behind it nothing loads into the other set:
         wait = None if (abl & 1) or (abl & 128) else (2 if t + 3 < MAX_TILES else 0)       # the last set waits for everything)
@@ -421,7 +432,7 @@ def main():
         f.write(f"#define VQP_ASM_0_{DEFAULT_VAR} \\\n    " + lit(program(var=DEFAULT_VAR)) + "\n")
         combos = [(0, DEFAULT_VAR)]
         f.write("#ifdef DVQ_DIAG\n")
-        for var in (0, 1, 2, 3, 4, 5, 7):
+        for var in (0, 1, 5, 16, 17, 18, 19):
             for stamps in (0, 8):
                 if (0, var | stamps) in combos:
                     continue

@@ -63,8 +63,8 @@ print("kernel span (first start .. last end): %.2f us" % span)
 print("pairs per workgroup: mean %.1f max %d; all-entries rows: %d" % (st[:, 5].mean(), st[:, 5].max(), st[:, 6].sum()))
 print("%-46s %8s | %8s %8s %8s %8s %8s" % ("variant", "call us", "prologue", "loop", "merge", "refine", "span"))
 VARIANTS = ([({"DVQ_VQP_VAR": v}, f"VAR {v}: " + w) for v, w in (
-    (0, "as generated"), (1, "deferred scores of waves 8-15"), (2, "vector work in the first ten gaps"), (3, "1 + 2"),
-    (4, "static priority, younger first"), (5, "1 + 4"), (7, "1 + 2 + 4"))]
+    (0, "as generated"), (1, "deferred scores of waves 8-15"), (5, "1 + static priority, younger first"),
+    (16, "priority by progress"), (17, "16 + 1"), (18, "16 + vector work in the first ten gaps"), (19, "16 + 1 + 2"))]
     + [({"DVQ_VQP_ABL": a}, f"ABL {a:3d} {w}") for a, w in (
         (32, "no MFMA"), (96, "no MFMA, no fragment reads"), (4, "no conversion"), (8, "no scoring"), (2, "no merge"), (1, "no row loads"),
         (15, "no loads/merge/conversion/scoring"), (256, "row loads without nt"), (512, "row loads from tile 0 only (L2)"))])

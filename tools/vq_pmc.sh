@@ -14,7 +14,7 @@ for sub in ("a", "b"):
     for p in glob.glob(f"{out}/{sub}/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(lambda: [0.0, 0])
         for row in csv.DictReader(open(p)):
-            if "vq_stream" not in row["Kernel_Name"]: continue
+            if "vq_stream" not in row["Kernel_Name"] and "vq_pipe" not in row["Kernel_Name"]: continue
             a = acc[row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
         for k, (v, n) in sorted(acc.items()):
             print(f"{k:34s} per launch {v / n:16.0f}   ({n} launches)")
