@@ -125,6 +125,8 @@ def test_every_barrier_waits_for_the_waves_own_lds_operations():
         return
     sys.path.insert(0, os.path.join(root, "tools"))
     import check_barriers
+    if not os.path.exists(os.path.join(csrc, "vq_pipe_loop.h")):         # generated, not tracked (the Makefile has the same rule)
+        subprocess.run([sys.executable, os.path.join(root, "tools", "gen_vq_pipe.py")], check=True, capture_output=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-S", "--cuda-device-only"]
     with tempfile.TemporaryDirectory() as tmp:
         def build(src):
