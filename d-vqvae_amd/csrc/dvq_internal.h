@@ -225,7 +225,7 @@ struct DvqKnobs {
     int pn_exhaustive;    // 1: exact stage evaluates every point (what the filter must reproduce bit for bit)
     int pn_caps[2];       // candidate-list capacities (tests shrink them to reach the overflow paths); <= 0: default
     long pn_chunk;        // samples per PointNet launch (<= 0: at most 4 096, at least four launches per pass; DVQ_PN_CHUNK)
-    int pn_trunk3;        // DVQ_PN_TRUNK3=1: full tiles on pn_trunk3_kernel (three workgroups per CU; measured 4.5 % slower); default 0: pn_trunk_filter_kernel (two)
+    int pn_trunk3;        // diagnostics build only: DVQ_PN_TRUNK3=1: full tiles on pn_trunk3_kernel (three workgroups per CU; measured 4.5 % slower); default 0: pn_trunk_filter_kernel (two)
     int pn_streams;       // 1 (default): the exact stage / STN FCs of a launch on a second stream beside the next launch's trunk kernel (DVQ_PN_STREAMS=0: one stream)
     int pn_slots;         // scratch sets the launches rotate through (<= 0: 2; DVQ_PN_SLOTS)
     int pn_stats;

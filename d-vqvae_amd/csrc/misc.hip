@@ -43,7 +43,11 @@ DvqKnobs* read_knobs() {
     }
     k->pn_chunk = num("DVQ_PN_CHUNK");
     k->pn_streams = is("DVQ_PN_STREAMS", '0') ? 0 : 1;
-    k->pn_trunk3 = is("DVQ_PN_TRUNK3", '1') ? 1 : 0;
+#ifdef DVQ_DIAG
+    k->pn_trunk3 = is("DVQ_PN_TRUNK3", '1') ? 1 : 0;            // the kernel exists in the diagnostics build only
+#else
+    k->pn_trunk3 = 0;
+#endif
     k->pn_slots = (int)num("DVQ_PN_SLOTS");
     k->pn_stats = getenv("DVQ_PN_STATS") != nullptr;
     k->pixelcnn_chunk = num("DVQ_PIXELCNN_CHUNK");

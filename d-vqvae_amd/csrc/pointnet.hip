@@ -117,7 +117,10 @@ PnScratch plan(int64_t B, int N, void* ws) {
         s.slot[i].tstat = (unsigned*)take((size_t)chunk * (s.Npad / 256) * 16);
         s.slot[i].cbuf = take((size_t)chunk * 128 * 4);
     }
-    s.h1 = dvq_gemm_mode() == 1 ? nullptr : take((size_t)chunk * s.Npad * 64 * 4);   // the unfused trunk (DVQ_GEMM=fp32) only
+    // conv1 rows of the UNFUSED trunk: DVQ_GEMM=fp32, or a weights struct without bf16 planes (include/dvq.h: the planes are optional).
+    // That trunk runs on one stream and one scratch set, so with two sets it borrows the second set's conv2 rows (twice its size);
+    // with one set (a single launch) it gets rows of its own.
+    s.h1 = s.slots >= 2 ? s.slot[1].h2 : take((size_t)chunk * s.Npad * 64 * 4);
     s.stats = (unsigned long long*)take(64);
     s.f0 = take((size_t)chunk * 1024 * 4);
     s.f1 = take((size_t)chunk * 512 * 4);
@@ -215,9 +218,14 @@ PnSide* side_for(hipStream_t st) {
     PnSide*& sd = sides[std::make_pair(dev, st)];
     if (!sd) {
         PnSide* n = new PnSide();
-        // DVQ_PN_S2_PRIO=1: the second stream at the device's highest priority (its kernels are short and gate the next trunk launch)
+        // diagnostics build, DVQ_PN_S2_PRIO=1: the second stream at the device's highest priority (measured: no effect)
         int lo = 0, hi = 0;
+#ifdef DVQ_DIAG
         const bool prio = getenv("DVQ_PN_S2_PRIO") && getenv("DVQ_PN_S2_PRIO")[0] == '1' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
+#else
+        const bool prio = false;
+        (void)lo;
+#endif
         if ((prio ? hipStreamCreateWithPriority(&n->s2, hipStreamNonBlocking, hi) : hipStreamCreateWithFlags(&n->s2, hipStreamNonBlocking)) != hipSuccess) {
             delete n;
             return nullptr;
@@ -254,6 +262,16 @@ int encode_two_streams(const dvq_pointnet_weights* w, const float* pc, int64_t B
     PN_HIP(hipStreamWaitEvent(s2, sd->event(0), 0), "hipStreamWaitEvent");        // S2 starts behind everything enqueued on S1 so far
     float* tr_all = trans_out ? trans_out : s.tr;
     int rc = DVQ_OK;
+    // inside the loops a failed event / wait call sets rc and leaves them: the join below is ALWAYS attempted, so that nothing S2 still
+    // has in flight can touch the caller's workspace, features or transforms after this function has returned
+#define PN_TRY(call, what)                                                                      \
+    if (rc == DVQ_OK) {                                                                         \
+        const hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess) {                                                                \
+            dvq_set_error("pointnet_encode: %s failed: %s", what, hipGetErrorString(e__));     \
+            rc = DVQ_ELAUNCH;                                                                   \
+        }                                                                                       \
+    }
     long idx = 0;
     for (int pass = 0; pass < 2 && rc == DVQ_OK; ++pass)
         for (long c = 0; c < launches && rc == DVQ_OK; ++c, ++idx) {
@@ -262,35 +280,43 @@ int encode_two_streams(const dvq_pointnet_weights* w, const float* pc, int64_t B
             const float* pcb = pc + b0 * (long)w->C * N;
             const PnSlot& sl = s.slot[idx % s.slots];
             float* tr = tr_all + b0 * 9;
-            if (idx >= s.slots) PN_HIP(hipStreamWaitEvent(st, sd->event(e_free + idx % s.slots), 0), "hipStreamWaitEvent");
-            if (pass == 1) PN_HIP(hipStreamWaitEvent(st, sd->event(e_tr + c), 0), "hipStreamWaitEvent");
-            rc = pass == 0 ? dvq_launch_pn_filter_front(pcb, w->C, N, s.Npad, Bc, nullptr, w->s_w1, w->s_b1, w->s_w2, w->s_w2p, w->s_b2, w->s_w3f,
+            if (idx >= s.slots) PN_TRY(hipStreamWaitEvent(st, sd->event(e_free + idx % s.slots), 0), "hipStreamWaitEvent");
+            if (pass == 1) PN_TRY(hipStreamWaitEvent(st, sd->event(e_tr + c), 0), "hipStreamWaitEvent");
+            if (rc == DVQ_OK)
+                rc = pass == 0 ? dvq_launch_pn_filter_front(pcb, w->C, N, s.Npad, Bc, nullptr, w->s_w1, w->s_b1, w->s_w2, w->s_w2p, w->s_b2, w->s_w3f,
                                                         sl.h2, sl.part, sl.tstat, sl.cbuf, stats, st)
                            : dvq_launch_pn_filter_front(pcb, w->C, N, s.Npad, Bc, tr, w->w1, w->b1, w->w2, w->w2p, w->b2, w->w3f, sl.h2, sl.part,
                                                         sl.tstat, sl.cbuf, stats, st);
             if (rc != DVQ_OK) break;
-            PN_HIP(hipEventRecord(sd->event(e_front + idx % s.slots), st), "hipEventRecord");
-            PN_HIP(hipStreamWaitEvent(s2, sd->event(e_front + idx % s.slots), 0), "hipStreamWaitEvent");
+            PN_TRY(hipEventRecord(sd->event(e_front + idx % s.slots), st), "hipEventRecord");
+            PN_TRY(hipStreamWaitEvent(s2, sd->event(e_front + idx % s.slots), 0), "hipStreamWaitEvent");
             if (pass == 0) {
                 // STN3d: trunk with ReLU on the last layer, then fc1/fc2 (BN folded, ReLU) and fc3 (+identity)
-                rc = dvq_launch_pn_filter_back(N, s.Npad, Bc, w->s_w3f, w->s_w3, w->s_b3, 1, sl.h2, sl.part, sl.tstat, sl.cbuf, s.f0, 1024, stats, s2);
-                PN_HIP(hipEventRecord(sd->event(e_free + idx % s.slots), s2), "hipEventRecord");
+                if (rc == DVQ_OK) rc = dvq_launch_pn_filter_back(N, s.Npad, Bc, w->s_w3f, w->s_w3, w->s_b3, 1, sl.h2, sl.part, sl.tstat, sl.cbuf, s.f0, 1024, stats, s2);
+                PN_TRY(hipEventRecord(sd->event(e_free + idx % s.slots), s2), "hipEventRecord");
                 if (rc == DVQ_OK) rc = dense(s.f0, 1024, 1024, w->s_f1, w->s_f1p, w->s_c1, Bc, 512, 1, s.f1, 512, s2);
                 if (rc == DVQ_OK) rc = dense(s.f1, 512, 512, w->s_f2, w->s_f2p, w->s_c2, Bc, 256, 1, s.f2, 256, s2);
                 if (rc == DVQ_OK) rc = dense(s.f2, 256, 256, w->s_f3, w->s_f3p, w->s_c3, Bc, 9, 0, tr, 9, s2);
-                PN_HIP(hipEventRecord(sd->event(e_tr + c), s2), "hipEventRecord");
+                PN_TRY(hipEventRecord(sd->event(e_tr + c), s2), "hipEventRecord");
             } else {
                 // main trunk on the transformed cloud; no ReLU after the last BN (pointnet_encoder.py:162)
-                rc = dvq_launch_pn_filter_back(N, s.Npad, Bc, w->w3f, w->w3, w->b3, 0, sl.h2, sl.part, sl.tstat, sl.cbuf, feat + b0 * ld_feat, ld_feat, stats, s2);
-                PN_HIP(hipEventRecord(sd->event(e_free + idx % s.slots), s2), "hipEventRecord");
+                if (rc == DVQ_OK) rc = dvq_launch_pn_filter_back(N, s.Npad, Bc, w->w3f, w->w3, w->b3, 0, sl.h2, sl.part, sl.tstat, sl.cbuf, feat + b0 * ld_feat, ld_feat, stats, s2);
+                PN_TRY(hipEventRecord(sd->event(e_free + idx % s.slots), s2), "hipEventRecord");
             }
         }
-    // join: whatever happened, the caller's stream continues behind everything enqueued on S2
-    PN_HIP(hipEventRecord(sd->event(0), s2), "hipEventRecord");
-    PN_HIP(hipStreamWaitEvent(st, sd->event(0), 0), "hipStreamWaitEvent");
+#undef PN_TRY
+    // join: whatever happened, the caller's stream continues behind everything enqueued on S2 (best effort: a failure here is reported
+    // only when nothing failed before)
+    {
+        const hipError_t e1 = hipEventRecord(sd->event(0), s2);
+        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(st, sd->event(0), 0) : e1;
+        if (e2 != hipSuccess && rc == DVQ_OK) {
+            dvq_set_error("pointnet_encode: joining the second stream failed: %s", hipGetErrorString(e2));
+            rc = DVQ_ELAUNCH;
+        }
+    }
     return rc;
 }
-
 }  // namespace
 
 extern "C" size_t dvq_pointnet_workspace_bytes(int64_t B, int N) {
@@ -314,7 +340,7 @@ extern "C" int dvq_pointnet_encode(const dvq_pointnet_weights* w, const float* p
     }
     hipStream_t st = (hipStream_t)stream;
     const bool filtered = use_filter(w, N);
-    if (filtered && s.slots >= 2 && dvq_knobs().pn_streams) return encode_two_streams(w, pc, B, N, feat, ld_feat, trans_out, s, st);
+    if (filtered && s.slots >= 2 && dvq_knobs().pn_streams && !dvq_knobs().pn_stats) return encode_two_streams(w, pc, B, N, feat, ld_feat, trans_out, s, st);
     for (int64_t b0 = 0; b0 < B; b0 += s.chunk) {
         const long Bc = (long)((B - b0 < s.chunk) ? (B - b0) : s.chunk);
         const float* pcb = pc + b0 * (long)w->C * N;

@@ -691,6 +691,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     }
 }
 
+#ifdef DVQ_DIAG   // diagnostics build only (round 6): measured 4.5 % slower than the two-per-CU kernel; kept for tests/ and tools/, not shipped
 // ------------------------------------------------------------------------------------------------------------------------
 // pn_trunk3_kernel: the full-tile trunk kernel laid out for THREE workgroups per CU (<= 168 registers, <= 53 KB of LDS); same
 // arithmetic for conv1 / conv2 / h2, same record format, same run-time checks as pn_trunk_filter_kernel<C, false>.  What differs:
@@ -1070,6 +1071,8 @@ __global__ __launch_bounds__(256, PN3_WGS) void pn_trunk3_kernel(const float* __
     dvq_lds_barrier();
     publish(24);
 }
+
+#endif  // DVQ_DIAG (pn_trunk3_kernel)
 
 // ------------------------------------------------------------------------------------------------------------------------
 // exact_dot: THE definition of a conv3 score on this path.  16 lanes per dot, lane j owns k = 4j .. 4j+3 and 64+4j .. 64+4j+3 (fixed
@@ -1738,9 +1741,11 @@ int dvq_launch_pn_filter_front(const float* pc, int C, int N, int Npad, long B, 
     {
         DVQ_PROF("pn_trunk", 2.0 * pts * (4.0 * 64 + 64.0 * 128 + 128.0 * 1024), pts * (16 + 512) + (double)grid * 16384, st);
         const int lds_main = (abl & 524288) ? 100 * 1024 : F_LDS;   // diagnostics: ONE workgroup per CU (what a wave costs when it has its SIMD to itself)
-        // three workgroups per CU (pn_trunk3_kernel) unless DVQ_PN_TRUNK3=0 or a timing diagnostic of the two-per-CU kernel is asked for
+#ifdef DVQ_DIAG
+        // diagnostics build, DVQ_PN_TRUNK3=1: three workgroups per CU (pn_trunk3_kernel) unless a timing diagnostic of the two-per-CU
+        // kernel is asked for
         const bool three = dvq_knobs().pn_trunk3 && !(abl & ~(32768 | 65536));
-        const int G_LDS = getenv("DVQ_PN_G_LDS") ? atoi(getenv("DVQ_PN_G_LDS")) : pn_g_lds();   // EXPERIMENT
+        const int G_LDS = pn_g_lds();
         if (three && C == 3)
             DVQ_LAUNCH((pn_trunk3_kernel<3>), dim3((unsigned)grid), dim3(256), G_LDS, st, pc, trans, N, Npad, tiles, deal, B, W1, b1,
                        b2, (const char*)w3f, h2buf, (f32x4*)part, part2, tstat, cbuf, abl);
@@ -1748,6 +1753,7 @@ int dvq_launch_pn_filter_front(const float* pc, int C, int N, int Npad, long B, 
             DVQ_LAUNCH((pn_trunk3_kernel<4>), dim3((unsigned)grid), dim3(256), G_LDS, st, pc, trans, N, Npad, tiles, deal, B, W1, b1,
                        b2, (const char*)w3f, h2buf, (f32x4*)part, part2, tstat, cbuf, abl);
         else
+#endif
         if (C == 3)
             DVQ_LAUNCH((pn_trunk_filter_kernel<3, false>), dim3((unsigned)grid), dim3(256), lds_main, st, pc, trans, N, Npad, tiles, deal, B, W1, b1,
                        b2, (const char*)w3f, h2buf, (f32x4*)part, part2, tstat, cbuf, abl);

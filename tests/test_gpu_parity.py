@@ -1312,13 +1312,13 @@ def test_fp32_gemm_branch_matches_goldens(tmp_path):
 
 
 def test_pointnet_three_workgroups_per_cu_kernel(tmp_path):
-    """DVQ_PN_TRUNK3=1 (read when the library loads) puts the full tiles on pn_trunk3_kernel -- the trunk kernel laid out for three
+    """Diagnostics build + DVQ_PN_TRUNK3=1 (read when the library loads) puts the full tiles on pn_trunk3_kernel -- the trunk kernel laid out for three
     workgroups per CU (168 registers, 52 KB of LDS, 32-channel chunks; measured 4.5 % slower than the default and therefore not the
     default).  A fresh process runs the PointNet tests of this file on it: goldens, filtered == exhaustive bit for
     bit, tail tiles, ties, non-finite inputs, the run-time checks with their fault injection, and the two full-machine stress tests --
     the ones that caught this kernel's barrier without an LDS wait (csrc/dvq_internal.h: dvq_lds_barrier)."""
     import os, subprocess, sys
-    env = dict(os.environ, DVQ_PN_TRUNK3="1")
+    env = dict(os.environ, DVQ_PN_TRUNK3="1", DVQ_DIAG_LIB="1")          # (the kernel is compiled into the diagnostics build only)
     sel = ("test_pointnet_golden or test_pointnet_filter or test_pointnet_batched or test_pointnet_runtime_checks or "
            "test_pointnet_large_clouds or test_pointnet_pipeline")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", sel,
@@ -1418,6 +1418,22 @@ def test_pointnet_large_clouds_nonfinite_inputs_and_missing_filter_image():
         packed.cstruct.w3f, packed.cstruct.s_w3f = saved
     f6, _, _ = _with_env("DVQ_PN_FILTER", "0", lambda: net(x[:1].contiguous()))
     assert torch.equal(f_nofilter, f6)
+    # a struct without ANY pre-split plane (include/dvq.h: the planes are optional, all or nothing) takes the unfused trunk -- conv1 rows in
+    # scratch of its own (one launch) or in the second scratch set's (several launches): within 1e-5 of the plane kernels' features
+    cs = packed.cstruct
+    names = ("w3f", "s_w3f", "w2p", "w3p", "s_w2p", "s_w3p", "s_f1p", "s_f2p", "s_f3p")
+    saved = {n: getattr(cs, n) for n in names}
+    xs = gpu(synth.synthetic_clouds(2100, 300, seed=6, channels=4))    # > 2 048 samples: several launches, two scratch sets
+    try:
+        want1, want_many = net(x[:1].contiguous())[0], net(xs)[0]
+        for n in names:
+            setattr(cs, n, None)
+        got1, got_many = net(x[:1].contiguous())[0], net(xs)[0]
+    finally:
+        for n, v in saved.items():
+            setattr(cs, n, v)
+    assert_close(got1, want1, atol=TOL)
+    assert_close(got_many, want_many, atol=TOL)
 
 
 @pytest.mark.parametrize("dataset", ["obman", "grab", "FHAB"])
