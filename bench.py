@@ -106,8 +106,14 @@ def relaunch_if_needed(args):
         sys.exit(subprocess.call(cmd))
 
 
+_RANK_LOG = None
+
+
 def log(msg):
-    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+    line = f"[bench {time.strftime('%H:%M:%S')}] {msg}"
+    print(line, file=sys.stderr, flush=True)
+    if _RANK_LOG is not None:
+        print(line, file=_RANK_LOG, flush=True)
 
 
 def usable_cores():
@@ -586,6 +592,19 @@ def main():
     from dvqvae_amd.network.gen_net import GenNet
 
     rank, local_rank, world = dist.init(args.backend, args.share_gpu, args.force_pg)
+    if world > 1:
+        # every rank's stderr (its own log lines, tracebacks, RCCL's native messages) also lands in bench_rank<r>.log: ranks other
+        # than 0 write there only, rank 0 keeps the console as well
+        path = os.path.join(os.environ.get("DVQ_BENCH_LOG_DIR", "."), f"bench_rank{rank}.log")
+        try:
+            if rank == 0:
+                global _RANK_LOG
+                _RANK_LOG = open(path, "w")
+            else:
+                fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+                os.dup2(fd, 2)
+        except OSError as e:
+            log(f"no per-rank log file ({e})")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -687,6 +706,7 @@ def main():
             os.environ["DVQ_PN_STREAMS"] = pn_streams_was
         lib.dvq_reload_env()
 
+    rows_per_rank = dist.gather_objects([lo, hi])            # every rank's [lo, hi) of the global batch, as each rank computed it
     out = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -701,7 +721,11 @@ def main():
                                       f"the step, synthetic weights",
                           "global_batch": B_global, "points": N, "codebook": K, "parallelism": f"batch-shard x{world}",
                           "allgather_bytes_per_rank": B * 61 * 4,
-                          "collective": dist.collective_used}}
+                          "collective": dist.collective_used,
+                          # what the communication layer itself says it spans: ncclCommCount of the C ABI's communicator (None: the
+                          # collectives went through torch.distributed), the process group's size, and every rank's row range
+                          "rccl_ranks_seen": dist.comm_ranks_seen(dev), "process_group_ranks": world,
+                          "rows_per_rank": rows_per_rank}}
         if kernels:
             pe_ms = prof_elapsed * 1e3
             out["roofline"] = step_roofline(kernels, pe_ms, args.prof_steps, ms_per_step, B)

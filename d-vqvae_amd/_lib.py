@@ -22,7 +22,7 @@ _lock = threading.Lock()
 _lib = None
 
 DVQ_MAX_SRC = 8
-ABI_VERSION = 8            # DVQ_ABI_VERSION of include/dvq.h, which the struct mirrors below follow (tests/test_abi.py compares both with the library's)
+ABI_VERSION = 9            # DVQ_ABI_VERSION of include/dvq.h, which the struct mirrors below follow (tests/test_abi.py compares both with the library's)
 PLANES_BF16X3, PLANES_F16X2 = 0, 1
 
 c_f32p = C.c_void_p      # device pointers travel as integers
@@ -127,6 +127,7 @@ SIGNATURES = {
     "dvq_comm_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),
     "dvq_comm_init": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "dvq_allgather_params": (C.c_int, [C.c_void_p, c_f32p, C.c_int64, C.c_int, c_f32p, c_stream]),
+    "dvq_comm_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "dvq_comm_destroy": (C.c_int, [C.c_void_p]),
     "dvq_interior": (C.c_int, [c_f32p, c_f32p, C.c_int, c_f32p, C.c_int64, C.c_int64, C.c_int64, c_i64p, C.c_int64,
                                C.c_int, C.c_void_p, c_stream]),

@@ -8,7 +8,7 @@
 #include <dlfcn.h>
 #include <string.h>
 
-// The five RCCL entry points used here, declared locally (rccl.h's own declarations, ABI-stable since NCCL 2.0): the library
+// The six RCCL entry points used here, declared locally (rccl.h's own declarations, ABI-stable since NCCL 2.0): the library
 // builds on a machine without the RCCL headers and, resolving the symbols by dlopen, loads on one without the library.
 extern "C" {
 typedef struct ncclComm* ncclComm_t;
@@ -25,6 +25,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
@@ -48,7 +49,8 @@ const Rccl& rccl() {
         x.AllGather = (decltype(x.AllGather))dlsym(x.handle, "ncclAllGather");
         x.CommDestroy = (decltype(x.CommDestroy))dlsym(x.handle, "ncclCommDestroy");
         x.GetErrorString = (decltype(x.GetErrorString))dlsym(x.handle, "ncclGetErrorString");
-        x.ok = x.GetUniqueId && x.CommInitRank && x.AllGather && x.CommDestroy && x.GetErrorString;
+        x.CommCount = (decltype(x.CommCount))dlsym(x.handle, "ncclCommCount");
+        x.ok = x.GetUniqueId && x.CommInitRank && x.AllGather && x.CommDestroy && x.GetErrorString && x.CommCount;
         return x;
     }();
     return r;
@@ -89,6 +91,13 @@ extern "C" int dvq_allgather_params(void* comm, const float* local, int64_t rows
     if (!rccl().ok) { dvq_set_error("allgather_params: librccl not found"); return DVQ_ENODEVICE; }
     const ncclResult_t e = rccl().AllGather(local, out, (size_t)rows_per_rank * cols, ncclFloat32, (ncclComm_t)comm, (hipStream_t)stream);
     return e == ncclSuccess ? DVQ_OK : fail("allgather_params", e);
+}
+
+extern "C" int dvq_comm_count(void* comm, int* ranks_out) {
+    DVQ_REQUIRE(comm && ranks_out, "comm_count: null pointer");
+    if (!rccl().ok) { dvq_set_error("comm_count: librccl not found"); return DVQ_ENODEVICE; }
+    const ncclResult_t e = rccl().CommCount((ncclComm_t)comm, ranks_out);      // what RCCL itself says the communicator spans
+    return e == ncclSuccess ? DVQ_OK : fail("comm_count", e);
 }
 
 extern "C" int dvq_comm_destroy(void* comm) {

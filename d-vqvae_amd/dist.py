@@ -88,13 +88,45 @@ def _abi_comm(device: torch.device):
 
     handle, good = C.c_void_p(), False
     if everybody(have):
-        with torch.cuda.device(idx):
-            good = lib.dvq_comm_init(box[0], 128, world, rank, C.byref(handle)) == 0
+        # ncclCommInitRank blocks until every rank has joined the bootstrap: a rank that never arrives (a crashed peer, a blocked
+        # socket) would leave this one hanging for ever.  The call runs on a helper thread; if it has not returned after
+        # DVQ_COMM_TIMEOUT seconds (default 180) this process says so and EXITS non-zero -- the launcher then tears the job down.
+        import threading
+        result = {}
+
+        def init():
+            with torch.cuda.device(idx):
+                result["rc"] = lib.dvq_comm_init(box[0], 128, world, rank, C.byref(handle))
+        th = threading.Thread(target=init, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("DVQ_COMM_TIMEOUT", "180")))
+        if th.is_alive():
+            import sys
+            print(f"[dvq dist] rank {rank}/{world}: dvq_comm_init (RCCL bootstrap) did not return within the time limit; exiting",
+                  file=sys.stderr, flush=True)
+            os._exit(70)
+        good = result.get("rc", 1) == 0
         if not everybody(good) and good:
             lib.dvq_comm_destroy(handle)
             good = False
     _comms[idx] = handle if good else None
     return _comms[idx]
+
+
+def comm_ranks_seen(device: Optional[torch.device] = None) -> Optional[int]:
+    """Ranks of the C ABI's RCCL communicator as RCCL itself reports them (ncclCommCount through dvq_comm_count), or None when the
+    last collectives went through torch.distributed (gloo, the fallback, one process)."""
+    import ctypes as C
+    from . import _lib
+    if not _comms:
+        return None
+    idx = (device.index if device is not None and device.index is not None else torch.cuda.current_device())
+    h = _comms.get(idx)
+    if h is None:
+        return None
+    n = C.c_int(-1)
+    _lib.check(_lib.load().dvq_comm_count(h, C.byref(n)), "dvq_comm_count")
+    return int(n.value)
 
 
 def _gather_equal(local: torch.Tensor, world: int) -> torch.Tensor:
@@ -155,6 +187,15 @@ def all_gather_rows(local: torch.Tensor, total_rows: Optional[int] = None, verif
     buf[: local.shape[0]] = local
     out = _gather_equal(buf, world)                           # ragged: padded shards, the padding cut out afterwards
     return torch.cat([out[r * pad: r * pad + (hi - lo)] for r, (lo, hi) in enumerate(sizes)])
+
+
+def gather_objects(obj):
+    """every rank's small Python object, rank-major (one process: [obj])"""
+    if not _active():
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
 
 
 def barrier():

@@ -39,7 +39,7 @@ typedef enum {
 
 /* The version of this header.  dvq_abi_version() returns the library's: a binding checks the two for equality at load time
  * (struct layouts change between versions). */
-#define DVQ_ABI_VERSION 8
+#define DVQ_ABI_VERSION 9
 int dvq_abi_version(void);
 const char* dvq_last_error(void);
 /* number of visible HIP devices, or -1; does not create a context */
@@ -328,13 +328,15 @@ int dvq_interior(const float* normals /* [B,V,3] */, const float* hand /* [B,V,3
  *   dvq_allgather_params: out[r * rows_per_rank + i, :] = rank r's local[i, :]; enqueued on `stream`; equal shards only
  *                        (ragged batches: pad the shard, the host mirror does)
  * RCCL is resolved at the first call (dlopen); without it these return DVQ_ENODEVICE and the rest of the library is unaffected. */
-/* 1 when librccl and the five entry points used here resolve in this process, else 0: a probe that creates nothing (v8; making a
+/* 1 when librccl and the six entry points used here resolve in this process, else 0: a probe that creates nothing (v8; making a
  * unique id starts RCCL's bootstrap thread and socket, which only rank 0 should do) */
 int dvq_comm_available(void);
 int dvq_comm_unique_id(void* id_out, size_t id_bytes /* >= 128 */);
 int dvq_comm_init(const void* id, size_t id_bytes, int world, int rank, void** comm_out);
 int dvq_allgather_params(void* comm, const float* local /* [rows_per_rank, cols] */, int64_t rows_per_rank, int cols /* 61 */,
                          float* out /* [world * rows_per_rank, cols] */, dvq_stream_t stream);
+/* ranks of the communicator as RCCL reports them (ncclCommCount; v9): lets a caller show that the collective really spans N processes */
+int dvq_comm_count(void* comm, int* ranks_out);
 int dvq_comm_destroy(void* comm);
 
 /* ------------------------------------------------------------------ optional per-launch timing

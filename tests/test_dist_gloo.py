@@ -38,6 +38,9 @@ def _worker(rank, world, port, total, ret):
     uneven = full[: total // 3] if rank == 0 else full[total // 3:]                 # shards shard_range would not produce
     ok = ok and torch.equal(dist.all_gather_rows(uneven.clone()), full)
     mx = dist.max_over_ranks(float(rank + 1), "cpu")
+    rows = dist.gather_objects([lo, hi])                                            # the bench line's rows_per_rank
+    ok = ok and rows == [list(dist.shard_range(total, q, world)) for q in range(world)]
+    ok = ok and dist.comm_ranks_seen() is None                                      # no RCCL communicator under gloo
     dist.barrier()
     ret[rank] = (ok, mx)
     td.destroy_process_group()

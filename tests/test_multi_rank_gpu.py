@@ -14,6 +14,7 @@ import json
 import os
 import socket
 import subprocess
+import tempfile
 import sys
 
 import pytest
@@ -31,16 +32,20 @@ def _port():
 
 
 def _bench(extra, env=None, batch=None):
-    e = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_port())
+    logs = tempfile.mkdtemp(prefix="dvq_bench_logs_")                              # bench_rank<r>.log of every rank of this run
+    e = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_port(), DVQ_BENCH_LOG_DIR=logs)
     e.update(env or {})
     cmd = list(BENCH)
     if batch is not None:
         cmd[cmd.index("--batch") + 1] = str(batch)
     r = subprocess.run(cmd + extra, env=e, capture_output=True, text=True, timeout=2400, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    per_rank = {f: open(os.path.join(logs, f)).read()[-1500:] for f in sorted(os.listdir(logs))}
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:] + "".join(f"\n--- {f}\n{t}" for f, t in per_rank.items())
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, f"expected ONE JSON line on rank 0, got {len(lines)}:\n{r.stdout[-2000:]}"
-    return json.loads(lines[0])
+    line = json.loads(lines[0])
+    line["_rank_logs"] = sorted(per_rank)
+    return line
 
 
 @pytest.fixture(scope="module")
@@ -61,6 +66,8 @@ def test_bench_two_ranks_on_one_gpu_equals_one_rank(single):
 def test_bench_ragged_shards_three_ranks(single):
     three = _bench(["--gpus", "3", "--share-gpu", "--backend", "gloo"])      # 2048 = 683 + 683 + 682: the padded all-gather
     assert three["n_gpus"] == 3 and three["gathered_sha256"] == single["gathered_sha256"]
+    assert three["config"]["rows_per_rank"] == [[0, 683], [683, 1366], [1366, 2048]] and three["config"]["rccl_ranks_seen"] is None
+    assert three["_rank_logs"] == ["bench_rank0.log", "bench_rank1.log", "bench_rank2.log"]      # every rank's stderr, kept in a file
 
 
 def test_bench_eight_ranks_at_the_real_global_batch():
@@ -78,6 +85,11 @@ def test_bench_rccl_world_size_one(single):
     one = _bench(["--gpus", "1", "--force-pg", "--backend", "nccl"])
     assert "dvq_allgather_params" in one["config"]["collective"] and "RCCL" in one["config"]["collective"], one["config"]["collective"]
     assert one["gathered_sha256"] == single["gathered_sha256"]
+    # first-contact evidence of the bench line: what the communicator itself reports (ncclCommCount through dvq_comm_count), the
+    # process group's size, and the rows every rank computed, as gathered from the ranks
+    assert one["config"]["rccl_ranks_seen"] == 1 and one["config"]["process_group_ranks"] == 1
+    assert one["config"]["rows_per_rank"] == [[0, 2048]]
+    assert single["config"]["rccl_ranks_seen"] is None, "no communicator is made without a process group"
 
 
 def _generate(out_dir, nproc):
