@@ -94,6 +94,7 @@ def parse():
                     help="create the process group and run every collective even at world size 1 (first contact with RCCL on a "
                          "one-GPU box: init, all_gather_into_tensor, barrier, all_reduce)")
     ap.add_argument("--no-latency", action="store_true", help="skip the small-batch latency leg (B = 1, 8, 100)")
+    ap.add_argument("--sources-digest", action="store_true", help="print the digest of the kernel sources (what a PMC file must carry to be quoted) and exit")
     return ap.parse_args()
 
 
@@ -128,17 +129,55 @@ def usable_cores():
     return max(1, n)
 
 
+def kernel_sources_sha256():
+    """One digest over what the library's kernels are built from (d-vqvae_amd/csrc: *.hip, *.h but not the generated header, the
+    Makefile; the generator of the generated header): tools/collect_profiles.sh stores it beside the counters it collects, and
+    pmc_traffic() quotes a committed PMC file only while the digest still matches."""
+    import glob, hashlib
+    src = os.path.join(ROOT, "d-vqvae_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h")) + [os.path.join(src, "Makefile"),
+                   os.path.join(ROOT, "tools", "gen_vq_pipe.py")])
+    h = hashlib.sha256()
+    for f in files:
+        if os.path.basename(f) == "vq_pipe_loop.h":
+            continue
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read() + b"\0")
+    return h.hexdigest()
+
+
+def pmc_file_is_current(doc):
+    """(True, "") when the PMC file `doc` was collected on THIS tree's kernels, else (False, reason): the digest of the kernel
+    sources stored with the counters must equal this tree's, and where a git history is at hand (not on the GPU box) the commit
+    it names must be HEAD or an ancestor of it."""
+    want = doc.get("kernel_sources_sha256")
+    if not want:
+        return False, "the file carries no digest of the kernel sources it was collected on"
+    if want != kernel_sources_sha256():
+        return False, "the kernel sources changed since it was collected (digest differs)"
+    commit = doc.get("commit")
+    if commit and os.path.isdir(os.path.join(ROOT, ".git")):
+        import subprocess
+        try:
+            r = subprocess.run(["git", "-C", ROOT, "merge-base", "--is-ancestor", commit, "HEAD"], capture_output=True, timeout=20)
+            if r.returncode != 0:
+                return False, f"its commit {commit} is not HEAD or an ancestor of HEAD"
+        except Exception:
+            pass
+    return True, ""
+
+
 def pmc_traffic(kind, batch):
     """(HBM bytes per launch, source) of a kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction +
     WRITE_SIZE, profiles/*_pmc_hbm_traffic.json: an EARLIER run of the same command, collected at the default batch only);
-    (None, None) if there is none.  Not measured in this run: PMC collection needs rocprofv3 around the process.
+    (None, None) if there is none, (None, "refused: ...") if the newest file was collected on other kernels than this tree's
+    (pmc_file_is_current).  Not measured in this run: PMC collection needs rocprofv3 around the process.
     A profiler key covers every template variant the library launches under it (gemm_gate: plain launches <2, 4, false> and
     launches that continue a class-table accumulator state <2, 4, true>): the figure is the launch-weighted mean."""
     if batch != 65536:
         return None, None
     # kernel names as rocprofv3 prints them (truncated in the committed files): a PREFIX of the template-argument list, so that
     # "<2, 4>" (before the accumulator-state argument), "<2, 4, false>" and "<2, 4, true>" all match
-    names = {"vq_fast": ("::vq_stream",),      # vq_stream16_kernel (default) / vq_stream_kernel (DVQ_VQ_KERNEL=8)
+    names = {"vq_fast": ("::vq_stream", "::vq_pipe"),      # vq_stream16_kernel (default) / vq_stream_kernel (DVQ_VQ_KERNEL=8) / vq_pipe_kernel (17)
              "pn_trunk": ("pn_trunk_filter_kernel<4, false", "pn_trunk_filter_kernel<3, false", "pn_trunk_filter_kernel<4>", "pn_trunk_filter_kernel<3>"),
              "pn_exact": ("pn_exact_kernel",),
              "gemm_gate": ("gemm_f16x2_pp_kernel<2,", "gemm_f16x2_pp_kernel<2>"),
@@ -150,6 +189,9 @@ def pmc_traffic(kind, batch):
         import glob
         path = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))[-1]
         doc = json.load(open(path))
+        ok, why = pmc_file_is_current(doc)
+        if not ok:
+            return None, f"refused: profiles/{os.path.basename(path)} is stale -- {why}"
         want_scope = "vq microbench" if kind == "vq_fast" else None
         tot_b = tot_n = 0.0
         for row in doc["per_launch_bytes"]:
@@ -585,6 +627,9 @@ def config_leg(args, lib, _lib, dev):
 
 def main():
     args = parse()
+    if args.sources_digest:
+        print(kernel_sources_sha256())
+        return
     relaunch_if_needed(args)
     import torch
     import dvqvae_amd

@@ -1546,7 +1546,7 @@ template <int C>
 __global__ __launch_bounds__(256) void pn_center_kernel(const float* __restrict__ pc, const float* __restrict__ trans, int N, long B,
                                                         const float* __restrict__ W1, const float* __restrict__ b1,
                                                         const float* __restrict__ W2, const float* __restrict__ b2,
-                                                        float* __restrict__ cbuf) {
+                                                        float* __restrict__ cbuf, unsigned* __restrict__ tstat, int tiles) {
     __shared__ float w2t[64][129];                         // w2t[k][ch] = W2[ch][k] (row stride 129: conflict-free both ways)
     __shared__ float h1c[4][64];
     __shared__ float h2c[4][128];
@@ -1555,6 +1555,7 @@ __global__ __launch_bounds__(256) void pn_center_kernel(const float* __restrict_
     for (int sb = 0; sb < CENTER_SPB; ++sb) {
         const long b = (long)blockIdx.x * CENTER_SPB + sb;
         if (b >= B) break;
+        for (int i = tid; i < 4 * tiles; i += 256) tstat[b * 4 * tiles + i] = 0u;   // the sample's tile records start from zero (the trunk kernel's atomicMax targets): no memset launch
         {
             const int p = (int)(((long)q * N) / 4);
             const float* src = pc + b * (long)C * N + p;
@@ -1660,7 +1661,7 @@ int dvq_launch_pn_filter_pack(const float* w2, const float* w3, void* image, hip
     return DVQ_OK;
 }
 
-// tiles of 256 points; h2buf [B][Npad][128] fp32, part [B][tiles][1024] float4 (+ float2 behind them), tstat [B][tiles][4] (zeroed here).
+// tiles of 256 points; h2buf [B][Npad][128] fp32, part [B][tiles][1024] float4 (+ float2 behind them), tstat [B][tiles][4] (zeroed by pn_center_kernel).
 // Two halves, so that the caller may put them on different streams (pointnet.hip: the exact stage of one launch runs beside the trunk
 // kernel of the next): dvq_launch_pn_filter_front = centres + trunk kernel(s), dvq_launch_pn_filter_back = pn_exact_kernel.
 static int pn_filter_geometry(int N, int* tiles, int* deal) {
@@ -1705,16 +1706,15 @@ int dvq_launch_pn_filter_front(const float* pc, int C, int N, int Npad, long B, 
     const long grid = B * deal;
     DVQ_REQUIRE(B * tiles < (1L << 31), "pointnet: grid too large");
     DVQ_REQUIRE(Npad >= N, "pointnet: bad padded row count");
-    if (hipMemsetAsync(tstat, 0, (size_t)B * tiles * 16, st) != hipSuccess ||
-        (stats && hipMemsetAsync(stats, 0, 64, st) != hipSuccess)) {
+    if (stats && hipMemsetAsync(stats, 0, 64, st) != hipSuccess) {       // statistics runs only; tstat is zeroed by pn_center_kernel
         dvq_set_error("pointnet: hipMemsetAsync failed");
         return DVQ_ELAUNCH;
     }
     {
         DVQ_PROF("pn_center", 2.0 * (double)B * 4 * (4.0 * 64 + 64.0 * 128), (double)B * (64 + 512), st);
         const unsigned cgrid = (unsigned)((B + CENTER_SPB - 1) / CENTER_SPB);
-        if (C == 3) DVQ_LAUNCH(pn_center_kernel<3>, dim3(cgrid), dim3(256), 0, st, pc, trans, N, B, W1, b1, W2, b2, cbuf);
-        else DVQ_LAUNCH(pn_center_kernel<4>, dim3(cgrid), dim3(256), 0, st, pc, trans, N, B, W1, b1, W2, b2, cbuf);
+        if (C == 3) DVQ_LAUNCH(pn_center_kernel<3>, dim3(cgrid), dim3(256), 0, st, pc, trans, N, B, W1, b1, W2, b2, cbuf, tstat, tiles);
+        else DVQ_LAUNCH(pn_center_kernel<4>, dim3(cgrid), dim3(256), 0, st, pc, trans, N, B, W1, b1, W2, b2, cbuf, tstat, tiles);
     }
     DVQ_CHECK_LAUNCH("pn_center");
     const double pts = (double)B * (deal * 256 + (deal < tiles ? 32 : 0));
