@@ -124,7 +124,7 @@ def test_every_barrier_waits_for_the_waves_own_lds_operations():
     if not os.path.exists(hipcc):
         return
     sys.path.insert(0, os.path.join(root, "tools"))
-    import check_barriers
+    import check_barriers, check_hazards
     if not os.path.exists(os.path.join(csrc, "vq_pipe_loop.h")):         # generated, not tracked (the Makefile has the same rule)
         subprocess.run([sys.executable, os.path.join(root, "tools", "gen_vq_pipe.py")], check=True, capture_output=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-S", "--cuda-device-only"]
@@ -136,15 +136,47 @@ def test_every_barrier_waits_for_the_waves_own_lds_operations():
             return out
         with concurrent.futures.ThreadPoolExecutor(max_workers=6) as ex:
             listings = list(ex.map(build, sorted(glob.glob(os.path.join(csrc, "*.hip")))))
-        bad, barriers = [], 0
+        bad, barriers, hazards, mfmas = [], 0, [], 0
         for path in listings:
             text = open(path).read()
             barriers += text.count("s_barrier")
+            mfmas += text.count("v_mfma_")
             for name, body in check_barriers.functions(text):
                 if "s_barrier" in body:
                     bad += [(os.path.basename(path), name[:80], hit) for hit in check_barriers.check(body)]
+                # round 6: the same listings through tools/check_hazards.py -- producer / consumer pairs that need wait states the
+                # hardware does not insert (the compiler does not look inside the inline-asm loops: vq_pipe_loop.h is 6 000 lines of it)
+                hazards += [msg for _, _, msg in check_hazards.check_lines(body.splitlines(), strict=True, name=os.path.basename(path) + ":" + name[:60])]
     assert barriers > 100, f"only {barriers} s_barrier instructions found"
     assert not bad, f"s_barrier reachable with an LDS operation of the wave in flight: {bad}"
+    assert mfmas > 1000 and not hazards, f"missing wait states: {hazards[:5]}"
+
+
+def test_hazard_checker_rules():
+    """tools/check_hazards.py on two-instruction listings: each rule fires without the wait states and is quiet with them."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import check_hazards as ch
+    mfma = "v_mfma_f32_32x32x16_f16 v[0:15], v[16:19], v[20:23], v[0:15]"
+    cases = [("R3", ["v_add_f32_e32 v1, v2, v3", "v_mov_b32_dpp v4, v1 row_shr:1 row_mask:0xf bank_mask:0xf"], "s_nop 1"),
+             ("R1", ["v_readfirstlane_b32 s4, v1", "global_load_dword v5, v6, s[4:5]"], "s_nop 4"),
+             ("R2", ["v_cmp_le_f32_e64 s[64:65], v1, v2", "v_readlane_b32 s3, v5, s64"], "s_nop 3"),
+             ("R4", ["v_cmpx_le_f32_e32 v1, v2", "v_mov_b32_dpp v4, v9 row_shr:1"], "s_nop 4"),
+             ("R5", ["v_sqrt_f32_e32 v1, v1", "v_mul_f32_e32 v2, v1, v3"], "s_nop 0"),
+             ("R6", ["v_cvt_f16_f32_sdwa v1, v2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD", "v_add_f32_e32 v3, v1, v1"], "s_nop 0"),
+             ("R7", [mfma, "v_add_f32_e32 v30, v0, v1"], "s_nop 10"),
+             ("R7", [mfma, "ds_write_b32 v40, v3"], "s_nop 10"),
+             ("R8", ["v_cmp_lt_f32_e32 vcc, v1, v2", "v_div_fmas_f32 v3, v4, v5, v6"], "s_nop 3"),
+             ("R9", ["s_mov_b32 m0, s4", "buffer_load_dword v1, s[8:11], 0 offen lds"], "s_nop 0")]
+    for rule, pair, nop in cases:
+        assert [b[1] for b in ch.check_lines(pair)] == [rule], (rule, pair)
+        assert ch.check_lines([pair[0], nop, pair[1]]) == [], (rule, nop)
+        short = "s_nop %d" % (int(nop.split()[1]) - 1)
+        if int(nop.split()[1]) > 0:
+            assert [b[1] for b in ch.check_lines([pair[0], short, pair[1]])] == [rule], (rule, short)
+    assert ch.check_lines([mfma, mfma]) == []                       # an accumulator chain is interlocked
+    assert ch.check_lines(["v_add_f32_e32 v1, v2, v3", "L1:", "v_mov_b32_dpp v4, v1 row_shr:1"]) == []       # a label ends the window ...
+    assert len(ch.check_lines(["v_add_f32_e32 v1, v2, v3", "L1:", "v_mov_b32_dpp v4, v1 row_shr:1"], strict=True)) == 1   # ... unless strict
 
 
 def test_barrier_checker_sees_the_round5_shape():

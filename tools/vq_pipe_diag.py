@@ -51,30 +51,43 @@ if ONLY == "var":
     VARIANTS_FILTER = lambda env: "DVQ_VQP_VAR" in env
 else:
     VARIANTS_FILTER = lambda env: True
-setenv(DVQ_VQP_DBG=1)
-d, span, st = stamps()
-t0 = st[:, 0].min()
-ph = {"start skew": st[:, 0] - t0, "tables + prologue": st[:, 1] - st[:, 0], "tile loop": st[:, 2] - st[:, 1],
-      "last merge + expand": st[:, 3] - st[:, 2], "refine + store": st[:, 4] - st[:, 3], "whole workgroup": st[:, 4] - st[:, 0]}
-for k, v in ph.items():
-    v = v * 0.01
-    print(f"{k:20s} median {np.median(v):6.2f} us   p10 {np.percentile(v, 10):6.2f}   p90 {np.percentile(v, 90):6.2f}   max {v.max():6.2f}")
-print("kernel span (first start .. last end): %.2f us" % span)
-print("pairs per workgroup: mean %.1f max %d; all-entries rows: %d" % (st[:, 5].mean(), st[:, 5].max(), st[:, 6].sum()))
-print("%-46s %8s | %8s %8s %8s %8s %8s" % ("variant", "call us", "prologue", "loop", "merge", "refine", "span"))
 VARIANTS = ([({"DVQ_VQP_VAR": v}, f"VAR {v}: " + w) for v, w in (
     (0, "as generated"), (1, "deferred scores of waves 8-15"), (5, "1 + static priority, younger first"),
     (16, "priority by progress"), (17, "16 + 1"), (18, "16 + vector work in the first ten gaps"), (19, "16 + 1 + 2"))]
     + [({"DVQ_VQP_ABL": a}, f"ABL {a:3d} {w}") for a, w in (
         (32, "no MFMA"), (96, "no MFMA, no fragment reads"), (4, "no conversion"), (8, "no scoring"), (2, "no merge"), (1, "no row loads"),
         (15, "no loads/merge/conversion/scoring"), (256, "row loads without nt"), (512, "row loads from tile 0 only (L2)"))])
-for env, what in VARIANTS:
-    if not VARIANTS_FILTER(env): continue
+def phase_table():
+    setenv(DVQ_VQP_DBG=1)
+    d, span, st = stamps()
+    t0 = st[:, 0].min()
+    ph = {"start skew": st[:, 0] - t0, "tables + prologue": st[:, 1] - st[:, 0], "tile loop": st[:, 2] - st[:, 1],
+          "last merge + expand": st[:, 3] - st[:, 2], "refine + store": st[:, 4] - st[:, 3], "whole workgroup": st[:, 4] - st[:, 0]}
+    for k, v in ph.items():
+        v = v * 0.01
+        print(f"{k:20s} median {np.median(v):6.2f} us   p10 {np.percentile(v, 10):6.2f}   p90 {np.percentile(v, 90):6.2f}   max {v.max():6.2f}")
+    print("kernel span (first start .. last end): %.2f us" % span)
+    print("pairs per workgroup: mean %.1f max %d; all-entries rows: %d" % (st[:, 5].mean(), st[:, 5].max(), st[:, 6].sum()))
+    print("%-46s %8s | %8s %8s %8s %8s %8s" % ("variant", "call us", "prologue", "loop", "merge", "refine", "span"), flush=True)
+
+
+ONE = os.environ.get("VQP_DIAG_ONE")              # child: one row of the table ("index")
+if ONE is not None:
+    env, what = VARIANTS[int(ONE)]
     setenv(**env)
     t = timeit()
     setenv(DVQ_VQP_DBG=1, **env)
     d, span, _ = stamps()
     print("%-46s %8.2f | %8.2f %8.2f %8.2f %8.2f %8.2f" % (what, t, d[0], d[1], d[2], d[3], span), flush=True)
+    sys.exit(0)
+import subprocess
+phase_table()
+for i, (env, what) in enumerate(VARIANTS):
+    if not VARIANTS_FILTER(env): continue
+    # every row in a process of its own: an ablation computes with garbage (its results are invalid by design) and may fault
+    r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, VQP_DIAG_ONE=str(i)), capture_output=True, text=True, timeout=300)
+    rows = [ln for ln in r.stdout.splitlines() if " | " in ln and not ln.startswith("variant")]
+    print(rows[-1] if r.returncode == 0 and rows else "%-46s FAILED (rc %d): %s" % (what, r.returncode, (r.stderr.strip().splitlines() or ["?"])[-1][:120]), flush=True)
 os.environ["DVQ_VQ_KERNEL"] = "16"
 setenv()
 print("sixteen-wave kernel: %.2f us" % timeit())
