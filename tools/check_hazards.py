@@ -11,7 +11,7 @@ Rules (CDNA3 ISA guide section 4.5 "manually inserted wait states" and the gfx94
   R3  VALU writes a VGPR                   -> DPP instruction reads that VGPR                       2
   R4  VALU writes EXEC                     -> DPP instruction                                       5
   R5  transcendental VALU writes a VGPR    -> non-transcendental VALU reads it                      1
-  R6  VALU writes half a VGPR (SDWA dst_sel, op_sel high half) -> VALU reads that VGPR              1
+  R6  VALU writes the HIGH half of a VGPR (SDWA dst_sel, op_sel dst bit, mixhi) -> VALU reads that VGPR  1
   R7  MFMA writes VGPRs                    -> VALU / LDS / VMEM reads or VALU overwrites them       passes-dependent: 4x4 5, 16x16 7 / 11
                                               (4 / 8 passes), 32x32 11 / 19 (8 / 16 passes)
   R8  VALU writes VCC                      -> v_div_fmas                                            4
@@ -204,8 +204,13 @@ def check_lines(lines, strict=False, name="?"):
             elif h["kind"] == "salu":
                 if ("m0",) in h["dst"] and a < 1 and ("m0",) in src:
                     viol("R9", h, 1)
-        half = kind == "valu" and (("dst_sel:" in line and "dst_sel:DWORD" not in line) or bool(re.search(r"op_sel:\[[01],[01],[01],1\]|op_sel:\[[01],[01],1\]|op_sel:\[[01],1\]", line))
-                                   and not op.startswith("v_pk_"))
+        # a write of half a register: SDWA dst_sel, the dst bit of op_sel on 16-bit VOP3 (the mix instructions select SOURCE halves with
+        # op_sel: their mixlo / mixhi forms are partial writes by definition), not the packed ops (they write both halves)
+        partial_opsel = bool(re.search(r"op_sel:\[[01],[01],[01],1\]|op_sel:\[[01],[01],1\]|op_sel:\[[01],1\]", line)) and not op.startswith(("v_pk_", "v_fma_mix", "v_mad_mix"))
+        # (the hazard is the SHIFT of a 16-bit result into bits 16..31 -- LLVM calls it "Shift16Def" --: mixlo and dst_sel:WORD_0 write in place)
+        half = kind == "valu" and (op.startswith(("v_fma_mixhi", "v_mad_mixhi"))
+                                   or ("dst_sel:" in line and "dst_sel:DWORD" not in line and "dst_sel:WORD_0" not in line and "dst_sel:BYTE_0" not in line)
+                                   or partial_opsel)
         advance(1)
         hist.append({"age": 0, "kind": kind, "op": op, "dst": dst, "half": half, "trans": op.startswith(TRANS), "passes": mfma_passes(op) or 8,
                      "text": line})

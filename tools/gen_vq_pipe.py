@@ -144,7 +144,8 @@ def scores(t, on=True):
     m1, m2, g1, g2 = TS
     o = [I("s_nop 15")]                         # MFMA result -> vector ALU read (8-pass XDL: 12 states; 16 here)
     if not on:
-        return o + [I(f"v_mov_b32_e32 v{m1}, v0"), I(f"v_mov_b32_e32 v{m2}, v1"), I(f"ds_write_b64 v{V_SLOTW}, v[{m1}:{m2}]{off(t * MS_BUF)}", lds="")]
+        # (timing-only ablation: two raw scores, but ORDERED -- the tail's pair count relies on second >= first)
+        return o + [I(f"v_min_f32_e32 v{m1}, v0, v1"), I(f"v_max_f32_e32 v{m2}, v0, v1"), I(f"ds_write_b64 v{V_SLOTW}, v[{m1}:{m2}]{off(t * MS_BUF)}", lds="")]
     for e in range(16):
         o.append(I(f"v_and_or_b32 v{e}, v{e}, s{S_MASK}, {e}"))
     o += [I(f"v_min3_f32 v{m1}, v0, v1, v2"), I(f"v_med3_f32 v{m2}, v0, v1, v2")]
