@@ -78,6 +78,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-grasps", type=int, default=256, help="bounded CPU-baseline sample of the batched port (grasps)")
     ap.add_argument("--vq-iters", type=int, default=20)
+    ap.add_argument("--vq-train", type=int, default=1000, help="calls of the VQ microbench's timed train (after 300 untimed ones: the chip's clock settles over the first few hundred calls)")
     ap.add_argument("--no-prof", action="store_true", help="skip the second (profiled) pass")
     ap.add_argument("--vq-only", action="store_true", help="only the VQ argmin microbench (BASELINE config 2)")
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4],
@@ -237,8 +238,12 @@ def vq_microbench(args, lib, _lib, ops, dev, K):
     torch.cuda.synchronize(dev)
     lib.dvq_prof_enable(0)
     pk = prof_read(lib, _lib); lib.dvq_prof_reset()
-    # (b) one event pair around a back-to-back train of calls on the launch stream: launch gaps included, event cost amortised
-    n_train = max(args.vq_iters, 30)
+    # (b) one event pair around a back-to-back train of calls on the launch stream: launch gaps included, event cost amortised.
+    # The train is long enough for the steady state (tools/vq_clock_probe.py: a 30-call train after an idle gap gives 37-40 us per
+    # call, trains of 1 000 and more 32 us -- the clock settles over the first few hundred calls), after an untimed warm-up train.
+    n_train = max(args.vq_train, 30)
+    for i in range(300):
+        idx = ops.vq_argmin(zs[i % 6], E, packed=packed)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for i in range(n_train):
@@ -258,7 +263,7 @@ def vq_microbench(args, lib, _lib, ops, dev, K):
            "workload": "VectorQuantizer K=512 D=256 argmin-only, M=65536; duration = every kernel of one call "
                        "(one persistent kernel: z streamed once under an fp16-MFMA filter with the codebook in registers, exact fp32 "
                        "refine of the ambiguous rows in the workgroup), codebook packed once",
-           "timing": "one HIP-event pair around a train of back-to-back calls on the launch stream, 6 rotating 64 MiB inputs",
+           "timing": f"one HIP-event pair around a train of {n_train} back-to-back calls on the launch stream after 300 untimed ones, 6 rotating 64 MiB inputs",
            "kernels_us": {k: v["ms"] / v["count"] * 1e3 for k, v in pk.items()}}
     # the exact fp32-MFMA kernel, for comparison
     lib.dvq_prof_reset(); lib.dvq_prof_enable(1)
