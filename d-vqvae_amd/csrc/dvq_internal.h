@@ -37,7 +37,8 @@ __device__ __forceinline__ void dvq_dma_barrier() {
 // chunk's W3 rows, the ring pairs).  A wave then passes the barrier with its stores still in flight, its neighbours read the old
 // contents -- nothing at one workgroup per CU, where the four waves run in step, a wrong tile record every few thousand tiles as soon
 // as workgroups share a CU.  (This is the shape of the round-3 fault of pn_trunk_filter_kernel, whose barrier has the wait in the
-// current build.)  Every barrier that orders LDS traffic in the PointNet kernels goes through here.
+// current build.)  EVERY workgroup barrier of pointnet.hip and pointnet_filter.hip goes through here (round 6: the exact stage's,
+// the centre kernel's and the unfused trunk's too).
 __device__ __forceinline__ void dvq_lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();

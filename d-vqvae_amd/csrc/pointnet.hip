@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_kernel(const float* __restric
             t_split8(v, a3[2 * t4 + q]);
         }
     }
-    __syncthreads();                                       // everybody is done with W2 in the stages
+    dvq_lds_barrier();                                       // everybody is done with W2 in the stages
     // ---- conv3: 16 chunks of 64 output channels, each in two K halves of 64
     t_issue(W3p, 1024L * 128, 128, 0, 0, tl, wave, lane);
     int stage = 0;
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_kernel(const float* __restric
             if (h == 0) red[wave * 1024 + n] = m;
         }
     }
-    __syncthreads();
+    dvq_lds_barrier();
     for (int col = tid; col < 1024; col += 256)
         partial[(long)blockIdx.x * 1024 + col] = fmaxf(fmaxf(red[col], red[1024 + col]), fmaxf(red[2048 + col], red[3072 + col]));
 }

@@ -1313,7 +1313,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
         n_multi += cands != 1;
         n_cand += cands;
     }
-    __syncthreads();
+    dvq_lds_barrier();
     if (stamps) tp1 = __builtin_amdgcn_s_memtime();
     // ---- phase A2: the pairs in POINT order (counting sort in the LDS).  A cloud's 1 024 channels take their maxima at ~100-200
     // distinct points, so ~1 500 candidate pairs name each conv2 row ~10 times: evaluated channel by channel every pair fetched
@@ -1323,7 +1323,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
     for (int n = tid; n < 1024; n += 256)
         for (int k = 0; k < cand_n[n]; ++k) atomicAdd(&pcnt[cand[n][k] & 1023], 1);     // N > 1024: points 1024 apart share a slot range
     for (int i = tid; i < npairs; i += 256) atomicAdd(&pcnt[(pair_list[i] >> 10) & 1023], 1);
-    __syncthreads();
+    dvq_lds_barrier();
     int total;
     {
         const int c0 = pcnt[4 * tid], c1 = pcnt[4 * tid + 1], c2 = pcnt[4 * tid + 2], c3 = pcnt[4 * tid + 3];
@@ -1334,7 +1334,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
             if ((tid & 63) >= o) incl += v;
         }
         if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
-        __syncthreads();
+        dvq_lds_barrier();
         int base = 0;
         for (int w = 0; w < (tid >> 6); ++w) base += wave_tot[w];
         total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
@@ -1344,7 +1344,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
         pcnt[4 * tid + 2] = excl + c0 + c1;
         pcnt[4 * tid + 3] = excl + c0 + c1 + c2;
     }
-    __syncthreads();
+    dvq_lds_barrier();
     const bool by_point = total <= SORT_CAP && !(abl & 64);
     if (by_point) {
         for (int n = tid; n < 1024; n += 256)
@@ -1356,7 +1356,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
             const int code = pair_list[i];
             sorted[atomicAdd(&pcnt[(code >> 10) & 1023], 1)] = (unsigned)code;
         }
-        __syncthreads();
+        dvq_lds_barrier();
         if (stamps) tp2 = __builtin_amdgcn_s_memtime();
         // ---- phase B, point order: every 16-lane group takes a contiguous share of the list, four pairs in flight
         const int per = (total + 15) >> 4, i0 = g * per, i1 = min(total, i0 + per);
@@ -1459,7 +1459,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
         }
         if (j == 0) atomicMax(&best_k[n], f2key(best));
     }
-    __syncthreads();
+    dvq_lds_barrier();
     // ---- phase C: everything (NaN-propagating maximum, torch.max semantics): the channels on all_list over ALL points, four channels
     // per sweep of the rows (a row's slice is loaded once for the four)
     auto eval_all_list = [&](int count) {
@@ -1487,13 +1487,13 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
 #pragma unroll
                 for (int u = 0; u < 4; ++u) fb_part[u][g] = best[u];
             }
-            __syncthreads();
+            dvq_lds_barrier();
             if (tid < 4 && i + tid < count) {
                 float v = fb_part[tid][0];
                 for (int k = 1; k < 16; ++k) v = max_nan(v, fb_part[tid][k]);
                 best_k[all_list[i + tid]] = (v != v) ? 0xffffffffu : f2key(v);       // NaN: the largest key, decoded below
             }
-            __syncthreads();
+            dvq_lds_barrier();
         }
     };
     eval_all_list(all_count);
@@ -1501,9 +1501,9 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
     // for every point of tile t, so  max_t (top_t - E_t) <= max - w.c <= max_t (top_t + E_t).  A maximum outside that interval means a
     // record did not describe its tile (a wrong score or id; a missing input that was the tile's best shows up in the trunk kernel's
     // own tag check instead): such a channel is evaluated over all points, and counted.
-    __syncthreads();                                       // best_k / wcs complete; all_list free again
+    dvq_lds_barrier();                                       // best_k / wcs complete; all_list free again
     if (tid == 0) all_count = 0;
-    __syncthreads();
+    dvq_lds_barrier();
     unsigned n_bad = 0;
 #pragma unroll
     for (int ci = 0; ci < 4; ++ci) {
@@ -1517,7 +1517,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
             ++n_bad;
         }
     }
-    __syncthreads();
+    dvq_lds_barrier();
     eval_all_list(all_count);
     if (n_suspect) atomicAdd(&g_pn_faults[0], (unsigned long long)n_suspect);
     if (n_bad) atomicAdd(&g_pn_faults[1], (unsigned long long)n_bad);
@@ -1575,7 +1575,7 @@ __global__ __launch_bounds__(256) void pn_center_kernel(const float* __restrict_
             a = fmaf(x3, w[3], a);
             h1c[q][k] = fmaxf(a + b1[k], 0.f);
         }
-        __syncthreads();                                   // h1c (and, the first time, w2t) complete
+        dvq_lds_barrier();                                   // h1c (and, the first time, w2t) complete
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int ch = k + 64 * half;
@@ -1583,7 +1583,7 @@ __global__ __launch_bounds__(256) void pn_center_kernel(const float* __restrict_
             for (int i = 0; i < 64; ++i) a = fmaf(w2t[i][ch], h1c[q][i], a);
             h2c[q][ch] = fmaxf(a + b2[ch], 0.f);
         }
-        __syncthreads();
+        dvq_lds_barrier();
         if (tid < 128) cbuf[b * 128 + tid] = 0.25f * ((h2c[0][tid] + h2c[1][tid]) + (h2c[2][tid] + h2c[3][tid]));
         // the next sample's h1c writes come after this barrier pair: h2c reads above are done before its second barrier
     }

@@ -4,6 +4,8 @@ import os
 import sys
 import re
 
+import pytest
+
 from dvqvae_amd import _lib
 
 
@@ -56,7 +58,7 @@ def test_kernels_are_built_without_the_slp_vectorizer():
     assert "$(CXXFLAGS) -DDVQ_DIAG" in mk, "the diagnostics build must use the same CXXFLAGS"
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
-        return
+        pytest.skip("hipcc not found: the listing checks need the compiler")
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-S",
                         "--cuda-device-only", "-o", "-", "pointnet_filter.hip"], cwd=csrc, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -122,7 +124,7 @@ def test_every_barrier_waits_for_the_waves_own_lds_operations():
     csrc = os.path.join(root, "d-vqvae_amd", "csrc")
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
-        return
+        pytest.skip("hipcc not found: the listing checks need the compiler")
     sys.path.insert(0, os.path.join(root, "tools"))
     import check_barriers, check_hazards
     if not os.path.exists(os.path.join(csrc, "vq_pipe_loop.h")):         # generated, not tracked (the Makefile has the same rule)
