@@ -126,7 +126,7 @@ def test_every_barrier_waits_for_the_waves_own_lds_operations():
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not found: the listing checks need the compiler")
     sys.path.insert(0, os.path.join(root, "tools"))
-    import check_barriers, check_hazards
+    import check_barriers, check_hazards, check_waitcnt
     if not os.path.exists(os.path.join(csrc, "vq_pipe_loop.h")):         # generated, not tracked (the Makefile has the same rule)
         subprocess.run([sys.executable, os.path.join(root, "tools", "gen_vq_pipe.py")], check=True, capture_output=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-S", "--cuda-device-only"]
@@ -138,7 +138,7 @@ def test_every_barrier_waits_for_the_waves_own_lds_operations():
             return out
         with concurrent.futures.ThreadPoolExecutor(max_workers=6) as ex:
             listings = list(ex.map(build, sorted(glob.glob(os.path.join(csrc, "*.hip")))))
-        bad, barriers, hazards, mfmas = [], 0, [], 0
+        bad, barriers, hazards, mfmas, unwaited = [], 0, [], 0, []
         for path in listings:
             text = open(path).read()
             barriers += text.count("s_barrier")
@@ -149,9 +149,35 @@ def test_every_barrier_waits_for_the_waves_own_lds_operations():
                 # round 6: the same listings through tools/check_hazards.py -- producer / consumer pairs that need wait states the
                 # hardware does not insert (the compiler does not look inside the inline-asm loops: vq_pipe_loop.h is 6 000 lines of it)
                 hazards += [msg for _, _, msg in check_hazards.check_lines(body.splitlines(), strict=True, name=os.path.basename(path) + ":" + name[:60])]
+                # ... and tools/check_waitcnt.py: no register is read or overwritten while a load into it may be in flight on some path
+                # (s_waitcnt lgkmcnt / vmcnt re-derived from the listing: the compiler's own counts and the hand-counted ones of the asm loops)
+                unwaited += check_waitcnt.check(body, os.path.basename(path) + ":" + name[:60])
     assert barriers > 100, f"only {barriers} s_barrier instructions found"
     assert not bad, f"s_barrier reachable with an LDS operation of the wave in flight: {bad}"
     assert mfmas > 1000 and not hazards, f"missing wait states: {hazards[:5]}"
+    assert not unwaited, f"a register is used with a load possibly in flight: {unwaited[:5]}"
+
+
+def test_waitcnt_checker_rules():
+    """tools/check_waitcnt.py on small listings: in-order LDS / vector-memory counters, scalar reads out of order, joins, branches
+    in the middle of a block, a load overwriting an older load's destination."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import check_waitcnt as cw
+    run = lambda lines: cw.check("\n".join(lines), "t")
+    use = "v_add_f32_e32 v3, v1, v1"
+    assert len(run(["ds_read_b32 v1, v2", use])) == 1
+    assert run(["ds_read_b32 v1, v2", "s_waitcnt lgkmcnt(0)", use]) == []
+    assert run(["ds_read_b32 v1, v2", "ds_read_b32 v4, v2", "s_waitcnt lgkmcnt(1)", use]) == []                 # in order: the older one is done
+    assert len(run(["ds_read_b32 v1, v2", "ds_read_b32 v4, v2", "s_waitcnt lgkmcnt(1)", "v_add_f32_e32 v3, v4, v4"])) == 1
+    assert len(run(["ds_read_b32 v1, v2", "s_load_dword s4, s[0:1], 0x0", "ds_read_b32 v4, v2", "s_waitcnt lgkmcnt(1)", use])) == 1   # scalar reads return out of order
+    assert run(["global_load_dword v1, v2, s[0:1]", "global_store_dword v2, v5, s[0:1]", "s_waitcnt vmcnt(1)", use]) == []
+    assert len(run(["global_load_dword v1, v2, s[0:1]", "s_waitcnt lgkmcnt(0)", use])) == 1                      # the wrong counter
+    assert len(run(["global_load_dword v1, v2, s[0:1]", "s_cbranch_scc1 .LBB0_2", ".LBB0_1:", "s_waitcnt vmcnt(0)", ".LBB0_2:", use])) == 1   # one path skips the wait
+    assert run(["s_cbranch_scc1 .LBB0_2", "global_load_dword v1, v2, s[0:1]", "s_waitcnt vmcnt(0)", ".LBB0_2:", use]) == []      # the branch target sees the state AT the branch
+    assert run(["global_load_dword v1, v2, s[0:1]", "global_load_dword v1, v6, s[0:1]", "s_waitcnt vmcnt(0)", use]) == []         # load over an older load's destination
+    assert len(run(["global_load_dword v1, v2, s[0:1]", "v_mov_b32_e32 v1, 0"])) == 1                             # overwrite under a load in flight
+    assert len(run([".LBB0_1:", use, "ds_read_b32 v1, v2", "s_cbranch_scc1 .LBB0_1"])) == 1                       # around a loop's back edge
 
 
 def test_hazard_checker_rules():
