@@ -20,7 +20,7 @@
 //      group are all evaluated.
 //
 // Matrix-core cost per (32 points x 32 channels x K=128): 8 x v_mfma_f32_32x32x16_f16 instead of 48 bf16 MFMAs; the
-// kernel is bound by vector-instruction issue: 3 instructions per score (id, med3, max) since round 5 -- a top-two per 16-point
+// kernel is bound by vector-instruction issue: 2.5 instructions per score (id; max3 / med3 per group of three) since round 6 -- a top-two per 16-point
 // group flags about as many points for re-evaluation as the top-three per 32 points of round 4 did.
 #include "dvq_internal.h"
 #include <vector>
@@ -544,19 +544,30 @@ __global__ __launch_bounds__(256, 2) void pn_trunk_filter_kernel(const float* __
     /* anyway -- finish() used to set it on the block's winner with an instruction of its own                                        */
 #define F_CHAIN_BLOCK(ACC, PB, M1, M2, CT)                                                                     \
     do {                                                                                                       \
-        M1 = NEG_BIG; M2 = NEG_BIG;                                                                            \
         if (abl & 128) { M1 = ACC[0]; M2 = ACC[15]; } else   /* timing only: no chain */                       \
-        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                       \
-            const float x = __uint_as_float((__float_as_uint(ACC[e]) & id_mask) | (CT)[16 * (PB) + e]);        \
-            M2 = __builtin_amdgcn_fmed3f(M1, M2, x);                                                           \
-            M1 = max_nc(M1, x);                                                                                \
+        {                                                                                                      \
+            /* round 6: groups of three -- v_max3 / v_med3 give a group's two largest, merged into the running pair by          */ \
+            /* second = med3(M1, g1, max(M2, g2)): 40 instead of 48 instructions per 16 scores, the same pair                    */ \
+            float x_[16];                                                                                      \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e)                                                     \
+                x_[e] = __uint_as_float((__float_as_uint(ACC[e]) & id_mask) | (CT)[16 * (PB) + e]);           \
+            M1 = fmaxf(fmaxf(x_[0], x_[1]), x_[2]);                                                            \
+            M2 = __builtin_amdgcn_fmed3f(x_[0], x_[1], x_[2]);                                                 \
+            _Pragma("unroll") for (int g = 3; g < 15; g += 3) {                                                \
+                const float g1_ = fmaxf(fmaxf(x_[g], x_[g + 1]), x_[g + 2]);                                   \
+                const float g2_ = max_nc(M2, __builtin_amdgcn_fmed3f(x_[g], x_[g + 1], x_[g + 2]));            \
+                M2 = __builtin_amdgcn_fmed3f(M1, g1_, g2_);                                                    \
+                M1 = max_nc(M1, g1_);                                                                          \
+            }                                                                                                  \
+            M2 = __builtin_amdgcn_fmed3f(M1, M2, x_[15]);                                                      \
+            M1 = max_nc(M1, x_[15]);                                                                           \
         }                                                                                                      \
     } while (0)
 #define F_INTERLEAVE()                                                                                         \
     do {                                                                                                       \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                        \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                 \
-            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                                                 \
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                                                 \
         }                                                                                                      \
     } while (0)
     // every lane hands its own sorted pair of a block over (16 points of one channel); the publishing wave merges the sixteen groups
