@@ -79,11 +79,14 @@ constexpr int DBG_WG_BYTES = 64 + NWV * 32 * 4;            // per-workgroup debu
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 // ------------------------------------------------------------------------------------------------ pack
-__global__ void vq_pack_norm_kernel(const float* __restrict__ E, float* __restrict__ ee, PackHeader* hdr) {
+// A codebook of Kr < K entries (Kr a multiple of 32; round 6: the model's K = 128 codebooks) is PADDED to the kernels' K = 512: the
+// padding entries have a zero image and 3e38 as |e|^2 (their filter scores are 3e38, never within eps of a real one; the canonical
+// paths stop at Kr); hdr->K = Kr.
+__global__ void vq_pack_norm_kernel(const float* __restrict__ E, int Kr, float* __restrict__ ee, PackHeader* hdr) {
     __shared__ float red[K];
     __shared__ float redm[K];
     const int k = threadIdx.x;                                   // blockDim = K
-    const float* p = E + k * D;
+    const float* p = E + (k < Kr ? k : 0) * D;
     float acc = 0.f, mx = 0.f;
     bool finite = true;
     for (int j = 0; j < D; ++j) {
@@ -91,9 +94,9 @@ __global__ void vq_pack_norm_kernel(const float* __restrict__ E, float* __restri
         finite = finite && (fabsf(p[j]) <= 3.0e38f);
         mx = fmaxf(mx, fabsf(p[j]));
     }
-    ee[k] = acc;
-    red[k] = (finite && acc <= 3.0e38f) ? acc : INFINITY;
-    redm[k] = finite ? mx : INFINITY;
+    ee[k] = k < Kr ? acc : 3.0e38f;
+    red[k] = k >= Kr ? 0.f : (finite && acc <= 3.0e38f) ? acc : INFINITY;
+    redm[k] = k >= Kr ? 0.f : finite ? mx : INFINITY;
     __syncthreads();
     for (int o = K / 2; o > 0; o >>= 1) {
         if (k < o) {
@@ -109,26 +112,26 @@ __global__ void vq_pack_norm_kernel(const float* __restrict__ E, float* __restri
         const bool ok = redm[0] > 0.f && e >= -EXP_LIMIT && e <= EXP_LIMIT && red[0] <= 3.0e38f;
         hdr->sexp = ok ? 13 - e : 0;
         hdr->valid = ok ? 1 : 0;
-        hdr->K = K;
+        hdr->K = Kr;
         hdr->D = D;
         hdr->layout = 3;
     }
 }
 
 // image: fp16 of -2 sE e in fragment order
-__global__ void vq_pack_img_kernel(const float* __restrict__ E, const PackHeader* __restrict__ hdr, _Float16* __restrict__ img) {
+__global__ void vq_pack_img_kernel(const float* __restrict__ E, int Kr, const PackHeader* __restrict__ hdr, _Float16* __restrict__ img) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= K * D) return;
-    img[img_pos(gid / D, gid % D)] = (_Float16)(-2.0f * pow2f(hdr->sexp) * E[gid]);   // (subnormals kept; the error kernel measures what is stored)
+    img[img_pos(gid / D, gid % D)] = gid < Kr * D ? (_Float16)(-2.0f * pow2f(hdr->sexp) * E[gid]) : (_Float16)0.0f;   // (subnormals kept; the error kernel measures what is stored)
 }
 
 // measured rounding error of the image, per entry, as a 2-norm in codebook units; its maximum goes into the header
-__global__ void vq_pack_err_kernel(const float* __restrict__ E, const _Float16* __restrict__ img, PackHeader* hdr) {
+__global__ void vq_pack_err_kernel(const float* __restrict__ E, int Kr, const _Float16* __restrict__ img, PackHeader* hdr) {
     __shared__ float red[K];
     const int k = threadIdx.x;                                   // blockDim = K
     const float m2s = -2.0f * pow2f(hdr->sexp);
     float acc = 0.f;
-    for (int j = 0; j < D; ++j) {
+    for (int j = 0; j < D && k < Kr; ++j) {
         const float sv = m2s * E[k * D + j];                     // exact (power-of-two scale, range checked by `valid`)
         const float d = sv - (float)img[img_pos(k, j)];          // exact: fp32 values at most 11 significant bits apart (or sv itself)
         acc = fmaf(d, d, acc);
@@ -850,22 +853,23 @@ int device_cus() {
 
 }  // namespace
 
-extern "C" int dvq_vq_fast_supported(int Kq, int Dq) { return Kq == K && Dq == D; }
+// K = 512 is the kernels' shape; fewer entries (a multiple of 32) run the same kernels on a padded image (vq_pack_norm_kernel)
+extern "C" int dvq_vq_fast_supported(int Kq, int Dq) { return Dq == D && Kq >= 32 && Kq <= K && Kq % 32 == 0; }
 
 extern "C" size_t dvq_vq_pack_bytes(int Kq, int Dq) { return dvq_vq_fast_supported(Kq, Dq) ? PK_BYTES : 0; }
 
 extern "C" int dvq_vq_pack(const float* E, int Kq, int Dq, void* packed, size_t packed_bytes, dvq_stream_t stream) {
-    DVQ_REQUIRE(dvq_vq_fast_supported(Kq, Dq), "vq_pack: the fast path supports K=%d, D=%d only (got %d, %d)", K, D, Kq, Dq);
+    DVQ_REQUIRE(dvq_vq_fast_supported(Kq, Dq), "vq_pack: the fast path supports K<=%d (a multiple of 32), D=%d only (got %d, %d)", K, D, Kq, Dq);
     DVQ_REQUIRE(E && packed && dvq_aligned16(E) && dvq_aligned16(packed), "vq_pack: null/unaligned pointer");
     DVQ_REQUIRE(packed_bytes >= PK_BYTES, "vq_pack: buffer %zu < %zu bytes", packed_bytes, PK_BYTES);
     hipStream_t st = (hipStream_t)stream;
     char* pk = (char*)packed;
-    DVQ_LAUNCH(vq_pack_norm_kernel, dim3(1), dim3(K), 0, st, E, (float*)(pk + PK_OFF_EE), (PackHeader*)pk);
+    DVQ_LAUNCH(vq_pack_norm_kernel, dim3(1), dim3(K), 0, st, E, Kq, (float*)(pk + PK_OFF_EE), (PackHeader*)pk);
     DVQ_CHECK_LAUNCH("vq_pack_norm");
-    DVQ_LAUNCH(vq_pack_img_kernel, dim3((K * D + 255) / 256), dim3(256), 0, st, E, (const PackHeader*)pk,
+    DVQ_LAUNCH(vq_pack_img_kernel, dim3((K * D + 255) / 256), dim3(256), 0, st, E, Kq, (const PackHeader*)pk,
                        (_Float16*)(pk + PK_OFF_IMG));
     DVQ_CHECK_LAUNCH("vq_pack_img");
-    DVQ_LAUNCH(vq_pack_err_kernel, dim3(1), dim3(K), 0, st, E, (const _Float16*)(pk + PK_OFF_IMG), (PackHeader*)pk);
+    DVQ_LAUNCH(vq_pack_err_kernel, dim3(1), dim3(K), 0, st, E, Kq, (const _Float16*)(pk + PK_OFF_IMG), (PackHeader*)pk);
     DVQ_CHECK_LAUNCH("vq_pack_err");
     return DVQ_OK;
 }
@@ -879,7 +883,7 @@ extern "C" size_t dvq_vq_fast_workspace_bytes(int64_t M, int Kq, int Dq) {
 extern "C" int dvq_vq_argmin_fast(const float* z, const float* E, const void* packed, int64_t M, int Kq, int Dq,
                                   int64_t* idx, unsigned long long* slow_rows, void* workspace, size_t workspace_bytes,
                                   dvq_stream_t stream) {
-    DVQ_REQUIRE(dvq_vq_fast_supported(Kq, Dq), "vq_argmin_fast: supports K=%d, D=%d only (got %d, %d)", K, D, Kq, Dq);
+    DVQ_REQUIRE(dvq_vq_fast_supported(Kq, Dq), "vq_argmin_fast: supports K<=%d (a multiple of 32), D=%d only (got %d, %d)", K, D, Kq, Dq);
     DVQ_REQUIRE(M >= 0 && M < (1L << 31), "vq_argmin_fast: bad M");
     if (M == 0) return DVQ_OK;
     DVQ_REQUIRE(z && E && packed && idx && workspace, "vq_argmin_fast: null pointer");
@@ -918,6 +922,7 @@ extern "C" int dvq_vq_argmin_fast(const float* z, const float* E, const void* pa
     // vq_stream16.hip (34.1-35.0 us against 35.6-35.9 us for this file's eight-wave kernel, DVQ_VQ_KERNEL=8, in bench.py's
     // microbenchmark; 36.4 us both before); DVQ_VQ_KERNEL=32: vq_rows.hip (rows resident, codebook streamed: 42 us).  Same indices.
     int which = dvq_knobs().vq_kernel;
+    if (Kq != K) which = 16;                                        // a padded image (fewer than 512 entries): the default kernel knows where the real entries end
     unsigned long long* dbg16 = nullptr;
 #ifdef DVQ_DIAG
     if (getenv("DVQ_VQ_DBG") || getenv("DVQ_VQ_ABL")) which = 8;                 // stamps / ablations of the eight-wave kernel
@@ -931,7 +936,7 @@ extern "C" int dvq_vq_argmin_fast(const float* z, const float* E, const void* pa
         return dvq_launch_vq_pipe(z, E, packed, (long)M, idx, slow_rows, dbg16, st);
     }
     if (which == 16) {
-        DVQ_PROF("vq_argmin_fast", 2.0 * M * K * D, (double)M * D * 4 + (double)K * D * 4 + (double)M * 8, st);
+        DVQ_PROF("vq_argmin_fast", 2.0 * M * Kq * D, (double)M * D * 4 + (double)Kq * D * 4 + (double)M * 8, st);
         return dvq_launch_vq_stream16(z, E, packed, (long)M, idx, slow_rows, dbg16, st);
     }
     if (which == 32) {

@@ -421,8 +421,9 @@ __global__ __launch_bounds__(NT) void vq_stream16_kernel(const float* __restrict
 #pragma unroll
         for (int s = 0; s < 16; ++s) af[s] = img[s * 64];
     }
-    if (tid < K) reinterpret_cast<float*>(lds + L_EES)[tid] = ee_g[tid] * c.sEf;      // accumulator start values (read back per tile:
-                                                                                       // 16 resident registers would spill fragments)
+    const int Kr = hdr->K;                                 // real entries (a multiple of 32); the rest of the image is padding (vq_pack_norm_kernel)
+    if (tid < K) reinterpret_cast<float*>(lds + L_EES)[tid] = tid < Kr ? ee_g[tid] * c.sEf : 3.0e38f;   // accumulator start values (read back per
+                                                                                       // tile: 16 resident registers would spill fragments)
     for (int u = tid; u < MAX_TILES * TILE; u += NT) reinterpret_cast<unsigned long long*>(lds + L_RES)[u] = ~0ull;
     for (int u = tid; u < PAIR_CAP; u += NT) reinterpret_cast<unsigned*>(lds + L_PAIR)[u] = ~0u;
     if (tid < 32) reinterpret_cast<unsigned*>(lds + L_CNT)[tid] = 0u;
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(NT) void vq_stream16_kernel(const float* __restrict
     // what is left (NaN/Inf, fp16 overflow, invalid codebook image, overflowing list): all K entries canonically
     for (int o = 0; o < n_slow; ++o) {
         const int rowslot = s_slow[o];
-        if (tid < K) {
+        if (tid < Kr) {
             float zz2, dot2;
             chain_pair(z + grow_of(rowslot) * D, E + (long)tid * D, zz2, dot2);
             const float tsum = zz2 + ee_g[tid];

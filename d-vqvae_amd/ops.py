@@ -244,7 +244,7 @@ def vq_pack(E: Tensor) -> Tensor:
 def vq_argmin(z: Tensor, E: Tensor, return_dist: bool = False, fast: Optional[bool] = None,
               packed: Optional[Tensor] = None, slow_rows: Optional[Tensor] = None):
     """idx[m] = argmin_k (|z_m|^2 + |E_k|^2) - 2 z_m.E_k in the canonical fp32 order -> int64 [M].
-    K=512/D=256 on dense rows takes the fast kernel (fp16-MFMA filter + exact refine in one launch; same indices, bit for bit); everything else
+    K<=512 (a multiple of 32)/D=256 on dense rows takes the fast kernel (fp16-MFMA filter + exact refine in one launch; same indices, bit for bit); everything else
     (and ``return_dist``) the exact fp32-MFMA kernel.  ``fast`` forces the choice; ``packed`` = vq_pack(E) skips the
     per-call codebook packing (three tiny kernels); ``slow_rows`` (int64 [1] on the device, accumulated, never reset)
     counts the rows the fast kernel could not decide from their candidate lists (see dvq.h)."""

@@ -119,8 +119,9 @@ int dvq_vq_argmin(const float* z, int64_t ldz, const float* E, int64_t M, int K,
                   int64_t* idx, float* dmin, void* workspace, size_t workspace_bytes,
                   dvq_stream_t stream);
 
-/* Fast path for the headline shape (K = 512, D = 256, dense z): returns the SAME indices as dvq_vq_argmin,
- * bit for bit.  One persistent kernel (one workgroup per CU, the fp16 codebook image held in registers): z is read from
+/* Fast path for the headline shape (K = 512, D = 256, dense z) and, since round 6, for codebooks of K = 32, 64 ... 480 entries at
+ * D = 256 (the model's six K = 128 codebooks: the image is padded to 512 entries that never win): returns the SAME indices as
+ * dvq_vq_argmin, bit for bit.  One persistent kernel (one workgroup per CU, the fp16 codebook image held in registers): z is read from
  * HBM once and streamed under an fp16-MFMA filter with a proven error bound that keeps every row's candidate entries (the
  * exact fp32 argmin is always among them); rows with one candidate are decided, the rest are re-evaluated in the
  * canonical fp32 order inside the same workgroup (DESIGN.md "vq_argmin").  `packed` is the codebook image built once

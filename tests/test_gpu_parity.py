@@ -873,6 +873,40 @@ def test_pointnet_pipeline_on_two_streams_and_one():
     assert ops.pointnet_fault_counters() == (0, 0)
 
 
+@pytest.mark.parametrize("K", [32, 128, 256, 480])
+def test_vq_fast_padded_codebooks(K):
+    """Round 6: codebooks of fewer than 512 entries at D = 256 (the model's six K = 128 codebooks) run the fast kernel on an image padded
+    to 512 entries -- zero rows whose |e|^2 is 3e38: they never win, never become candidates, and the canonical all-entries scan stops
+    at K.  Fast == exact == oracle/vq_canonical.c on random rows, rows on / next to entries, exact ties (the lowest index wins), NaN /
+    Inf / zero / huge rows (the all-entries path), a duplicated LAST entry, scaled data.  (DVQVAE.forward's six codebooks take this path
+    in the G8 golden test.)"""
+    D = 256
+    assert ops.vq_fast_supported(K, D) and not ops.vq_fast_supported(K + 1, D) and not ops.vq_fast_supported(544, D) and not ops.vq_fast_supported(K, 128)
+    E = synth.synthetic_normal((K, D), 21, f"vqpad/E/{K}")
+    E[K - 1] = E[3]                                            # a tie between a low entry and the last real one: 3 wins
+    if K > 40:
+        E[40] = E[39] + 1e-6 * synth.synthetic_normal((D,), 21, "vqpad/eps")
+    z = synth.synthetic_normal((3000, D), 21, f"vqpad/z/{K}")
+    z[0] = E[3]; z[1] = E[K - 1]; z[2] = E[K - 2]; z[3] = 0.0
+    z[4, 5] = float("nan"); z[5, 7] = float("inf"); z[6] = 3e38; z[7] = 1e18 * z[7]; z[8] = 1e-20 * z[8]; z[9] = -E[0]
+    z[10:10 + min(K, 200)] = E[:min(K, 200)] + 1e-3 * z[10:10 + min(K, 200)]
+    idx = _fast_vs_exact(gpu(z), gpu(E), f"padded K={K}")
+    ci, _ = vq_canonical.argmin(z.numpy(), E.numpy())
+    assert np.array_equal(idx.cpu().numpy(), ci)
+    assert idx[0] == 3 and idx[1] == 3 and idx[2] == K - 2 and int(idx.max()) < K
+    for scale_z, scale_e in [(100.0, 0.01), (1e-3, 1e3), (1.0, 1.0 / K)]:
+        Es = synth.synthetic_uniform((K, D), 22, f"vqpad/Es/{K}/{scale_e}", -scale_e, scale_e)
+        zs = synth.synthetic_normal((2048, D), 22, f"vqpad/zs/{scale_z}", scale_z)
+        _fast_vs_exact(gpu(zs), gpu(Es), f"padded K={K}, scales {scale_z},{scale_e}")
+    for M in (1, 33, 70001):
+        zz = torch.randn(M, D, device=DEV)
+        _fast_vs_exact(zz, gpu(E), f"padded K={K}, M={M}")
+    # the other kernels (DVQ_VQ_KERNEL=17 / 8 / 32) must not be handed a padded image: the selection falls back to the default one
+    for kern in ("17", "8", "32"):
+        got = _with_env("DVQ_VQ_KERNEL", kern, lambda: ops.vq_argmin(gpu(z), gpu(E), fast=True))
+        assert torch.equal(got, idx), f"DVQ_VQ_KERNEL={kern} with a padded codebook"
+
+
 def test_vq_fast_scales_and_tie_prone_codebook():
     for scale_z, scale_e in [(1.0, 1.0 / 512), (100.0, 0.01), (1e-3, 1e3), (30.0, 30.0)]:
         E = synth.synthetic_uniform((512, 256), 10, f"vqs/E/{scale_e}", -scale_e, scale_e)
