@@ -131,3 +131,41 @@ def test_oracle_assemble61_layout():
     out = O.assemble61(recon, pos)[0]
     assert out[:10].tolist() == list(range(10)) and out[10:13].tolist() == [100, 101, 102]
     assert out[13:58].tolist() == list(range(10, 55)) and out[58:].tolist() == [103, 104, 105]
+
+
+def test_bench_quotes_pmc_traffic_only_from_this_trees_kernels(tmp_path, monkeypatch):
+    """bench.py's `roofline.traffic` is looked up in the newest committed profiles/*_pmc_hbm_traffic.json: only while that file carries
+    the digest of THIS tree's kernel sources (tools/collect_profiles.sh stores `bench.py --sources-digest` beside the counters) and,
+    with a git history at hand, a commit that is HEAD or an ancestor of it; otherwise traffic is None and the source says why."""
+    import importlib.util
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    digest = bench.kernel_sources_sha256()
+    assert len(digest) == 64 and digest == bench.kernel_sources_sha256()
+    head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    ok, why = bench.pmc_file_is_current({"kernel_sources_sha256": digest, "commit": head or None})
+    assert ok and why == ""
+    ok, why = bench.pmc_file_is_current({"kernel_sources_sha256": "0" * 64, "commit": head or None})
+    assert not ok and "digest differs" in why
+    ok, why = bench.pmc_file_is_current({"commit": head or None})
+    assert not ok and "no digest" in why
+    if head:
+        ok, why = bench.pmc_file_is_current({"kernel_sources_sha256": digest, "commit": "0123456789abcdef0123456789abcdef01234567"})
+        assert not ok and "ancestor" in why
+    # through pmc_traffic(): a profiles directory whose newest file is stale -> (None, "refused: ...")
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    rows = [{"kernel": "void (anonymous namespace)::vq_stream16_kernel<0>(float const*", "launches": 10, "hbm_bytes_corrected": 7.0e7, "scope": "vq microbench"}]
+    (prof / "r99_v1_pmc_hbm_traffic.json").write_text(json.dumps({"collected": "tag r99_v1", "commit": head or None, "kernel_sources_sha256": "f" * 64,
+                                                                    "per_launch_bytes": rows}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_sources_sha256", lambda: digest)
+    val, src = bench.pmc_traffic("vq_fast", 65536)
+    assert val is None and src.startswith("refused:") and "stale" in src
+    (prof / "r99_v2_pmc_hbm_traffic.json").write_text(json.dumps({"collected": "tag r99_v2", "commit": None, "kernel_sources_sha256": digest,
+                                                                    "per_launch_bytes": rows}))
+    val, src = bench.pmc_traffic("vq_fast", 65536)
+    assert val == 7.0e7 and "r99_v2" in src
