@@ -59,12 +59,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmParams p) {
     const int tid = threadIdx.x;
     const int tiles_n = (p.N + BN - 1) / BN;
     const long tiles_m = (p.M + BM - 1) / BM;
-    // XCD-aware map: panel (m-tile) index = 8 * (j / tiles_n) + (b % 8)
+    // XCD-aware map: panel (m-tile) index = 8 * (j / tiles_n) + (b % 8).  With fewer than eight row panels (round 6: the VQ argmin's
+    // K / 128 = 1 .. 4 codebook panels against thousands of column tiles of z rows) that map leaves 8 - tiles_m of the eight XCDs
+    // without work -- the exact argmin took 410 us per 65 536 rows whether K was 128 or 512 --: there the COLUMN tiles are dealt over
+    // the XCDs instead and the few row panels of one column tile follow each other on one XCD (its z rows are fetched into one L2).
     const long b = blockIdx.x;
     const long j = b >> 3;
-    const long mt = (j / tiles_n) * 8 + (b & 7);
-    const int nt = (int)(j % tiles_n);
-    if (mt >= tiles_m) return;
+    long mt;
+    int nt;
+    if (tiles_m < 8) {
+        mt = j % tiles_m;
+        nt = (int)((j / tiles_m) * 8 + (b & 7));
+        if (nt >= tiles_n) return;
+    } else {
+        mt = (j / tiles_n) * 8 + (b & 7);
+        nt = (int)(j % tiles_n);
+        if (mt >= tiles_m) return;
+    }
     const long m0 = mt * BM;
     const int n0 = nt * BN;
 
@@ -142,7 +153,7 @@ int launch(const GemmParams& p, hipStream_t stream) {
     }
     const long tiles_m = (p.M + BM - 1) / BM;
     const long tiles_n = (p.N + BN - 1) / BN;
-    const long grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
+    const long grid = tiles_m < 8 ? tiles_m * ((tiles_n + 7) / 8) * 8 : ((tiles_m + 7) / 8) * 8 * tiles_n;   // (the kernel's two block -> tile maps)
     static const char* const names[] = {"gemm_bias", "gemm_resid", "gemm_gate", "gemm_colmax", "gemm_argmin"};
     double ksum = 0;
     for (int s = 0; s < p.nsrc; ++s) ksum += p.src[s].K;
