@@ -1552,7 +1552,7 @@ __global__ __launch_bounds__(256, 4) void pn_exact_kernel(const f32x4* __restric
 // Centre of a sample: mean of the conv2 rows of the points 0, N/4, N/2, 3N/4, plain fp32 (any vector would do -- it shifts
 // every score of a channel by the same w.c -- but one close to the rows makes the fp16 residuals, hence the bounds, small).
 // One workgroup takes CENTER_SPB samples: W2 (32 KB) is staged in the LDS once (transposed, conflict-free) for all of them.
-constexpr int CENTER_SPB = 8;
+constexpr int CENTER_SPB = 4;                             // (8: 80 us per launch of 3 641 samples, 4: 61, 2: 64, 1: 65 -- round 6)
 template <int C>
 __global__ __launch_bounds__(256) void pn_center_kernel(const float* __restrict__ pc, const float* __restrict__ trans, int N, long B,
                                                         const float* __restrict__ W1, const float* __restrict__ b1,
