@@ -152,7 +152,6 @@ def check_lines(lines, strict=False, name="?"):
                 if "vcc" in mods:
                     src.add(("vcc",))
         elif kind == "lds":
-            wr = not op.startswith(("ds_write", "ds_add_u32", "ds_add_f32", "ds_max_", "ds_min_", "ds_or_", "ds_and_")) or "_rtn" in op
             if op.startswith(("ds_read", "ds_swizzle", "ds_bpermute", "ds_permute")) or "_rtn" in op:
                 dst = regs(ops[0]); src = set().union(*[regs(o) for o in ops[1:]]) if len(ops) > 1 else set()
             else:

@@ -52,7 +52,6 @@ def blocks(body):
     return [(n, [x for x in c if x]) for n, c in out]
 
 
-INF = 1 << 20
 ORIGIN = {}          # (kind, reg) -> text of the most recently analysed load into it (diagnostics only)
 
 
