@@ -92,6 +92,15 @@ def test_bench_rccl_world_size_one(single):
     assert single["config"]["rccl_ranks_seen"] is None, "no communicator is made without a process group"
 
 
+def test_bench_exits_nonzero_when_the_rccl_bootstrap_does_not_return_in_time():
+    """dvq_comm_init (ncclCommInitRank behind the C ABI) runs under DVQ_COMM_TIMEOUT: a bootstrap that does not return in time -- here
+    a limit no real call can meet -- ends the process with exit code 70 and a line on stderr instead of hanging the job."""
+    e = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_port(), DVQ_COMM_TIMEOUT="0.000001", DVQ_BENCH_LOG_DIR=tempfile.mkdtemp(prefix="dvq_bench_logs_"))
+    r = subprocess.run(list(BENCH) + ["--gpus", "1", "--force-pg", "--backend", "nccl"], env=e, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 70, (r.returncode, r.stderr[-1500:])
+    assert "did not return within the time limit" in r.stderr
+
+
 def _generate(out_dir, nproc):
     script = os.path.join(ROOT, "d-vqvae_amd", "gen_diverse_grasp_ho3d.py")
     args = ["--num_objects", "3", "--num_grasp", "5", "--points", "512", "--seed", "7", "--out_dir", out_dir,
